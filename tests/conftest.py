@@ -1,0 +1,39 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU tests are selected with -m gpu; without a device they are skipped, not failed."""
+    have = None
+    for item in items:
+        if "gpu" in item.keywords:
+            if have is None:
+                try:
+                    from graph_learning_amd import _lib
+                    have = _lib.device_count() > 0
+                except Exception:  # library missing or no HIP runtime
+                    have = False
+            if not have:
+                item.add_marker(pytest.mark.skip(reason="no MI355X visible"))

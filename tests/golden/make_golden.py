@@ -1,0 +1,242 @@
+"""Generate the golden vectors that pin the oracle (and through it the HIP path).
+
+Run ONLY in the build container, where the reference is mounted read-only:
+
+    PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports the real reference (``graph_learn``), runs it on small seeded inputs
+and stores inputs + outputs as ``.npz`` files next to this script.  Only data
+is stored -- no reference source travels.  The GPU box never runs this file.
+Versions used: see the ``versions`` entry written into every file.
+"""
+
+import os
+import sys
+
+import numpy as np
+import scipy
+from numpy.random import default_rng
+from scipy.spatial.distance import pdist, squareform
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+
+from graph_learn import lgmrf as ref_lgmrf  # noqa: E402
+from graph_learn import operators as ref_ops  # noqa: E402
+from graph_learn import smooth_learning as ref_sl  # noqa: E402
+from graph_learn.evaluation import relative_error as ref_relerr  # noqa: E402
+from graph_learn.sampling.graphs import sample_er_laplacian  # noqa: E402
+from graph_learn.sampling.signals import sample_lgmrf  # noqa: E402
+from graph_learn.temporal.smooth import WindowLogModel  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+VERS = np.array([f"numpy {np.__version__}", f"scipy {scipy.__version__}",
+                 "reference LTS4/graph-learning @ 2024-12-20"])
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, versions=VERS, **arrays)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def smooth_signals(n, d, seed, p=None):
+    """ER Laplacian + LGMRF signals, exactly as tests/test_clustering.py builds them."""
+    rng = default_rng(seed)
+    lap = sample_er_laplacian(n, (6.0 / n) if p is None else p, 0.3, 2.0, seed=rng)
+    return sample_lgmrf(lap, d, seed=rng), lap
+
+
+def raw_iterates(z, alpha, beta, iters, step_size=0.5, edge_init=None):
+    """w and dvar after exactly k iterations: run the reference with tol=0 (never
+    breaks: rel < 0 is impossible) and edge_tol=-inf (threshold disabled), and
+    recover dvar = S w_k ... no: dvar is a separate variable, not S w.  The
+    reference does not return it, so only w is captured here; dvar is pinned
+    through the next iterate (w_{k+1} depends on dvar_k)."""
+    out = {}
+    for k in iters:
+        ei = None if edge_init is None else edge_init.copy()
+        w = ref_sl.gsp_learn_graph_log_degrees(z, alpha, beta, edge_init=ei, maxit=k, tol=0.0,
+                                               step_size=step_size, edge_tol=-np.inf)
+        out[k] = squareform(w, checks=False)
+    return out
+
+
+def count_iterations(fn):
+    """Number of loop iterations the reference ran = norm calls / 4 + 1
+    (4 per iteration for i > 0, smooth_learning.py:158-159)."""
+    calls = {"n": 0}
+    real = np.linalg.norm
+
+    def spy(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    np.linalg.norm = spy
+    try:
+        res = fn()
+    finally:
+        np.linalg.norm = real
+    return res, calls["n"] // 4 + 1
+
+
+def gen_logmodel():
+    iters = (1, 2, 3, 10, 50, 200)
+    for n, d, seed in ((7, 23, 11), (16, 40, 12), (64, 256, 1234)):
+        x, lap = smooth_signals(n, d, seed)
+        z = pdist(x.T) ** 2
+        arrays = {"x": x, "laplacian": lap, "z": z}
+        for k in (None, 2, 5, 6):
+            if k is not None and k >= n:
+                continue
+            m = ref_sl.LogModel(avg_degree=k)
+            m._initialize(x)
+            arrays[f"theta_deg{k}"] = np.float64(m.theta_)
+        deg = 6 if n > 7 else 2
+        theta = float(arrays[f"theta_deg{deg}"])
+        zt = z * theta
+        its = iters + ((2000,) if n <= 16 else ())
+        for k, w in raw_iterates(zt, 1, 1, its).items():
+            arrays[f"raw_w_it{k}"] = w
+        # defaults (maxit 1000, tol 1e-5, edge_tol 1e-3)
+        (model, n_it) = count_iterations(lambda: ref_sl.LogModel(avg_degree=deg).fit(x))
+        arrays["weights_default"] = model.weights_
+        arrays["n_iter_default"] = np.int64(n_it)
+        arrays["deg"] = np.int64(deg)
+        # converge mode with generous maxit
+        (w_conv, n_conv) = count_iterations(
+            lambda: ref_sl.gsp_learn_graph_log_degrees(zt, 1, 1, maxit=20000, tol=1e-5, edge_tol=-np.inf))
+        arrays["raw_w_converged"] = squareform(w_conv, checks=False)
+        arrays["n_iter_converged"] = np.int64(n_conv)
+        # non-unit alpha/beta/step
+        arrays["raw_w_a2_b05_s03_it50"] = squareform(
+            ref_sl.gsp_learn_graph_log_degrees(zt, 2.0, 0.5, maxit=50, tol=0.0, step_size=0.3,
+                                               edge_tol=-np.inf), checks=False)
+        # warm start
+        rng = default_rng(seed + 1000)
+        ei = rng.uniform(0, 0.2, size=z.shape) * (rng.uniform(size=z.shape) < 0.3)
+        arrays["edge_init"] = ei
+        arrays["raw_w_warm_it30"] = raw_iterates(zt, 1, 1, (30,), edge_init=ei)[30]
+        save(f"logmodel_n{n}_d{d}", **arrays)
+
+
+def gen_batched():
+    """2-D (B, E) path with its spectral-norm stopping rule (smooth_learning.py:128-129,158-159)."""
+    x, _ = smooth_signals(12, 60, 21)
+    xs = x.reshape(3, 20, 12)
+    z = np.stack([pdist(xx.T) ** 2 for xx in xs])
+    out_fixed = ref_sl.gsp_learn_graph_log_degrees(z.copy(), 1, 1, maxit=40, tol=0.0, edge_tol=-np.inf)
+    (out_conv, n_it) = count_iterations(
+        lambda: ref_sl.gsp_learn_graph_log_degrees(z.copy(), 1, 1, maxit=5000, tol=1e-4, edge_tol=1e-3))
+    data = default_rng(240920).standard_normal((23, 7))
+    wl = WindowLogModel(window_size=5, avg_degree=2).fit(data)
+    wz = WindowLogModel(window_size=5, avg_degree=2)._initialize(data)
+    save("batched_B3_n12", z=z, raw_w_it40=out_fixed, w_converged=out_conv, n_iter_converged=np.int64(n_it),
+         win_x=data, win_theta=np.asarray(wl.theta_), win_weights=wl.weights_, win_z=wz)
+
+
+def gen_theta():
+    rng = default_rng(5)
+    z = squareform(pdist(rng.standard_normal((30, 4))) ** 2)
+    # a row with ties: duplicate two points
+    pts = rng.standard_normal((20, 3))
+    pts[3] = pts[7]
+    pts[11] = pts[7]
+    zt = squareform(pdist(pts) ** 2)
+    save("theta", z=z, k=np.array([1, 2, 5, 10]),
+         theta=np.array([ref_sl.get_theta(z, k) for k in (1, 2, 5, 10)]),
+         z_ties=zt, k_ties=np.array([3, 4]),
+         theta_ties=np.array([ref_sl.get_theta(zt, k) for k in (3, 4)]))
+
+
+def gen_sum_squareform():
+    arrays = {}
+    for n in (2, 3, 5, 8, 33):
+        s, st = ref_sl.sum_squareform(n)
+        arrays[f"S_{n}"] = s.toarray()
+        arrays[f"S_{n}_indptr"] = s.indptr
+        arrays[f"S_{n}_indices"] = s.indices
+        arrays[f"St_{n}_indptr"] = st.indptr
+        arrays[f"St_{n}_indices"] = st.indices
+    save("sum_squareform", **arrays)
+
+
+def gen_lgmrf():
+    arrays = {}
+    for n in (8, 16, 32):
+        rng = default_rng(7)
+        lap = sample_er_laplacian(n, 6.0 / n if n > 8 else 0.5, 0.3, 2.0, seed=rng)
+        prec = lap + np.eye(n)
+        x = rng.multivariate_normal(np.zeros(n), np.linalg.inv(prec), size=40 * n)
+        cov = x.T @ x / x.shape[0]
+        arrays[f"cov_{n}"] = cov
+        for npar in (1, 10):
+            for rt in (1, 2):
+                if n == 32 and (npar, rt) != (1, 1):
+                    continue
+                m = ref_lgmrf.LGMRF(norm_par=npar, regularization_type=rt).fit(cov.copy())
+                arrays[f"lapl_{n}_np{npar}_rt{rt}"] = m.laplacian_
+                arrays[f"inv_{n}_np{npar}_rt{rt}"] = m.inv_laplacian_
+                arrays[f"conv_{n}_np{npar}_rt{rt}"] = np.int64(m.converged_)
+        if n == 16:
+            mask = (rng.uniform(size=(n, n)) < 0.6).astype(float)
+            mask = np.triu(mask, 1)
+            mask = mask + mask.T + np.eye(n)
+            m = ref_lgmrf.LGMRF(adj_mask=mask.copy()).fit(cov.copy())
+            arrays["mask_16"] = mask
+            arrays["lapl_16_mask"] = m.laplacian_
+            arrays["inv_16_mask"] = m.inv_laplacian_
+            arrays["conv_16_mask"] = np.int64(m.converged_)
+            # capped cycles (never converges in 3)
+            m = ref_lgmrf.LGMRF(max_cycle=3).fit(cov.copy())
+            arrays["lapl_16_cyc3"] = m.laplacian_
+            arrays["conv_16_cyc3"] = np.int64(m.converged_)
+    # direct QP pairs
+    rng = default_rng(99)
+    for tag, m_, tol, mi in (("a", 6, 1e-6, 100), ("b", 20, 1e-6, 100), ("c", 20, 1e-14, 7)):
+        a = rng.standard_normal((m_, m_))
+        q = a @ a.T / m_ + 0.1 * np.eye(m_)
+        p = rng.standard_normal(m_)
+        arrays[f"qp_{tag}_Q"] = q
+        arrays[f"qp_{tag}_p"] = p
+        arrays[f"qp_{tag}_z"] = ref_lgmrf.nonnegative_qp_solver(q, p, step=0.1, tol=tol, max_iter=mi)
+        arrays[f"qp_{tag}_tol"] = np.float64(tol)
+        arrays[f"qp_{tag}_maxit"] = np.int64(mi)
+    # relative_error, both branches
+    a = rng.standard_normal((5, 5))
+    b = rng.standard_normal((5, 5))
+    arrays["re_a"], arrays["re_b"] = a, b
+    arrays["re_ab"] = np.float64(ref_relerr(a, b))
+    arrays["re_0b"] = np.float64(ref_relerr(np.zeros((5, 5)), b))
+    save("lgmrf", **arrays)
+
+
+def gen_operators():
+    """A few seeds of tests/test_operators.py:25-72,209-226 with outputs stored."""
+    arrays = {}
+    for seed in (3, 11, 1):
+        rng = default_rng(seed)
+        n = int(rng.integers(20, 100))
+        k = int(rng.integers(1, 10))
+        w = rng.standard_normal((k, n * (n - 1) // 2))
+        dual = rng.standard_normal((k, n, n))
+        arrays[f"w_{seed}"] = w
+        arrays[f"dual_{seed}"] = dual
+        arrays[f"lap_{seed}"] = ref_ops.laplacian_squareform_vec(w)
+        arrays[f"adj_{seed}"] = ref_ops.laplacian_squareform_adj_vec(dual)
+        arrays[f"opadj_{seed}"] = ref_ops.op_adj_dual(dual)
+        arrays[f"s2v_{seed}"] = ref_ops.square_to_vec(dual)
+    rng = default_rng(3)
+    sig = rng.standard_normal((37, 13))
+    arrays["signals"] = sig
+    arrays["sq_pdiffs"] = ref_ops.squared_pdiffs(sig)
+    save("operators", **arrays)
+
+
+if __name__ == "__main__":
+    gen_sum_squareform()
+    gen_theta()
+    gen_logmodel()
+    gen_batched()
+    gen_lgmrf()
+    gen_operators()

@@ -1,0 +1,191 @@
+"""Pin the CPU oracle against golden vectors produced by the real reference.
+
+The golden files were written by tests/golden/make_golden.py (which imports the
+reference in the build container).  These tests run everywhere, without a GPU.
+"""
+
+import numpy as np
+import pytest
+from scipy.spatial.distance import squareform
+
+from oracle import lgmrf as olg
+from oracle import logdeg as old
+from oracle import operators as oop
+
+
+# ---------------------------------------------------------------- sum_squareform (A3)
+@pytest.mark.parametrize("n", [2, 3, 5, 8, 33])
+def test_degree_operator_structure(golden, n):
+    g = golden("sum_squareform")
+    s, st = old.degree_operator(n)
+    assert np.array_equal(s.toarray(), g[f"S_{n}"])
+    assert np.array_equal(s.indptr, g[f"S_{n}_indptr"])
+    assert np.array_equal(s.indices, g[f"S_{n}_indices"])
+    assert np.array_equal(st.indptr, g[f"St_{n}_indptr"])
+    assert np.array_equal(st.indices, g[f"St_{n}_indices"])
+    assert s.indices.dtype == g[f"S_{n}_indices"].dtype
+
+
+def test_degree_operator_closed_form():
+    n = 9
+    s, st = old.degree_operator(n)
+    w = np.random.default_rng(0).standard_normal(n * (n - 1) // 2)
+    d = np.random.default_rng(1).standard_normal(n)
+    assert np.allclose(s @ w, squareform(w).sum(1))
+    i, j = np.triu_indices(n, 1)
+    assert np.allclose(st @ d, d[i] + d[j])
+
+
+# ---------------------------------------------------------------- get_theta (A2)
+def test_theta_golden(golden):
+    g = golden("theta")
+    for k, ref in zip(g["k"], g["theta"]):
+        with np.errstate(divide="ignore"):
+            got = old.theta_for_degree(g["z"], int(k))
+        assert got == ref or np.isclose(got, ref, rtol=1e-15)
+    for k, ref in zip(g["k_ties"], g["theta_ties"]):
+        with np.errstate(divide="ignore"):
+            got = old.theta_for_degree(g["z_ties"], int(k))
+        assert got == ref
+
+
+# ---------------------------------------------------------------- LogModel (A1, A4-A11)
+CASES = ["logmodel_n7_d23", "logmodel_n16_d40", "logmodel_n64_d256"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_distances_and_theta(golden, case):
+    g = golden(case)
+    z = old.signal_distances(g["x"])
+    assert np.array_equal(z, g["z"])
+    for key in g.files:
+        if key.startswith("theta_deg") and key != "theta_degNone":
+            k = int(key[len("theta_deg"):])
+            assert old.theta_for_degree(squareform(z), k) == float(g[key])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fixed_iteration_iterates_bit_exact(golden, case):
+    g = golden(case)
+    zt = g["z"] * float(g[f"theta_deg{int(g['deg'])}"])
+    ops = old.degree_operator(old.n_nodes_from_edges(zt.size))
+    for key in g.files:
+        if key.startswith("raw_w_it"):
+            k = int(key[len("raw_w_it"):])
+            _, info = old.learn_log_degrees(zt, 1, 1, maxit=k, tol=0.0, edge_tol=-np.inf,
+                                            return_info=True, ops=ops)
+            assert info["n_iter"] == k
+            assert np.array_equal(info["raw"], g[key]), key
+    _, info = old.learn_log_degrees(zt, 2.0, 0.5, maxit=50, tol=0.0, step_size=0.3,
+                                    edge_tol=-np.inf, return_info=True, ops=ops)
+    assert np.array_equal(info["raw"], g["raw_w_a2_b05_s03_it50"])
+    _, info = old.learn_log_degrees(zt, 1, 1, edge_init=g["edge_init"].copy(), maxit=30, tol=0.0,
+                                    edge_tol=-np.inf, return_info=True, ops=ops)
+    assert np.array_equal(info["raw"], g["raw_w_warm_it30"])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_default_fit_and_stopping_iteration(golden, case):
+    g = golden(case)
+    m = old.LogModelOracle(avg_degree=int(g["deg"])).fit(g["x"])
+    assert np.array_equal(m.weights_, g["weights_default"])
+    assert m.info_["n_iter"] == int(g["n_iter_default"])
+    zt = g["z"] * m.theta_
+    _, info = old.learn_log_degrees(zt, 1, 1, maxit=20000, tol=1e-5, edge_tol=-np.inf, return_info=True)
+    assert info["n_iter"] == int(g["n_iter_converged"])
+    assert np.array_equal(info["raw"], g["raw_w_converged"])
+
+
+def test_c1_headline_numbers(golden):
+    """n=64, d=256, seed 1234 -> 471 iterations, theta 0.01121, 445 edges."""
+    g = golden("logmodel_n64_d256")
+    assert int(g["n_iter_converged"]) == 471
+    assert abs(float(g["theta_deg6"]) - 0.01121) < 1e-5
+    assert (g["weights_default"] > 0).sum() // 2 == 445
+
+
+def test_batched_2d_path(golden):
+    g = golden("batched_B3_n12")
+    out, info = old.learn_log_degrees(g["z"].copy(), 1, 1, maxit=40, tol=0.0, edge_tol=-np.inf,
+                                      return_info=True)
+    assert out.shape == g["z"].shape
+    assert np.array_equal(out, g["raw_w_it40"])
+    out, info = old.learn_log_degrees(g["z"].copy(), 1, 1, maxit=5000, tol=1e-4, edge_tol=1e-3,
+                                      return_info=True)
+    assert info["n_iter"] == int(g["n_iter_converged"])
+    assert np.array_equal(out, g["w_converged"])
+
+
+def test_more_than_2d_raises():
+    with pytest.raises(ValueError, match="vector or matrix"):
+        old.learn_log_degrees(np.zeros((2, 2, 3)), 1, 1)
+
+
+# ---------------------------------------------------------------- LGMRF (B1-B5)
+def test_relative_error(golden):
+    g = golden("lgmrf")
+    assert olg.relative_error(g["re_a"], g["re_b"]) == float(g["re_ab"])
+    assert olg.relative_error(np.zeros((5, 5)), g["re_b"]) == float(g["re_0b"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_qp_solver(golden, tag):
+    g = golden("lgmrf")
+    z = olg.nonneg_qp_admm(g[f"qp_{tag}_Q"], g[f"qp_{tag}_p"], step=0.1, tol=float(g[f"qp_{tag}_tol"]),
+                           max_iter=int(g[f"qp_{tag}_maxit"]))
+    assert np.array_equal(z, g[f"qp_{tag}_z"])
+
+
+@pytest.mark.parametrize("n,npar,rt", [(8, 1, 1), (8, 1, 2), (8, 10, 1), (8, 10, 2), (16, 1, 1),
+                                        (16, 10, 2), (32, 1, 1)])
+def test_lgmrf_fit(golden, n, npar, rt):
+    g = golden("lgmrf")
+    m = olg.LGMRFOracle(norm_par=npar, regularization_type=rt).fit(g[f"cov_{n}"].copy())
+    assert m.converged_ == int(g[f"conv_{n}_np{npar}_rt{rt}"])
+    assert np.array_equal(m.laplacian_, g[f"lapl_{n}_np{npar}_rt{rt}"])
+    assert np.array_equal(m.inv_laplacian_, g[f"inv_{n}_np{npar}_rt{rt}"])
+
+
+def test_lgmrf_mask_and_cycle_cap(golden):
+    g = golden("lgmrf")
+    m = olg.LGMRFOracle(adj_mask=g["mask_16"].copy()).fit(g["cov_16"].copy())
+    assert m.converged_ == int(g["conv_16_mask"])
+    assert np.array_equal(m.laplacian_, g["lapl_16_mask"])
+    assert np.array_equal(m.inv_laplacian_, g["inv_16_mask"])
+    m = olg.LGMRFOracle(max_cycle=3).fit(g["cov_16"].copy())
+    assert m.converged_ == -1 == int(g["conv_16_cyc3"])
+    assert np.array_equal(m.laplacian_, g["lapl_16_cyc3"])
+
+
+def test_lgmrf_errors():
+    x = np.eye(4) + 1.0
+    with pytest.raises(ValueError):
+        olg.LGMRFOracle(laplacian_set="nope").fit(x.copy())
+    with pytest.raises(ValueError):
+        olg.LGMRFOracle(regularization_type=3).fit(x.copy())
+    with pytest.raises(ValueError):
+        olg.LGMRFOracle(adj_mask=np.ones((3, 3))).fit(x.copy())
+    with pytest.raises(NotImplementedError):
+        olg.LGMRFOracle(laplacian_set="c").fit(x.copy())
+
+
+def test_lgmrf_does_not_mutate_input(golden):
+    g = golden("lgmrf")
+    cov = g["cov_8"].copy()
+    olg.LGMRFOracle().fit(cov)
+    assert np.array_equal(cov, g["cov_8"])
+
+
+# ---------------------------------------------------------------- operators (O1-O4)
+@pytest.mark.parametrize("seed", [3, 11, 1])
+def test_operators_golden(golden, seed):
+    g = golden("operators")
+    assert np.array_equal(oop.laplacian_from_vec(g[f"w_{seed}"]), g[f"lap_{seed}"])
+    assert np.array_equal(oop.laplacian_adjoint(g[f"dual_{seed}"]), g[f"adj_{seed}"])
+    assert np.allclose(oop.laplacian_adjoint(g[f"dual_{seed}"]), g[f"opadj_{seed}"], rtol=0, atol=1e-14)
+    assert np.array_equal(oop.square_to_vec(g[f"dual_{seed}"]), g[f"s2v_{seed}"])
+
+
+def test_squared_pdiffs_golden(golden):
+    g = golden("operators")
+    assert np.array_equal(oop.squared_pdiffs(g["signals"]), g["sq_pdiffs"])
