@@ -1,0 +1,158 @@
+#!/usr/bin/env python
+"""Headline benchmark: primal-dual iterations/sec of the LogModel solver.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): LogModel n=4096 nodes, d=1024 samples,
+fp64, synthetic smooth signals (ER graph, X ~ N(0, pinv(L))), avg_degree=10,
+fixed-iteration mode (tol = 0).  One "step" = one primal-dual iteration
+(graph_learn/smooth_learning.py:146-167) over the whole edge lattice.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank solves
+its own independent problem (weak scaling, seed = rank), no collective on the
+iteration path; RCCL is used for the device barrier around the timed region and
+for the final gather of the learned adjacencies (BASELINE config 4).
+
+Prints ONE JSON line on rank 0.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md), the roofline the edge pass is bound by
+
+
+def algorithmic_bytes_per_iteration(n: int) -> int:
+    """read w, read z, write w over E = n(n-1)/2 fp64 edges = 24 E bytes."""
+    return 12 * n * (n - 1)
+
+
+def cpu_baseline(z_scaled: np.ndarray, budget_its=(3, 13)):
+    """Oracle (NumPy/SciPy restatement with the reference's CSR strategy) on the host cores:
+    (t(13 its) - t(3 its)) / 10, which excludes the one-time operator build."""
+    from oracle import logdeg as old
+
+    n = old.n_nodes_from_edges(z_scaled.size)
+    ops = old.degree_operator(n)
+
+    def run(k):
+        t = time.perf_counter()
+        old.learn_log_degrees(z_scaled, 1, 1, maxit=k, tol=0.0, edge_tol=-np.inf, ops=ops)
+        return time.perf_counter() - t
+
+    lo, hi = budget_its
+    t_lo, t_hi = run(lo), run(hi)
+    per_it = (t_hi - t_lo) / (hi - lo)
+    return {"value": 1.0 / per_it, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"same n={n} problem, ({hi}-{lo}) iterations of the NumPy/SciPy-CSR oracle, single thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--nodes", type=int, default=4096)
+    ap.add_argument("--samples", type=int, default=1024)
+    ap.add_argument("--avg-degree", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    from graph_learning_amd import _lib
+    from graph_learning_amd.synth import logmodel_problem
+
+    comm = None
+    if world > 1:
+        from graph_learning_amd.batch import make_comm
+
+        comm = make_comm(rank, world, local_rank)
+
+    n, d = args.nodes, args.samples
+    ctx = _lib.Context(local_rank)
+    x, _ = logmodel_problem(n, d, seed=rank)
+
+    sess = _lib.LogDegreeSession(n, ctx)
+    t0 = time.perf_counter()
+    theta = sess.set_signals(x, args.avg_degree)       # A1 + A2, inputs now resident in HBM
+    setup_s = time.perf_counter() - t0
+    sess.init(1.0, 1.0, 0.5, None)
+
+    sess.iterate_async(args.warmup)
+    ctx.sync()
+    if comm is not None:
+        comm.barrier()
+    ctx.timer_start()
+    t0 = time.perf_counter()
+    sess.iterate_async(args.steps)
+    gpu_ms = ctx.timer_stop()                            # HIP events on the solver's stream (+ sync)
+    wall_s = time.perf_counter() - t0
+    if comm is not None:
+        comm.barrier()
+        wall_s = comm.max_over_ranks(wall_s)
+        gpu_ms = comm.max_over_ranks(gpu_ms)
+
+    gather_s = None
+    if comm is not None and not args.no_gather:
+        t0 = time.perf_counter()
+        gathered = comm.allgather_condensed(sess, edge_tol=1e-3)
+        gather_s = comm.max_over_ranks(time.perf_counter() - t0)
+        assert gathered.shape == (world, n * (n - 1) // 2)
+
+    if rank == 0:
+        its_per_s = world * args.steps / wall_s
+        bytes_it = algorithmic_bytes_per_iteration(n)
+        launch_us = gpu_ms * 1e3 / args.steps
+        achieved = bytes_it / (launch_us * 1e-6) / 1e9
+        out = {
+            "metric": "primal-dual iterations/sec, LogModel n=4096 d=1024",
+            "value": its_per_s,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall_s * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"LogModel fixed-iteration loop n={n} d={d} avg_degree={args.avg_degree} "
+                                   f"(BASELINE configs[1]); one independent problem per GPU",
+                       "edges": n * (n - 1) // 2, "theta": theta, "setup_s_distances_theta": setup_s,
+                       "gather_s": gather_s},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_edge<false> (+ k_node, per iteration)",
+                         "algorithmic_bytes_per_launch": bytes_it, "avg_launch_us": launch_us},
+        }
+        if not args.no_cpu_baseline:
+            z = sess.get_distances() * theta
+            out["cpu_baseline"] = cpu_baseline(z)
+        print(json.dumps(out), flush=True)
+    sess.close()
+    if comm is not None:
+        comm.close()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

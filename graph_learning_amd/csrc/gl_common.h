@@ -1,0 +1,80 @@
+// Internal declarations shared by the HIP translation units of libgraphlearn_amd.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "graphlearn_amd.h"
+
+#define GL_API extern "C" __attribute__((visibility("default")))
+
+// ---------------------------------------------------------------------------
+// Context: one GPU, one stream, a last-error string and a pair of timer events.
+struct gl_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    hipDeviceProp_t prop;
+    // small pinned host staging area for status words / reductions
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
+};
+
+int gl_set_error(gl_ctx *ctx, int code, const char *fmt, ...);
+
+#define GL_HIP(ctx, call)                                                                   \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return gl_set_error((ctx), e_ == hipErrorOutOfMemory ? GL_E_NOMEM : GL_E_HIP,   \
+                                "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),      \
+                                __FILE__, __LINE__);                                        \
+    } while (0)
+
+#define GL_TRY(expr)              \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != GL_OK) return rc_; \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// Tiled layout of the upper-triangular edge lattice (DESIGN.md "Data layout").
+//   TB x TB tiles over block pairs (I <= J), tile id t(I,J) = I*nb - I(I-1)/2 + (J-I),
+//   each tile row-major TB*TB doubles; element (r,c) <-> edge (I*TB+r, J*TB+c),
+//   meaningful iff i < j < n, otherwise stored as 0.
+constexpr int GL_TB = 64;
+constexpr int GL_TILE_ELEMS = GL_TB * GL_TB;
+
+static inline int64_t gl_num_blocks(int64_t n) { return (n + GL_TB - 1) / GL_TB; }
+static inline int64_t gl_num_tiles(int64_t n) {
+    int64_t nb = gl_num_blocks(n);
+    return nb * (nb + 1) / 2;
+}
+
+__host__ __device__ static inline int64_t gl_tile_id(int64_t I, int64_t J, int64_t nb) {
+    return I * nb - I * (I - 1) / 2 + (J - I);
+}
+
+// inverse of gl_tile_id: largest I with I*nb - I(I-1)/2 <= t
+__host__ __device__ static inline void gl_tile_decode(int64_t t, int64_t nb, int &I, int &J) {
+    // solve I^2 - (2nb+1) I + 2t >= 0  ->  I = floor(((2nb+1) - sqrt((2nb+1)^2 - 8t)) / 2)
+    double b = 2.0 * (double)nb + 1.0;
+    int64_t i = (int64_t)((b - sqrt(b * b - 8.0 * (double)t)) * 0.5);
+    if (i < 0) i = 0;
+    if (i > nb - 1) i = nb - 1;
+    while (i > 0 && i * nb - i * (i - 1) / 2 > t) --i;
+    while (i + 1 < nb && (i + 1) * nb - (i + 1) * i / 2 <= t) ++i;
+    I = (int)i;
+    J = (int)(t - (i * nb - i * (i - 1) / 2) + i);
+}
+
+__host__ __device__ static inline int64_t gl_condensed_index(int64_t i, int64_t j, int64_t n) {
+    return i * (2 * n - i - 1) / 2 + (j - i - 1);
+}

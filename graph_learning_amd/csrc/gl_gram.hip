@@ -1,0 +1,129 @@
+// Squared pairwise distances between the columns of the signal matrix.
+//
+// Reference: LogModel._initialize, graph_learn/smooth_learning.py:278
+//     sq_pdists = pdist(x.T) ** 2            (x is (d samples, n nodes))
+// Here: z_ij = G_ii + G_jj - 2 G_ij with the Gram matrix G = Xc^T Xc computed on
+// the fp64 matrix cores (v_mfma_f64_16x16x4_f64) -- the one dense contraction of
+// the hot path.  Xc = X minus the per-sample mean over nodes: pairwise
+// differences are unchanged, but the cancellation in G_ii + G_jj - 2 G_ij is
+// taken on centred data.  G is bitwise symmetric and G_ii comes out of the same
+// accumulation chain as G_ij, so coincident columns give z = 0 exactly and the
+// diagonal is exactly 0.
+#include "gl_logdeg.h"
+
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int GT = 64;   // output tile edge
+constexpr int GK = 16;   // samples per LDS stage
+constexpr int GLD = 80;  // LDS row stride in doubles (64 + 16: ds_read_b64 conflict-free)
+
+// x[t][:] -= mean_j x[t][j]   (one workgroup per sample)
+__global__ __launch_bounds__(256) void k_center_rows(double *__restrict__ x, int64_t d, int64_t n) {
+    __shared__ double s_part[256];
+    const int64_t t = blockIdx.x;
+    double *row = x + t * n;
+    double acc = 0;
+    for (int64_t j = threadIdx.x; j < n; j += 256) acc += row[j];
+    s_part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) s_part[threadIdx.x] += s_part[threadIdx.x + s];
+        __syncthreads();
+    }
+    const double mean = s_part[0] / (double)n;
+    for (int64_t j = threadIdx.x; j < n; j += 256) row[j] -= mean;
+}
+
+// G[I*64.., J*64..] = sum_t x[t][i] x[t][j].  4 waves in a 2x2 arrangement, each
+// 32x32 outputs = 2x2 MFMA accumulators of 16x16.
+__global__ __launch_bounds__(256) void k_gram(const double *__restrict__ x, int64_t d, int64_t n,
+                                             double *__restrict__ G) {
+    __shared__ double As[GK][GLD];
+    __shared__ double Bs[GK][GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t i0 = (int64_t)blockIdx.y * GT, j0 = (int64_t)blockIdx.x * GT;
+    const int lrow = tid >> 4;        // 0..15  sample within the stage
+    const int lcol = (tid & 15) * 4;  // 0..60  node within the tile
+
+    v4d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    for (int64_t t0 = 0; t0 < d; t0 += GK) {
+        const int64_t t = t0 + lrow;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t ia = i0 + lcol + e, jb = j0 + lcol + e;
+            As[lrow][lcol + e] = (t < d && ia < n) ? x[t * n + ia] : 0.0;
+            Bs[lrow][lcol + e] = (t < d && jb < n) ? x[t * n + jb] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GK / 4; ++kk) {
+            const int kr = kk * 4 + (lane >> 4);
+            double a[2], b[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                a[m] = As[kr][wm * 32 + m * 16 + (lane & 15)];
+                b[m] = Bs[kr][wn * 32 + m * 16 + (lane & 15)];
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t i = i0 + wm * 32 + mi * 16 + (lane >> 4) + 4 * r;
+                const int64_t j = j0 + wn * 32 + ni * 16 + (lane & 15);
+                if (i < n && j < n) G[i * n + j] = acc[mi][ni][r];
+            }
+}
+
+__global__ void k_take_diag(const double *__restrict__ G, int64_t n, double *__restrict__ diag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) diag[i] = G[i * n + i];
+}
+
+// in place: G_ij <- max(G_ii + G_jj - 2 G_ij, +0)
+__global__ void k_gram_to_dist(double *__restrict__ G, int64_t n, const double *__restrict__ diag) {
+    const int64_t i = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) {
+        const double z = (diag[i] + diag[j]) - 2 * G[i * n + j];
+        G[i * n + j] = z > 0 ? z : 0.0;
+    }
+}
+
+}  // namespace
+
+// x_dev (d x n) is centred IN PLACE; zsq_dev receives the n x n squared distances.
+int gl_gram_distances(gl_ctx *ctx, const double *x_dev, int64_t d, int64_t n, double *zsq_dev) {
+    double *x = const_cast<double *>(x_dev);
+    double *diag = nullptr;
+    GL_HIP(ctx, hipMalloc((void **)&diag, (size_t)n * 8));
+    k_center_rows<<<dim3((unsigned)d), dim3(256), 0, ctx->stream>>>(x, d, n);
+    const unsigned nb = (unsigned)((n + GT - 1) / GT);
+    k_gram<<<dim3(nb, nb), dim3(256), 0, ctx->stream>>>(x, d, n, zsq_dev);
+    k_take_diag<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(zsq_dev, n, diag);
+    k_gram_to_dist<<<dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, ctx->stream>>>(zsq_dev, n, diag);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(diag);
+    if (e != hipSuccess) return gl_set_error(ctx, GL_E_HIP, "gram/distance kernels: %s", hipGetErrorString(e));
+    return GL_OK;
+}

@@ -1,0 +1,125 @@
+/*
+ * graphlearn_amd.h -- C ABI of the MI355X-native graph-learning hot path.
+ *
+ * The reference (LTS4/graph-learning) is pure Python and has no FFI layer; the
+ * entry points below are what a ctypes binding for its hot path binds to.  Each
+ * one cites the reference interface it replaces (paths relative to the
+ * reference repository root).  See INTEGRATION.md for the reference-side stub.
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = GL_OK, < 0 = error (below);
+ *   - all host buffers are caller-owned, C-contiguous, float64 unless stated,
+ *     valid for the duration of the call only; nothing returned is
+ *     library-allocated except the opaque handles;
+ *   - edge vectors use SciPy "condensed" order: edge (i,j), i<j, at
+ *     i*(2n-i-1)/2 + (j-i-1)   (graph_learn/operators.py:39-41);
+ *   - a gl_ctx is bound to one GPU and one HIP stream and is not thread-safe;
+ *     distinct contexts are independent (one problem per GPU, one thread or
+ *     process per context);
+ *   - there is NO CPU fallback: without a gfx950 device gl_ctx_create fails.
+ */
+#ifndef GRAPHLEARN_AMD_H
+#define GRAPHLEARN_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GL_VERSION 100 /* 0.1.0 */
+
+enum {
+    GL_OK = 0,
+    GL_E_INVALID = -1,   /* bad argument            -> Python ValueError   */
+    GL_E_NOMEM = -2,     /* device/host allocation  -> Python MemoryError  */
+    GL_E_HIP = -3,       /* HIP runtime error       -> Python RuntimeError */
+    GL_E_NONFINITE = -4, /* NaN/Inf met where the algorithm cannot go on   */
+    GL_E_NODEVICE = -5,  /* no usable gfx950 device                         */
+    GL_E_COMM = -6,      /* RCCL error                                      */
+    GL_E_STATE = -7      /* call sequence error (e.g. iterate before init)  */
+};
+
+typedef struct gl_ctx gl_ctx;
+typedef struct gl_logdeg gl_logdeg;
+
+/* ---- library / context ------------------------------------------------- */
+int gl_version(void);
+const char *gl_strerror(int code);
+int gl_device_count(int *count);
+int gl_ctx_create(int device, gl_ctx **out);
+int gl_ctx_destroy(gl_ctx *ctx);
+const char *gl_last_error(gl_ctx *ctx);
+int gl_ctx_device_name(gl_ctx *ctx, char *buf, int buflen);
+int gl_ctx_sync(gl_ctx *ctx);
+/* HIP-event timer on the context's stream (bench.py's timed region). */
+int gl_ctx_timer_start(gl_ctx *ctx);
+int gl_ctx_timer_stop(gl_ctx *ctx, double *elapsed_ms);
+
+/* ---- log-degree solver session (LogModel hot path) ----------------------
+ * Replaces the body of gsp_learn_graph_log_degrees
+ * (graph_learn/smooth_learning.py:47-174) and LogModel._initialize / fit
+ * (:277-300), split into stages so that inputs can be made resident in HBM
+ * before a timed region:
+ *   create -> set_signals | set_distances -> init -> iterate* -> get_weights_*
+ */
+int gl_logdeg_create(gl_ctx *ctx, int64_t n_nodes, gl_logdeg **out);
+int gl_logdeg_destroy(gl_logdeg *s);
+
+/* A1+A2: squared pairwise distances between the COLUMNS of x (d x n,
+ * row-major) via an fp64 MFMA Gram contraction, then theta for `avg_degree`
+ * (get_theta, smooth_learning.py:201-219; avg_degree <= 0 means theta = 1,
+ * :279-280), then z*theta is laid out in the solver's tiled HBM layout.
+ * theta_out may be NULL. */
+int gl_logdeg_set_signals(gl_logdeg *s, const double *x, int64_t d, int64_t n_nodes,
+                          int avg_degree, double *theta_out);
+/* Distances given directly (condensed, already scaled), as the free function
+ * of the reference takes them (smooth_learning.py:48). */
+int gl_logdeg_set_distances(gl_logdeg *s, const double *z_condensed);
+/* Download what set_signals computed: condensed squared distances BEFORE the
+ * theta scaling (pdist(x.T)**2, smooth_learning.py:278). */
+int gl_logdeg_get_distances(gl_logdeg *s, double *z_condensed);
+
+/* A4+A5: gamma = step_size/(2 beta + sqrt(2(n-1))) (:135-137); w = edge_init
+ * (condensed, may be NULL = zeros) and dvar = S w (:140-144). */
+int gl_logdeg_init(gl_logdeg *s, double alpha, double beta, double step_size,
+                   const double *edge_init);
+
+/* A6-A9: run up to `maxit` further iterations of the loop (:146-167); stops
+ * early exactly like the reference when both relative changes < tol (never at
+ * the session's first iteration).  n_iter_out = iterations done by THIS call;
+ * converged_out = 1 if the stopping rule fired; rel_out[2] = last relative
+ * primal/dual change.  Any out pointer may be NULL. */
+int gl_logdeg_iterate(gl_logdeg *s, int64_t maxit, double tol, int64_t *n_iter_out,
+                      int *converged_out, double *rel_out);
+/* Same loop, enqueued without any host synchronisation or convergence poll
+ * (tol = 0 semantics): used by bench.py inside its event-timed region. */
+int gl_logdeg_iterate_async(gl_logdeg *s, int64_t n_iter);
+
+/* A10: w[w < edge_tol] = 0 (:169) applied on the way out (the resident
+ * iterate is not modified); condensed (E) or symmetric square (n x n, zero
+ * diagonal, = squareform(w), :171-172).  edge_tol = -inf disables it. */
+int gl_logdeg_get_weights_condensed(gl_logdeg *s, double edge_tol, double *w_out);
+int gl_logdeg_get_weights_square(gl_logdeg *s, double edge_tol, double *w_out);
+/* Dual variable dvar (n) -- for checkpoint/resume and the parity tests. */
+int gl_logdeg_get_dual(gl_logdeg *s, double *d_out);
+int64_t gl_logdeg_total_iterations(gl_logdeg *s);
+
+/* One-shot forms (what the reference-side binding calls). */
+/* gsp_learn_graph_log_degrees(distances, alpha, beta, edge_init, maxit, tol,
+ * step_size, edge_tol) for 1-D input -> condensed weights (E). */
+int gl_log_degrees_fit(gl_ctx *ctx, const double *z_condensed, int64_t n_nodes, double alpha,
+                       double beta, const double *edge_init, int64_t maxit, double tol,
+                       double step_size, double edge_tol, double *w_out_condensed,
+                       int64_t *n_iter_out, double *rel_out);
+/* LogModel(avg_degree, edge_init, maxit, tol, step_size, edge_tol).fit(x):
+ * x is (d, n) row-major; weights_out is n x n; alpha = beta = 1 (:289-298). */
+int gl_logmodel_fit_signals(gl_ctx *ctx, const double *x, int64_t d, int64_t n_nodes,
+                            int avg_degree, const double *edge_init, int64_t maxit, double tol,
+                            double step_size, double edge_tol, double *weights_out,
+                            double *theta_out, int64_t *n_iter_out, double *rel_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPHLEARN_AMD_H */

@@ -1,0 +1,215 @@
+"""Parity of the HIP log-degree path (through the C ABI) against the oracle and
+the golden vectors of the reference.  All tests here need an MI355X.
+
+Tolerances (fp64): the per-edge arithmetic is bit-identical to NumPy; only the
+order of the degree sums / norm sums differs, so fixed-iteration iterates agree
+to ~1e-15.  The contract checked is SURVEY.md section 7 "Parity definition":
+  (i)   fixed-iteration, un-thresholded iterates: atol 1e-10
+  (ii)  thresholded output: equal except where the oracle's raw value is within
+        atol of edge_tol
+  (iii) converge mode stops within +-1 iteration of the oracle.
+"""
+
+import numpy as np
+import pytest
+from scipy.spatial.distance import squareform
+
+from graph_learning_amd import LogModel, gsp_learn_graph_log_degrees
+from graph_learning_amd import _lib
+from graph_learning_amd.synth import logmodel_problem
+from oracle import logdeg as old
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-10
+CASES = ["logmodel_n7_d23", "logmodel_n16_d40", "logmodel_n64_d256"]
+
+
+def raw_iterate(z, alpha, beta, k, step_size=0.5, edge_init=None):
+    n = old.n_nodes_from_edges(z.size)
+    with _lib.LogDegreeSession(n) as s:
+        s.set_distances(z)
+        s.init(alpha, beta, step_size, edge_init)
+        n_it, conv, rel = s.iterate(k, 0.0)
+        assert n_it == k and not conv
+        return s.weights_condensed(), s.dual(), rel
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fixed_iterations_match_reference_golden(golden, case):
+    g = golden(case)
+    zt = g["z"] * float(g[f"theta_deg{int(g['deg'])}"])
+    for key in g.files:
+        if key.startswith("raw_w_it"):
+            k = int(key[len("raw_w_it"):])
+            w, _, _ = raw_iterate(zt, 1, 1, k)
+            np.testing.assert_allclose(w, g[key], rtol=0, atol=ATOL, err_msg=key)
+    w, _, _ = raw_iterate(zt, 2.0, 0.5, 50, step_size=0.3)
+    np.testing.assert_allclose(w, g["raw_w_a2_b05_s03_it50"], rtol=0, atol=ATOL)
+    w, _, _ = raw_iterate(zt, 1, 1, 30, edge_init=g["edge_init"])
+    np.testing.assert_allclose(w, g["raw_w_warm_it30"], rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_distances_and_theta_from_signals(golden, case):
+    g = golden(case)
+    n = g["x"].shape[1]
+    for key in g.files:
+        if not key.startswith("theta_deg"):
+            continue
+        k = None if key.endswith("None") else int(key[len("theta_deg"):])
+        with _lib.LogDegreeSession(n) as s:
+            theta = s.set_signals(g["x"], k)
+            z = s.get_distances()
+        # Gram-form distances vs the reference's direct differences
+        np.testing.assert_allclose(z, g["z"], rtol=1e-11, atol=1e-12 * g["z"].max())
+        assert theta == pytest.approx(float(g[key]), rel=1e-10)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_logmodel_fit_defaults(golden, case):
+    g = golden(case)
+    m = LogModel(avg_degree=int(g["deg"])).fit(g["x"])
+    ref = g["weights_default"]
+    assert m.weights_.shape == ref.shape and m.weights_.dtype == np.float64
+    assert abs(m.n_iter_ - int(g["n_iter_default"])) <= 1
+    assert m.theta_ == pytest.approx(float(g[f"theta_deg{int(g['deg'])}"]), rel=1e-10)
+    # (ii): entries may only differ where the reference value sits at the threshold
+    o = old.LogModelOracle(avg_degree=int(g["deg"])).fit(g["x"])
+    raw = squareform(o.info_["raw"])
+    near = np.abs(raw - 1e-3) < 1e-7
+    np.testing.assert_allclose(m.weights_[~near], ref[~near], rtol=0, atol=1e-7)
+    assert np.array_equal(m.weights_, m.weights_.T) and not m.weights_.diagonal().any()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_converge_mode_stops_like_reference(golden, case):
+    g = golden(case)
+    zt = g["z"] * float(g[f"theta_deg{int(g['deg'])}"])
+    w, info = gsp_learn_graph_log_degrees(zt, 1, 1, maxit=20000, tol=1e-5, edge_tol=-np.inf, return_info=True)
+    assert info["converged"]
+    assert abs(info["n_iter"] - int(g["n_iter_converged"])) <= 1
+    np.testing.assert_allclose(squareform(w, checks=False), g["raw_w_converged"], rtol=0, atol=1e-6)
+    if info["n_iter"] == int(g["n_iter_converged"]):
+        np.testing.assert_allclose(squareform(w, checks=False), g["raw_w_converged"], rtol=0, atol=ATOL)
+
+
+def test_dual_variable_and_rel_changes_match_oracle(golden):
+    g = golden("logmodel_n64_d256")
+    zt = g["z"] * float(g["theta_deg6"])
+    solver = old.FBFSolver(zt, 1, 1)
+    for _ in range(37):
+        rp, rd = solver.step()
+    w, d, rel = raw_iterate(zt, 1, 1, 37)
+    np.testing.assert_allclose(w, solver.w, rtol=0, atol=ATOL)
+    np.testing.assert_allclose(d, solver.d, rtol=0, atol=ATOL)
+    assert rel[0] == pytest.approx(rp, rel=1e-9) and rel[1] == pytest.approx(rd, rel=1e-9)
+
+
+def test_resume_equals_single_run(golden):
+    g = golden("logmodel_n16_d40")
+    zt = g["z"] * float(g["theta_deg6"])
+    with _lib.LogDegreeSession(16) as s:
+        s.set_distances(zt)
+        s.init(1, 1, 0.5, None)
+        s.iterate(13, 0.0)
+        s.iterate(7, 0.0)
+        s.iterate_async(30)
+        assert s.total_iterations == 50
+        w = s.weights_condensed()
+    np.testing.assert_array_equal(w, raw_iterate(zt, 1, 1, 50)[0])  # bit-identical: deterministic
+    np.testing.assert_allclose(w, g["raw_w_it50"], rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 63, 64, 65, 129, 200])
+def test_ragged_sizes_against_oracle(n):
+    """Tile edges: n below / at / just above multiples of the 64-wide tile."""
+    rng = np.random.default_rng(n)
+    e = n * (n - 1) // 2
+    z = rng.uniform(0.05, 3.0, size=e)
+    ei = rng.uniform(0, 0.3, size=e) * (rng.uniform(size=e) < 0.5)
+    ops = old.degree_operator(n)
+    for init in (None, ei):
+        _, info = old.learn_log_degrees(z, 1.3, 0.7, edge_init=None if init is None else init.copy(), maxit=25,
+                                        tol=0.0, edge_tol=-np.inf, return_info=True, ops=ops)
+        w, d, _ = raw_iterate(z, 1.3, 0.7, 25, edge_init=init)
+        np.testing.assert_allclose(w, info["raw"], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(d, info["dual"], rtol=0, atol=ATOL)
+
+
+def test_maxit_zero_returns_thresholded_init():
+    n, e = 9, 36
+    ei = np.linspace(0, 0.01, e)
+    w = gsp_learn_graph_log_degrees(np.ones(e), 1, 1, edge_init=ei.copy(), maxit=0)
+    exp = ei.copy()
+    exp[exp < 1e-3] = 0
+    np.testing.assert_array_equal(w, squareform(exp))
+
+
+def test_errors():
+    with pytest.raises(ValueError, match="vector or matrix"):
+        gsp_learn_graph_log_degrees(np.zeros((2, 2, 3)), 1, 1)
+    with pytest.raises(ValueError):
+        gsp_learn_graph_log_degrees(np.ones(10), 1, 1, edge_init=np.ones(9))
+    with pytest.raises(ValueError):
+        LogModel(avg_degree=2).fit(np.ones(5))
+    with pytest.raises(ValueError):
+        LogModel(avg_degree=7).fit(np.random.default_rng(0).standard_normal((10, 7)))
+
+
+def test_sklearn_surface():
+    m = LogModel(avg_degree=3, maxit=10)
+    assert m.get_params() == {"avg_degree": 3, "edge_init": None, "maxit": 10, "tol": 1e-5, "step_size": 0.5,
+                              "edge_tol": 1e-3}
+    m.set_params(tol=1e-3)
+    assert m.tol == 1e-3
+    x = np.random.default_rng(240920).standard_normal((23, 7))   # the reference's tests/test_models.py fixture
+    m.fit(x)
+    assert m.weights_.shape == (7, 7) and isinstance(m.theta_, float)
+    assert LogModel().fit(x).theta_ == 1
+
+
+# ------------------------------------------------------------------ BASELINE sizes
+def test_c2_size_five_iterations_against_oracle():
+    """n=4096, d=1024 (BASELINE config 2): distances, theta and 5 iterations vs the oracle."""
+    x, _ = logmodel_problem(4096, 1024, seed=0)
+    z_ref = old.signal_distances(x)
+    theta_ref = old.theta_for_degree(squareform(z_ref), 10)
+    with _lib.LogDegreeSession(4096) as s:
+        theta = s.set_signals(x, 10)
+        z = s.get_distances()
+        np.testing.assert_allclose(z, z_ref, rtol=1e-10, atol=1e-12 * z_ref.max())
+        assert theta == pytest.approx(theta_ref, rel=1e-10)
+        # iterate on the oracle's own z*theta so that both sides see identical inputs
+        s.set_distances(z_ref * theta_ref)
+        s.init(1, 1, 0.5, None)
+        s.iterate(5, 0.0)
+        w = s.weights_condensed()
+        d = s.dual()
+    _, info = old.learn_log_degrees(z_ref * theta_ref, 1, 1, maxit=5, tol=0.0, edge_tol=-np.inf, return_info=True)
+    np.testing.assert_allclose(w, info["raw"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(d, info["dual"], rtol=0, atol=ATOL)
+
+
+def test_c2_size_properties_after_many_iterations():
+    """Size-independent properties at n=4096 after 300 iterations: determinism, dual = prox
+    fixed-point structure (dvar < 0), symmetry of the square output, degree identity."""
+    x, _ = logmodel_problem(4096, 256, seed=3)
+    outs = []
+    for _ in range(2):
+        with _lib.LogDegreeSession(4096) as s:
+            s.set_signals(x, 10)
+            s.init(1, 1, 0.5, None)
+            s.iterate(300, 0.0)
+            outs.append((s.weights_condensed(), s.dual(), s.weights_square(1e-3)))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    w, d, sq = outs[0]
+    assert np.isfinite(w).all() and np.isfinite(d).all()
+    assert (d < 0).all()                       # dual of -log: strictly negative
+    assert np.array_equal(sq, sq.T) and not sq.diagonal().any()
+    wt = w.copy()
+    wt[wt < 1e-3] = 0
+    i, j = np.triu_indices(4096, 1)
+    assert np.array_equal(sq[i, j], wt)
+    deg = sq.sum(1)
+    assert (deg > 0).mean() > 0.99             # log barrier keeps (almost) every node connected
