@@ -64,6 +64,11 @@ SIGNATURES = {
     "gl_logmodel_fit_signals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p,
                                           C.c_int64, C.c_double, C.c_double, C.c_double, C.c_void_p, _c_double_p,
                                           _c_int64_p, _c_double_p]),
+    "gl_square_to_vec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "gl_laplacian_from_vec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "gl_laplacian_adjoint": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
+    "gl_squared_pdiffs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "gl_theta_from_distances": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, _c_double_p]),
 }
 
 _lib = None

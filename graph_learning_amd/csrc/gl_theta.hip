@@ -5,8 +5,8 @@
 //   head_i = sum(sorted[i, :k]);  lo_i = (k v_k^2 - head v_k)^-1/2 with v_k = sorted[i, k],
 //   hi_i the same with v_{k-1};  theta = sqrt(mean(lo) * mean(hi)).
 // Only the k+1 smallest entries of each row matter, so instead of sorting, each
-// workgroup runs an exact 8-pass radix select on the IEEE bit patterns (the
-// entries are >= +0, so the patterns order like the values) and then one pass
+// workgroup runs an exact 8-pass radix select on order-preserving keys made
+// from the IEEE bit patterns and then one pass
 // for {count, sum, max} of the entries below v_k.  Ties are handled exactly.
 #include "gl_logdeg.h"
 
@@ -14,7 +14,15 @@
 
 namespace {
 
-__device__ __forceinline__ unsigned long long key_of(double v) { return (unsigned long long)__double_as_longlong(v); }
+// order-preserving map double -> uint64 (negative values too, for user-supplied matrices)
+__device__ __forceinline__ unsigned long long key_of(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return u ^ ((u >> 63) ? ~0ull : 0x8000000000000000ull);
+}
+__device__ __forceinline__ double value_of(unsigned long long key) {
+    const unsigned long long u = key ^ ((key >> 63) ? 0x8000000000000000ull : ~0ull);
+    return __longlong_as_double((long long)u);
+}
 
 __global__ __launch_bounds__(256) void k_theta_rows(const double *__restrict__ zsq, int64_t n, int k,
                                                     double *__restrict__ terms) {
@@ -53,9 +61,9 @@ __global__ __launch_bounds__(256) void k_theta_rows(const double *__restrict__ z
         __syncthreads();
     }
     const unsigned long long vk_key = s_prefix;
-    const double vk = __longlong_as_double((long long)vk_key);
+    const double vk = value_of(vk_key);
 
-    double sum = 0, mx = 0;
+    double sum = 0, mx = -INFINITY;
     unsigned cnt = 0;
     for (int64_t j = tid; j < n; j += 256) {
         const double v = row[j];

@@ -119,6 +119,23 @@ int gl_logmodel_fit_signals(gl_ctx *ctx, const double *x, int64_t d, int64_t n_n
                             double step_size, double edge_tol, double *weights_out,
                             double *theta_out, int64_t *n_iter_out, double *rel_out);
 
+/* ---- Laplacian <-> edge-vector operators (graph_learn/operators.py) ------
+ * Batched over the leading axis B; host buffers in and out. */
+/* square_to_vec (:39-41): (B,n,n) -> (B,E) strict upper triangle. */
+int gl_square_to_vec(gl_ctx *ctx, const double *x, int64_t B, int64_t n_nodes, double *out);
+/* laplacian_squareform_vec (:58-70) / laplacian_squareform (:44-55):
+ * (B,E) edge weights -> (B,n,n) Laplacians L = D - W. */
+int gl_laplacian_from_vec(gl_ctx *ctx, const double *w, int64_t B, int64_t n_nodes, double *out);
+/* Adjoint (L* Y)_(i,j) = Y_ii + Y_jj - Y_ij - Y_ji, (B,n,n) -> (B,E).
+ * order 0: summation order of laplacian_squareform_adj(_vec) (:73-94);
+ * order 1: summation order of op_adj_dual (:176-180). */
+int gl_laplacian_adjoint(gl_ctx *ctx, const double *y, int64_t B, int64_t n_nodes, int order, double *out);
+/* squared_pdiffs (:224-226): (T,n) signals -> (T,E), (x_ti - x_tj)^2. */
+int gl_squared_pdiffs(gl_ctx *ctx, const double *x, int64_t T, int64_t n_nodes, double *out);
+/* get_theta, blocks=None (graph_learn/smooth_learning.py:201-219) on a host
+ * (n,n) matrix of squared distances (zero diagonal included in the ranking). */
+int gl_theta_from_distances(gl_ctx *ctx, const double *zsq, int64_t n_nodes, int avg_degree, double *theta_out);
+
 #ifdef __cplusplus
 }
 #endif

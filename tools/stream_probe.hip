@@ -1,0 +1,111 @@
+// Development probe (not part of the product): what does MI355X sustain for the edge pass's
+// traffic shape (read w, read z, write w; 8.39M fp64 edges = 67 MB per array)?
+//   ./stream_probe [n=4096] [reps=200]
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_stream(const double2* __restrict__ w, const double2* __restrict__ z,
+                                                double2* __restrict__ o, long n2, double c, double g) {
+    long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride * U) {
+        double2 a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            long k = i + u * stride;
+            if (k < n2) {
+                if (NT) { a[u].x = __builtin_nontemporal_load(&w[k].x); a[u].y = __builtin_nontemporal_load(&w[k].y);
+                          b[u].x = __builtin_nontemporal_load(&z[k].x); b[u].y = __builtin_nontemporal_load(&z[k].y); }
+                else { a[u] = w[k]; b[u] = z[k]; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            long k = i + u * stride;
+            if (k < n2) {
+                double2 r;
+                double t = c * a[u].x - g * b[u].x; r.x = t > 0 ? t : 0.0;
+                t = c * a[u].y - g * b[u].y; r.y = t > 0 ? t : 0.0;
+                if (NT) { __builtin_nontemporal_store(r.x, &o[k].x); __builtin_nontemporal_store(r.y, &o[k].y); }
+                else o[k] = r;
+            }
+        }
+    }
+}
+
+// contiguous chunk per block (each block streams its own contiguous range; U loads in flight per lane)
+template <int U>
+__global__ __launch_bounds__(256) void k_chunk(const double2* __restrict__ w, const double2* __restrict__ z,
+                                               double2* __restrict__ o, long n2, double c, double g) {
+    long per = (n2 + gridDim.x - 1) / gridDim.x;
+    long lo = (long)blockIdx.x * per, hi = lo + per < n2 ? lo + per : n2;
+    for (long i = lo + threadIdx.x; i < hi; i += 256 * U) {
+        double2 a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { long k = i + u * 256; if (k < hi) { a[u] = w[k]; b[u] = z[k]; } }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { long k = i + u * 256; if (k < hi) { double2 r; double t = c * a[u].x - g * b[u].x; r.x = t > 0 ? t : 0.0;
+                t = c * a[u].y - g * b[u].y; r.y = t > 0 ? t : 0.0; o[k] = r; } }
+    }
+}
+
+__global__ void k_empty(double* p) { if (threadIdx.x == 1234567) p[0] = 1; }
+
+int main(int argc, char** argv) {
+    long n = argc > 1 ? atol(argv[1]) : 4096;
+    int reps = argc > 2 ? atoi(argv[2]) : 200;
+    long nb = (n + 63) / 64, ntiles = nb * (nb + 1) / 2, elems = ntiles * 4096, n2 = elems / 2;
+    size_t bytes = elems * 8;
+    double *w0, *w1, *z;
+    CK(hipMalloc(&w0, bytes)); CK(hipMalloc(&w1, bytes)); CK(hipMalloc(&z, bytes));
+    CK(hipMemset(w0, 0, bytes)); CK(hipMemset(w1, 0, bytes)); CK(hipMemset(z, 0, bytes));
+    hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    double algo = 24.0 * (n * (n - 1) / 2);
+    printf("n=%ld elems=%ld (%.1f MB/array) algorithmic bytes/iter=%.1f MB\n", n, elems, bytes / 1e6, algo / 1e6);
+
+    auto run = [&](const char* name, auto launch) {
+        for (int i = 0; i < 20; ++i) launch(i);
+        CK(hipStreamSynchronize(st));
+        auto t0 = std::chrono::steady_clock::now();
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) launch(i);
+        auto t1 = std::chrono::steady_clock::now();
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        auto t2 = std::chrono::steady_clock::now();
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        double us = ms * 1e3 / reps;
+        printf("%-28s %8.2f us/launch  actual %6.2f TB/s  algo %6.2f TB/s | host enqueue %.2f us/launch, wall %.2f us/launch\n", name, us,
+               3.0 * bytes / us / 1e6, algo / us / 1e6,
+               std::chrono::duration<double, std::micro>(t1 - t0).count() / reps,
+               std::chrono::duration<double, std::micro>(t2 - t0).count() / reps);
+    };
+    int grids[] = {512, 1024, 2048, 4096, 8192};
+    for (int G : grids) {
+        char nm[64];
+        snprintf(nm, 64, "stream pp U4 G%d", G);
+        run(nm, [&](int i) { k_stream<4, false><<<G, 256, 0, st>>>((double2*)(i & 1 ? w1 : w0), (double2*)z, (double2*)(i & 1 ? w0 : w1), n2, 0.9, 0.1); });
+        snprintf(nm, 64, "stream pp U8 G%d", G);
+        run(nm, [&](int i) { k_stream<8, false><<<G, 256, 0, st>>>((double2*)(i & 1 ? w1 : w0), (double2*)z, (double2*)(i & 1 ? w0 : w1), n2, 0.9, 0.1); });
+    }
+    for (int G : {1024, 2048, 4096}) {
+        char nm[64];
+        snprintf(nm, 64, "stream inplace U8 G%d", G);
+        run(nm, [&](int i) { k_stream<8, false><<<G, 256, 0, st>>>((double2*)w0, (double2*)z, (double2*)w0, n2, 0.9, 0.1); });
+        snprintf(nm, 64, "stream pp NT U8 G%d", G);
+        run(nm, [&](int i) { k_stream<8, true><<<G, 256, 0, st>>>((double2*)(i & 1 ? w1 : w0), (double2*)z, (double2*)(i & 1 ? w0 : w1), n2, 0.9, 0.1); });
+        snprintf(nm, 64, "chunk pp U8 G%d", G);
+        run(nm, [&](int i) { k_chunk<8><<<G, 256, 0, st>>>((double2*)(i & 1 ? w1 : w0), (double2*)z, (double2*)(i & 1 ? w0 : w1), n2, 0.9, 0.1); });
+        snprintf(nm, 64, "chunk inplace U8 G%d", G);
+        run(nm, [&](int i) { k_chunk<8><<<G, 256, 0, st>>>((double2*)w0, (double2*)z, (double2*)w0, n2, 0.9, 0.1); });
+    }
+    int saved = reps;
+    for (int r : {100, 500, 1000, 2000, 4000}) { reps = r; char nm[64]; snprintf(nm, 64, "empty kernel x%d", r);
+        run(nm, [&](int i) { k_empty<<<1, 64, 0, st>>>(w0); }); }
+    reps = saved;
+    return 0;
+}
