@@ -2,24 +2,32 @@
 #pragma once
 #include "gl_common.h"
 
-// Device-side view of one problem (passed by value to the kernels).
+// Device-side view of one problem (passed by value to the kernels; nothing in it
+// changes from one iteration to the next, so a captured hipGraph can be replayed).
 struct LogdegDev {
-    double *w[2];        // edge iterate, tiled layout, ping-pong: iterate `it` lives in w[it & 1]
-    const double *z;     // scaled squared distances, tiled layout
-    double *dvar;        // dual variable d            (n_pad)
-    double *ybar;        // forward dual point  ybar   (n_pad)
-    double *pbar;        // prox dual point     pbar   (n_pad)
-    double *part_p;      // per-tile degree partials of p      [nb][n_pad]
-    double *part_w;      // per-tile degree partials of w_new  [nb][n_pad]
-    double *tnorm;       // per-tile {sum (q-y)^2, sum w^2}    [ntiles][2]
-    double *bnorm;       // per-node-block norm partials       [2][nb][4]
-    double *status;      // {done, final_iter, rel_primal, rel_dual}
+    double *w[2];          // edge iterate, tiled layout, ping-pong: iterate `it` lives in w[it & 1]
+    const double *z;       // scaled squared distances, tiled layout
+    double *dvar;          // dual variable d            (n_pad)
+    double *ybar;          // forward dual point  ybar   (n_pad)
+    double *pbar;          // prox dual point     pbar   (n_pad)
+    double *rowslab_p;     // row-degree partials of p:     [J][node i],  J >= I(i)      (nb x n_pad)
+    double *rowslab_w;     // row-degree partials of w_new
+    double *colslab;       // column-degree partials, one entry per (wave, tile) segment: [n_segments][2][64],
+                           // entries of one column block J are contiguous
+    const int *col_ptr;    // column block J -> [col_ptr[J], col_ptr[J+1]) colslab entries   (nb + 1)
+    const int *seg_dest;   // (wave, segment) -> colslab entry                                (G * kmax)
+    double *tnorm;         // per-wave {sum (q-y)^2, sum w^2}               [G][2]
+    double *bnorm;         // per-node-block norm partials                  [2][nb][4]
+    double *dstat;         // {rel_primal, rel_dual, tol}
+    long long *ctr;        // {done, final_iter, it_edge, it_node}
     int64_t n, nb, n_pad, ntiles;
-    double gamma;        // scaled step                      (smooth_learning.py:135-137)
-    double c;            // 1 - gamma*2*beta
-    double g2;           // 2*gamma
-    double a4g;          // 4*alpha*gamma
-    double tol;
+    int64_t npairs;        // ntiles * 32 row pairs = the flat work list
+    int G;                 // persistent edge grid (single-wave workgroups)
+    int kmax;              // segments reserved per wave in seg_dest
+    double gamma;          // scaled step                      (smooth_learning.py:135-137)
+    double c;              // 1 - gamma*2*beta
+    double g2;             // 2*gamma
+    double a4g;            // 4*alpha*gamma
 };
 
 struct gl_logdeg {
@@ -31,10 +39,16 @@ struct gl_logdeg {
     double *xdev = nullptr;       // signals (d x n) on device
     int64_t xdev_elems = 0;
     double *theta_terms = nullptr;  // 2 x n per-row terms of get_theta
+    int *col_ptr = nullptr, *seg_dest = nullptr;
+    int n_segments = 0;
     bool have_z = false, inited = false;
     bool have_zsq = false;
     int64_t it = 0;               // iterations completed (iterate lives in w[it & 1])
     double theta = 1.0;
+    // captured batch of iterations (launch-bound inner loop -> one graph launch)
+    hipGraphExec_t graph = nullptr;
+    int graph_iters = 0;
+    int wpc = 8;                  // edge waves per CU
 };
 
 // gl_gram.hip

@@ -11,16 +11,25 @@
 // the tile coordinates.  Arithmetic is fp64 with contraction disabled so that the
 // per-edge results equal NumPy's bit for bit; only the order of the degree sums
 // and norm sums differs (fixed, deterministic order: no atomics anywhere).
+//
+// Work decomposition of the edge pass (HBM/Infinity-Cache bound, 24 B per edge):
+// the tiled lattice is a flat list of "row pairs" (2 rows x 64 columns = 1 KiB, one
+// wave-wide 16-B load); a persistent grid of G = 8 x #CU single-wave workgroups
+// takes equal contiguous ranges of it, so every CU streams the same number of
+// bytes and the launch has no tail.
 #include "gl_logdeg.h"
 
 #include <algorithm>
 #include <limits>
+#include <type_traits>
+#include <vector>
 
 namespace {
 
 constexpr int TB = GL_TB;            // 64 x 64 tiles
-constexpr int EDGE_THREADS = 256;    // 4 waves, 16 tile rows each
-constexpr int ROWS_PER_LANE = 8;     // lane: 2 columns x 8 rows
+constexpr int ROWS_PER_LANE = 8;     // lane: 2 columns x 8 row pairs per segment
+constexpr int PAIRS_PER_TILE = TB / 2;
+constexpr int ITER_BATCH = 64;       // iterations per captured graph / per convergence poll
 
 __device__ __forceinline__ double shfl_xor_d(double v, int mask) { return __shfl_xor(v, mask, 64); }
 
@@ -58,223 +67,280 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// The stopping rule of smooth_learning.py:156-161,166 evaluated from the nb x 4
-// norm partials that the node pass of the previous iteration left behind.
-// Every caller gets bit-identical rp/rd (fixed reduction order).  One wave.
-__device__ __forceinline__ void eval_rel_changes(const double *bn, int64_t nb, int lane, double &rp,
-                                                 double &rd) {
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    for (int64_t b = lane; b < nb; b += 64) {
-        s0 += bn[4 * b + 0];
-        s1 += bn[4 * b + 1];
-        s2 += bn[4 * b + 2];
-        s3 += bn[4 * b + 3];
-    }
-    s0 = wave_sum(s0);
-    s1 = wave_sum(s1);
-    s2 = wave_sum(s2);
-    s3 = wave_sum(s3);
-    rp = sqrt(s0) / sqrt(s1);
-    rd = sqrt(s2) / sqrt(s3);
+// ---------------------------------------------------------------------------
+// Edge pass.  Every WAVE is an autonomous worker (workgroup = one wave, no LDS, no
+// barrier): it owns a contiguous range of the flat row-pair list and walks it in
+// steps of <= 8 row pairs inside one tile.  Loads of the next step are issued
+// slot by slot right after the slot's registers are consumed, so the next step's
+// data is already on its way while the row / column reductions of this step run.
+// Row sums are complete inside the wave (half-wave butterfly); column partials stay
+// in registers until the wave leaves the tile, then go to its colslab entry.
+// INIT = true computes only the degree sums of the current iterate (dvar = S w, :144).
+// ABL: development-only ablation mask (tools/edge_ablate.hip); the product uses ABL = 0.
+//   1 no node-vector gathers, 2 no row sums, 4 no column sums, 8 no w store, 16 no norms, 32 no z load
+struct EdgeStep {
+    int64_t t;   // tile
+    int a;       // first row pair of the step inside the tile
+    int cnt;     // row pairs in the step (0 = none)
+};
+
+__device__ __forceinline__ EdgeStep edge_step_at(int64_t p, int64_t pend) {
+    EdgeStep s;
+    s.t = p >> 5;
+    s.a = (int)(p & (PAIRS_PER_TILE - 1));
+    const int64_t left = pend - p;
+    int cnt = PAIRS_PER_TILE - s.a;
+    cnt = cnt < ROWS_PER_LANE ? cnt : ROWS_PER_LANE;
+    s.cnt = left <= 0 ? 0 : (left < cnt ? (int)left : cnt);
+    return s;
 }
 
-// ---------------------------------------------------------------------------
-// Edge pass.  One workgroup per 64x64 tile (I <= J).  INIT = true computes only
-// the degree sums of the current iterate (dvar = S w, :144).
-template <bool INIT>
-__global__ __launch_bounds__(EDGE_THREADS) void k_edge(LogdegDev P, int64_t it) {
-    __shared__ double s_row[2][TB];
-    __shared__ double s_col[2][4][TB];
-    __shared__ double s_nrm[2][4];
+template <bool INIT, int ABL = 0>
+__global__ __launch_bounds__(64) void k_edge(LogdegDev P) {
+    if (!INIT && P.ctr[0] != 0) return;  // converged earlier: leave everything as is
+    const long long it = INIT ? 0 : P.ctr[2];
 
-    if (!INIT && P.status[0] != 0.0) return;  // converged earlier: leave everything as is
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int I, J;
-    gl_tile_decode((int64_t)blockIdx.x, P.nb, I, J);
+    const int lane = threadIdx.x;
     const int half = lane >> 5;
     const int c0 = 2 * (lane & 31);
-    const int r0 = wave * 16 + half;  // + 2k
+    const int b = blockIdx.x;
+    if (!INIT && b == 0 && lane == 0) P.ctr[3] = it;  // hand the index to the node pass
+
     const double *__restrict__ wsrc = P.w[it & 1];
     double *__restrict__ wdst = P.w[(it + 1) & 1];
-    const int64_t base = (int64_t)blockIdx.x * GL_TILE_ELEMS + (int64_t)r0 * TB + c0;
-
-    double2 wv[ROWS_PER_LANE], zv[ROWS_PER_LANE];
-#pragma unroll
-    for (int k = 0; k < ROWS_PER_LANE; ++k) {
-        wv[k] = *reinterpret_cast<const double2 *>(wsrc + base + (int64_t)k * 2 * TB);
-        if (!INIT) zv[k] = *reinterpret_cast<const double2 *>(P.z + base + (int64_t)k * 2 * TB);
-    }
-
-    const int64_t j0 = (int64_t)J * TB + c0;
-    const int64_t ibase = (int64_t)I * TB + r0;
-    double dj[2] = {0, 0}, pj[2] = {0, 0};
-    if (!INIT) {
-        dj[0] = P.dvar[j0];
-        dj[1] = P.dvar[j0 + 1];
-        pj[0] = P.pbar[j0];
-        pj[1] = P.pbar[j0 + 1];
-    }
-    const bool full = (I < J) && ((int64_t)J * TB + TB <= P.n);
-
-    double rowp[ROWS_PER_LANE], roww[ROWS_PER_LANE];
-    double colp[2] = {0, 0}, colw[2] = {0, 0};
-    double nqy = 0, nw = 0;
     const double c = P.c, g = P.gamma, g2 = P.g2;
 
+    int64_t p = ((int64_t)b * P.npairs) / P.G;
+    const int64_t pend = ((int64_t)(b + 1) * P.npairs) / P.G;
+    const int lofs = half * TB + c0;  // lane offset inside a row pair
+
+    double2 wv[ROWS_PER_LANE], zv[ROWS_PER_LANE];
+    EdgeStep cur = edge_step_at(p, pend);
 #pragma unroll
     for (int k = 0; k < ROWS_PER_LANE; ++k) {
-        const int64_t i = ibase + 2 * k;
-        double di = 0, pi = 0;
-        if (!INIT) {
-            di = P.dvar[i];
-            pi = P.pbar[i];
-        }
-        double wn[2], pp[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int64_t j = j0 + e;
-            const bool valid = full || (i < j && j < P.n);
-            const double w = e ? wv[k].y : wv[k].x;
-            if (INIT) {
-                pp[e] = 0.0;
-                wn[e] = valid ? w : 0.0;
-            } else {
-                const double z = e ? zv[k].y : zv[k].x;
-                // :147  y = (1 - 2 gamma beta) w - gamma (S^T d)
-                const double y = c * w - g * (di + dj[e]);
-                // :150  p = max(0, y - 2 gamma z)
-                const double t = y - g2 * z;
-                const double p = t > 0 ? t : 0.0;
-                // :153  q = (1 - 2 gamma beta) p - gamma (S^T pbar)
-                const double q = c * p - g * (pi + pj[e]);
-                // :163  w <- w - y + q
-                const double wnew = (w - y) + q;
-                const double dq = q - y;  // == -y + q (:158)
-                pp[e] = valid ? p : 0.0;
-                wn[e] = valid ? wnew : 0.0;
-                nqy += valid ? dq * dq : 0.0;
-                nw += valid ? w * w : 0.0;
-            }
-            colp[e] += pp[e];
-            colw[e] += wn[e];
-        }
-        rowp[k] = pp[0] + pp[1];
-        roww[k] = wn[0] + wn[1];
-        if (!INIT) {
-            double2 o;
-            o.x = wn[0];
-            o.y = wn[1];
-            *reinterpret_cast<double2 *>(wdst + base + (int64_t)k * 2 * TB) = o;
+        wv[k] = double2{0.0, 0.0};
+        zv[k] = double2{0.0, 0.0};
+        if (k < cur.cnt) {
+            const int64_t off = cur.t * GL_TILE_ELEMS + (int64_t)(cur.a + k) * (2 * TB) + lofs;
+            wv[k] = *reinterpret_cast<const double2 *>(wsrc + off);
+            if (!INIT && !(ABL & 32)) zv[k] = *reinterpret_cast<const double2 *>(P.z + off);
         }
     }
 
-    // ---- degree partials of this tile: rows (nodes of block I), columns (block J)
-    const double rw = halfwave_rows8(roww, lane);
-    double rp_ = 0;
-    if (!INIT) rp_ = halfwave_rows8(rowp, lane);
-    if ((lane & 3) == 0) {
-        const int r = wave * 16 + 2 * ((lane >> 2) & 7) + half;
-        s_row[0][r] = rp_;
-        s_row[1][r] = rw;
-    }
+    int seg = 0;
+    int64_t tile_loaded = -1;
+    int I = 0, J = 0;
+    bool full = false;
+    double dj[2] = {0, 0}, pj[2] = {0, 0};
+    double colp[2] = {0, 0}, colw[2] = {0, 0};
+    double nqy = 0, nw = 0;
+
+    while (cur.cnt > 0) {
+        if (cur.t != tile_loaded) {
+            tile_loaded = cur.t;
+            gl_tile_decode(cur.t, P.nb, I, J);
+            full = (I < J) && ((int64_t)J * TB + TB <= P.n);
+            if (!INIT && !(ABL & 1)) {
+                const int64_t j0 = (int64_t)J * TB + c0;
+                dj[0] = P.dvar[j0];
+                dj[1] = P.dvar[j0 + 1];
+                pj[0] = P.pbar[j0];
+                pj[1] = P.pbar[j0 + 1];
+            }
+        }
+        const EdgeStep nxt = edge_step_at(p + cur.cnt, pend);
+        const int64_t tbase = cur.t * GL_TILE_ELEMS + lofs;
+        const int64_t nbase = nxt.t * GL_TILE_ELEMS + lofs;
+        const int irow0 = I * TB + 2 * cur.a + half;  // node of slot 0
+        const int jcol0 = J * TB + c0;
+
+        double rowp[ROWS_PER_LANE], roww[ROWS_PER_LANE];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        colp[e] += shfl_xor_d(colp[e], 32);
-        colw[e] += shfl_xor_d(colw[e], 32);
+        for (int k = 0; k < ROWS_PER_LANE; ++k) {
+            rowp[k] = 0.0;
+            roww[k] = 0.0;
+            if (k < cur.cnt) {
+                const int i = irow0 + 2 * k;
+                double di = 0, pi = 0;
+                if (!INIT && !(ABL & 1)) {
+                    di = P.dvar[i];
+                    pi = P.pbar[i];
+                }
+                double wn[2], pp[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const double w = e ? wv[k].y : wv[k].x;
+                    if (INIT) {
+                        pp[e] = 0.0;
+                        wn[e] = w;
+                    } else {
+                        const double z = e ? zv[k].y : zv[k].x;
+                        // :147  y = (1 - 2 gamma beta) w - gamma (S^T d)
+                        const double y = c * w - g * (di + dj[e]);
+                        // :150  p = max(0, y - 2 gamma z)
+                        const double tt = y - g2 * z;
+                        const double pr = tt > 0 ? tt : 0.0;
+                        // :153  q = (1 - 2 gamma beta) p - gamma (S^T pbar)
+                        const double q = c * pr - g * (pi + pj[e]);
+                        // :163  w <- w - y + q
+                        wn[e] = (w - y) + q;
+                        pp[e] = pr;
+                        if (!(ABL & 16)) {
+                            const double dq = q - y;  // == -y + q (:158)
+                            if (full) {
+                                nqy += dq * dq;
+                                nw += w * w;
+                            } else {
+                                const int j = jcol0 + e;
+                                const bool valid = i < j && j < P.n;
+                                nqy += valid ? dq * dq : 0.0;
+                                nw += valid ? w * w : 0.0;
+                            }
+                        }
+                    }
+                    if (!full) {  // diagonal / ragged tiles: entries outside i < j < n stay exactly 0
+                        const int j = jcol0 + e;
+                        const bool valid = i < j && j < P.n;
+                        pp[e] = valid ? pp[e] : 0.0;
+                        wn[e] = valid ? wn[e] : 0.0;
+                    }
+                    colp[e] += pp[e];
+                    colw[e] += wn[e];
+                }
+                rowp[k] = pp[0] + pp[1];
+                roww[k] = wn[0] + wn[1];
+                if (!INIT && !(ABL & 8)) {
+                    double2 o;
+                    o.x = wn[0];
+                    o.y = wn[1];
+                    *reinterpret_cast<double2 *>(wdst + tbase + (int64_t)(cur.a + k) * (2 * TB)) = o;
+                }
+                if (ABL & 8) nqy += wn[0] + wn[1];
+            }
+            // prefetch: this slot's registers are free again
+            if (k < nxt.cnt) {
+                const int64_t off = nbase + (int64_t)(nxt.a + k) * (2 * TB);
+                wv[k] = *reinterpret_cast<const double2 *>(wsrc + off);
+                if (!INIT && !(ABL & 32)) zv[k] = *reinterpret_cast<const double2 *>(P.z + off);
+            }
+        }
+
+        // ---- row degree partials of this step: complete inside the wave
+        if (ABL & 2) {
+#pragma unroll
+            for (int k = 0; k < ROWS_PER_LANE; ++k) nw += rowp[k] + roww[k];
+        } else {
+            const double rw = halfwave_rows8(roww, lane);
+            double rp_ = 0;
+            if (!INIT) rp_ = halfwave_rows8(rowp, lane);
+            const int k = (lane >> 2) & 7;
+            if ((lane & 3) == 0 && k < cur.cnt) {
+                const int64_t idx = (int64_t)J * P.n_pad + irow0 + 2 * k;
+                if (!INIT) P.rowslab_p[idx] = rp_;
+                P.rowslab_w[idx] = rw;
+            }
+        }
+
+        // ---- leaving the tile (or the range): flush the column partials
+        if (nxt.cnt == 0 || nxt.t != cur.t) {
+            if (ABL & 4) {
+                nw += (colp[0] + colp[1]) + (colw[0] + colw[1]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    colp[e] += shfl_xor_d(colp[e], 32);
+                    colw[e] += shfl_xor_d(colw[e], 32);
+                }
+                if (half == 0) {
+                    const int64_t ent = P.seg_dest[(int64_t)b * P.kmax + seg];
+                    double *dst = P.colslab + ent * (2 * TB) + c0;
+                    if (!INIT) *reinterpret_cast<double2 *>(dst) = double2{colp[0], colp[1]};
+                    *reinterpret_cast<double2 *>(dst + TB) = double2{colw[0], colw[1]};
+                }
+            }
+            colp[0] = colp[1] = colw[0] = colw[1] = 0.0;
+            ++seg;
+        }
+        p += cur.cnt;
+        cur = nxt;
     }
-    if (half == 0) {
-        s_col[0][wave][c0] = colp[0];
-        s_col[0][wave][c0 + 1] = colp[1];
-        s_col[1][wave][c0] = colw[0];
-        s_col[1][wave][c0 + 1] = colw[1];
-    }
+
     if (!INIT) {
         nqy = wave_sum(nqy);
         nw = wave_sum(nw);
         if (lane == 0) {
-            s_nrm[0][wave] = nqy;
-            s_nrm[1][wave] = nw;
+            P.tnorm[2 * b + 0] = nqy;
+            P.tnorm[2 * b + 1] = nw;
         }
-    }
-    __syncthreads();
-
-    if (tid < 2 * TB) {
-        const int q = tid >> 6;  // 0: p sums, 1: w sums
-        const int r = tid & 63;
-        const double rs = s_row[q][r];
-        const double cs = ((s_col[q][0][r] + s_col[q][1][r]) + s_col[q][2][r]) + s_col[q][3][r];
-        double *part = q ? P.part_w : P.part_p;
-        if (!(INIT && q == 0)) {
-            if (I == J) {
-                part[(int64_t)I * P.n_pad + (int64_t)I * TB + r] = rs + cs;
-            } else {
-                part[(int64_t)J * P.n_pad + (int64_t)I * TB + r] = rs;  // node I*TB+r, slot J
-                part[(int64_t)I * P.n_pad + (int64_t)J * TB + r] = cs;  // node J*TB+r, slot I
-            }
-        }
-    }
-    if (!INIT && tid == 0) {
-        P.tnorm[2 * (int64_t)blockIdx.x + 0] = ((s_nrm[0][0] + s_nrm[0][1]) + s_nrm[0][2]) + s_nrm[0][3];
-        P.tnorm[2 * (int64_t)blockIdx.x + 1] = ((s_nrm[1][0] + s_nrm[1][1]) + s_nrm[1][2]) + s_nrm[1][3];
     }
 }
 
 // ---------------------------------------------------------------------------
-// Node pass.  One workgroup per block of 64 nodes; wave v sums slab slots
-// s = v, v+4, ... ; lanes are nodes.  Order of every sum is fixed.
-// Also evaluates the stopping rule of the PREVIOUS iteration (deferred by one
-// pass; the ping-pong edge buffers keep the iterate it refers to intact).
+// Node pass.  One workgroup (16 waves) per block of 64 nodes: lanes are nodes,
+// wave v sums every 16th slab entry, so all slab loads of a lane are in flight
+// together; order of every sum is fixed.  It also evaluates the stopping rule
+// (:156-161,166) of the PREVIOUS iteration -- deferred by one pass so that no
+// extra launch or grid-wide wait sits on the iteration path; the ping-pong edge
+// buffers keep the iterate the rule refers to intact.
+constexpr int NODE_WAVES = 16;
+
 template <bool INIT>
-__global__ __launch_bounds__(256) void k_node(LogdegDev P, int64_t it) {
-    __shared__ double s_sum[2][4][TB];
-    __shared__ double s_red[4][4];
+__global__ __launch_bounds__(NODE_WAVES * 64) void k_node(LogdegDev P) {
+    __shared__ double s_sum[2][NODE_WAVES][TB];
+    __shared__ double s_red[2][NODE_WAVES];
     __shared__ int s_stop;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t b = blockIdx.x;
-
+    const int64_t B = blockIdx.x;
+    long long it = 0;
     if (!INIT) {
-        if (P.status[0] != 0.0) return;
-        if (it >= 2) {  // rule of iteration it-1 >= 1 (the reference skips i == 0, :156-161)
-            if (wave == 0) {
-                double rp, rd;
-                eval_rel_changes(P.bnorm + ((it - 1) & 1) * 4 * P.nb, P.nb, lane, rp, rd);
-                const int stop = (rp < P.tol && rd < P.tol) ? 1 : 0;
-                if (lane == 0) {
-                    s_stop = stop;
-                    if (b == 0) {
-                        P.status[2] = rp;
-                        P.status[3] = rd;
-                        if (stop) {
-                            P.status[1] = (double)it;  // iterations completed
-                            P.status[0] = 1.0;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            if (s_stop) return;
+        if (P.ctr[0] != 0) return;
+        it = P.ctr[3];
+    }
+    const bool chk = !INIT && it >= 2;  // rule of iteration it-1 >= 1 (the reference skips i == 0)
+    const int64_t i = B * TB + lane;
+
+    // loads first: stopping-rule partials, my node's state, then the slabs
+    double b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    if (chk && wave == 1) {
+        const double *bn = P.bnorm + ((it - 1) & 1) * 4 * P.nb;
+        for (int64_t bb = lane; bb < P.nb; bb += 64) {
+            b0 += bn[4 * bb + 0];
+            b1 += bn[4 * bb + 1];
+            b2 += bn[4 * bb + 2];
+            b3 += bn[4 * bb + 3];
         }
     }
+    double d_old = 0, yb_old = 0, pb_old = 0;
+    if (!INIT && wave == 0) {
+        d_old = P.dvar[i];
+        yb_old = P.ybar[i];
+        pb_old = P.pbar[i];
+    }
 
-    // slab sums for my 64 nodes
-    const int64_t i = b * TB + lane;
+    // degree sums of my 64 nodes: row partials of tiles (B, J >= B), column
+    // partials of every segment of the tiles (I <= B, B) (contiguous in colslab)
     double sp = 0, sw = 0;
 #pragma unroll 4
-    for (int64_t s = wave; s < P.nb; s += 4) {
-        if (!INIT) sp += P.part_p[s * P.n_pad + i];
-        sw += P.part_w[s * P.n_pad + i];
+    for (int64_t J = B + wave; J < P.nb; J += NODE_WAVES) {
+        if (!INIT) sp += P.rowslab_p[J * P.n_pad + i];
+        sw += P.rowslab_w[J * P.n_pad + i];
+    }
+    const int64_t e1 = P.col_ptr[B + 1];
+#pragma unroll 4
+    for (int64_t e = P.col_ptr[B] + wave; e < e1; e += NODE_WAVES) {
+        if (!INIT) sp += P.colslab[e * (2 * TB) + lane];
+        sw += P.colslab[e * (2 * TB) + TB + lane];
     }
     s_sum[0][wave][lane] = sp;
     s_sum[1][wave][lane] = sw;
 
-    // my share of the per-tile primal norm partials
-    double t0 = 0, t1 = 0;
+    // my share of the per-wave primal norm partials of the edge pass
     if (!INIT) {
-        for (int64_t t = b + (int64_t)tid * P.nb; t < P.ntiles; t += 256 * P.nb) {
-            t0 += P.tnorm[2 * t + 0];
-            t1 += P.tnorm[2 * t + 1];
+        double t0 = 0, t1 = 0;
+        for (int64_t gq = B + (int64_t)tid * P.nb; gq < P.G; gq += (int64_t)NODE_WAVES * 64 * P.nb) {
+            t0 += P.tnorm[2 * gq + 0];
+            t1 += P.tnorm[2 * gq + 1];
         }
         t0 = wave_sum(t0);
         t1 = wave_sum(t1);
@@ -283,22 +349,49 @@ __global__ __launch_bounds__(256) void k_node(LogdegDev P, int64_t it) {
             s_red[1][wave] = t1;
         }
     }
+    if (tid == 0) s_stop = 0;
     __syncthreads();
+    if (chk && wave == 1) {
+        b0 = wave_sum(b0);
+        b1 = wave_sum(b1);
+        b2 = wave_sum(b2);
+        b3 = wave_sum(b3);
+        const double rp = sqrt(b0) / sqrt(b1);  // ||q - y|| / ||w_prev||        (:158)
+        const double rd = sqrt(b2) / sqrt(b3);  // ||qbar - ybar|| / ||d_prev||  (:159)
+        const int stop = (rp < P.dstat[2] && rd < P.dstat[2]) ? 1 : 0;
+        if (lane == 0) {
+            if (stop) s_stop = 1;
+            if (B == 0) {
+                P.dstat[0] = rp;
+                P.dstat[1] = rd;
+                if (stop) {
+                    P.ctr[1] = it;  // iterations completed
+                    P.ctr[0] = 1;
+                }
+            }
+        }
+    }
+    if (chk) __syncthreads();
+    if (s_stop) return;
 
     if (wave == 0) {
-        sp = ((s_sum[0][0][lane] + s_sum[0][1][lane]) + s_sum[0][2][lane]) + s_sum[0][3][lane];
-        sw = ((s_sum[1][0][lane] + s_sum[1][1][lane]) + s_sum[1][2][lane]) + s_sum[1][3][lane];
+        sp = 0;
+        sw = 0;
+#pragma unroll
+        for (int v = 0; v < NODE_WAVES; ++v) {
+            sp += s_sum[0][v][lane];
+            sw += s_sum[1][v][lane];
+        }
         const bool real = i < P.n;
         double dnew, dq2 = 0, d2 = 0;
         if (INIT) {
             dnew = sw;  // :144  dvar = S w
         } else {
-            const double d = P.dvar[i], yb = P.ybar[i], pb = P.pbar[i];
-            const double qb = pb + P.gamma * sp;  // :154
-            const double dq = qb - yb;            // == -ybar + qbar (:159)
+            const double qb = pb_old + P.gamma * sp;  // :154
+            const double dq = qb - yb_old;            // == -ybar + qbar (:159)
             dq2 = real ? dq * dq : 0.0;
-            d2 = real ? d * d : 0.0;
-            dnew = (d - yb) + qb;                 // :164
+            d2 = real ? d_old * d_old : 0.0;
+            dnew = (d_old - yb_old) + qb;             // :164
         }
         // next iteration's forward + prox on the dual side (:148, :151)
         const double ybn = dnew + P.gamma * sw;
@@ -310,28 +403,49 @@ __global__ __launch_bounds__(256) void k_node(LogdegDev P, int64_t it) {
             dq2 = wave_sum(dq2);
             d2 = wave_sum(d2);
             if (lane == 0) {
-                double *bn = P.bnorm + (it & 1) * 4 * P.nb + 4 * b;
-                bn[0] = ((s_red[0][0] + s_red[0][1]) + s_red[0][2]) + s_red[0][3];
-                bn[1] = ((s_red[1][0] + s_red[1][1]) + s_red[1][2]) + s_red[1][3];
+                double r0 = 0, r1 = 0;
+#pragma unroll
+                for (int v = 0; v < NODE_WAVES; ++v) {
+                    r0 += s_red[0][v];
+                    r1 += s_red[1][v];
+                }
+                double *bn = P.bnorm + (it & 1) * 4 * P.nb + 4 * B;
+                bn[0] = r0;
+                bn[1] = r1;
                 bn[2] = dq2;
                 bn[3] = d2;
+                if (B == 0) P.ctr[2] = it + 1;  // the next edge pass runs iteration it + 1
             }
         }
     }
 }
 
 // After a batch of launches: rel. changes of the last completed iteration, and
-// the stopping rule for it (the deferred check has not seen it yet).
-__global__ void k_status(LogdegDev P, int64_t it) {
-    if (P.status[0] != 0.0 || it < 2) return;  // iteration 0 never stops (:156-161)
-    double rp, rd;
-    eval_rel_changes(P.bnorm + ((it - 1) & 1) * 4 * P.nb, P.nb, threadIdx.x, rp, rd);
-    if (threadIdx.x == 0) {
-        P.status[2] = rp;
-        P.status[3] = rd;
-        if (rp < P.tol && rd < P.tol) {
-            P.status[1] = (double)it;
-            P.status[0] = 1.0;
+// the stopping rule for it (the deferred check has not seen it yet).  One wave.
+__global__ void k_status(LogdegDev P) {
+    if (P.ctr[0] != 0) return;
+    const long long it = P.ctr[2];
+    if (it < 2) return;  // iteration 0 never stops (:156-161)
+    const int lane = threadIdx.x;
+    const double *bn = P.bnorm + ((it - 1) & 1) * 4 * P.nb;
+    double b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    for (int64_t bb = lane; bb < P.nb; bb += 64) {
+        b0 += bn[4 * bb + 0];
+        b1 += bn[4 * bb + 1];
+        b2 += bn[4 * bb + 2];
+        b3 += bn[4 * bb + 3];
+    }
+    b0 = wave_sum(b0);
+    b1 = wave_sum(b1);
+    b2 = wave_sum(b2);
+    b3 = wave_sum(b3);
+    const double rp = sqrt(b0) / sqrt(b1), rd = sqrt(b2) / sqrt(b3);
+    if (lane == 0) {
+        P.dstat[0] = rp;
+        P.dstat[1] = rd;
+        if (rp < P.dstat[2] && rd < P.dstat[2]) {
+            P.ctr[1] = it;
+            P.ctr[0] = 1;
         }
     }
 }
@@ -441,6 +555,99 @@ __global__ void k_fill(double *p, int64_t count, double v) {
 
 int check(gl_logdeg *s) { return (s && s->ctx) ? GL_OK : GL_E_INVALID; }
 
+// Where the column partials go.  The partition of the flat row-pair list over the
+// G waves is static, so the host knows which (wave, segment) holds partials of which
+// tile: colslab entries are laid out contiguously per column block J (col_ptr, read
+// by the node pass without indirection) and seg_dest[wave*kmax + seg] tells the edge
+// pass where to put them.
+int build_column_index(gl_logdeg *s) {
+    gl_ctx *ctx = s->ctx;
+    LogdegDev &D = s->dev;
+    std::vector<std::vector<int>> lists((size_t)D.nb);
+    for (int b = 0; b < D.G; ++b) {
+        int64_t p = ((int64_t)b * D.npairs) / D.G;
+        const int64_t pend = ((int64_t)(b + 1) * D.npairs) / D.G;
+        int seg = 0;
+        int64_t last_tile = -1;
+        while (p < pend) {
+            const int64_t t = p >> 5;
+            const int a = (int)(p & (PAIRS_PER_TILE - 1));
+            const int cnt = (int)std::min<int64_t>(PAIRS_PER_TILE - a, pend - p);
+            if (t != last_tile) {
+                int I, J;
+                gl_tile_decode(t, D.nb, I, J);
+                if (seg >= D.kmax) return gl_set_error(ctx, GL_E_STATE, "internal: segment table overflow");
+                lists[(size_t)J].push_back(b * D.kmax + seg);
+                ++seg;
+                last_tile = t;
+            }
+            p += cnt;
+        }
+    }
+    std::vector<int> ptr((size_t)D.nb + 1, 0);
+    std::vector<int> dest((size_t)D.G * D.kmax, 0);
+    for (int64_t J = 0; J < D.nb; ++J) {
+        int pos = ptr[(size_t)J];
+        for (int key : lists[(size_t)J]) dest[(size_t)key] = pos++;
+        ptr[(size_t)J + 1] = pos;
+    }
+    s->n_segments = ptr[(size_t)D.nb];
+    GL_HIP(ctx, hipMalloc((void **)&s->col_ptr, ptr.size() * sizeof(int)));
+    GL_HIP(ctx, hipMalloc((void **)&s->seg_dest, dest.size() * sizeof(int)));
+    GL_HIP(ctx, hipMalloc((void **)&D.colslab, (size_t)std::max(s->n_segments, 1) * 2 * GL_TB * 8));
+    GL_HIP(ctx, hipMemcpy(s->col_ptr, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+    GL_HIP(ctx, hipMemcpy(s->seg_dest, dest.data(), dest.size() * sizeof(int), hipMemcpyHostToDevice));
+    D.col_ptr = s->col_ptr;
+    D.seg_dest = s->seg_dest;
+    return GL_OK;
+}
+
+void drop_graph(gl_logdeg *s) {
+    if (s->graph) (void)hipGraphExecDestroy(s->graph);
+    s->graph = nullptr;
+    s->graph_iters = 0;
+}
+
+void enqueue_iteration(gl_logdeg *s) {
+    const LogdegDev &D = s->dev;
+    k_edge<false><<<dim3((unsigned)D.G), dim3(64), 0, s->ctx->stream>>>(D);
+    k_node<false><<<dim3((unsigned)D.nb), dim3(NODE_WAVES * 64), 0, s->ctx->stream>>>(D);
+}
+
+// ITER_BATCH iterations captured once per init() into a graph: the kernels take
+// their iteration index from device memory, so replaying the graph continues the loop.
+int ensure_graph(gl_logdeg *s) {
+    if (s->graph || getenv("GRAPHLEARN_AMD_NO_GRAPH")) return GL_OK;
+    gl_ctx *ctx = s->ctx;
+    hipGraph_t graph = nullptr;
+    GL_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    for (int k = 0; k < ITER_BATCH; ++k) enqueue_iteration(s);
+    hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+    if (e != hipSuccess) return gl_set_error(ctx, GL_E_HIP, "graph capture failed: %s", hipGetErrorString(e));
+    e = hipGraphInstantiate(&s->graph, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        s->graph = nullptr;
+        return gl_set_error(ctx, GL_E_HIP, "graph instantiate failed: %s", hipGetErrorString(e));
+    }
+    s->graph_iters = ITER_BATCH;
+    return GL_OK;
+}
+
+int launch_iterations(gl_logdeg *s, int64_t count) {
+    gl_ctx *ctx = s->ctx;
+    int64_t left = count;
+    if (left >= ITER_BATCH) GL_TRY(ensure_graph(s));
+    while (s->graph && left >= s->graph_iters) {
+        GL_HIP(ctx, hipGraphLaunch(s->graph, ctx->stream));
+        left -= s->graph_iters;
+    }
+    for (; left > 0; --left) enqueue_iteration(s);
+    GL_HIP(ctx, hipGetLastError());
+    s->it += count;
+    return GL_OK;
+}
+
 }  // namespace
 
 // ===========================================================================
@@ -459,24 +666,38 @@ GL_API int gl_logdeg_create(gl_ctx *ctx, int64_t n_nodes, gl_logdeg **out) {
     D.nb = gl_num_blocks(n_nodes);
     D.n_pad = D.nb * GL_TB;
     D.ntiles = gl_num_tiles(n_nodes);
+    D.npairs = D.ntiles * PAIRS_PER_TILE;
+    // persistent edge grid: `wpc` single-wave workgroups per CU (all co-resident), >= 8 row pairs each
+    s->wpc = 8;
+    if (const char *e = getenv("GRAPHLEARN_AMD_WPC")) s->wpc = std::max(1, std::min(16, atoi(e)));
+    D.G = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)s->wpc * ctx->prop.multiProcessorCount, D.npairs / 8));
+    const int64_t maxchunk = (D.npairs + D.G - 1) / D.G;
+    D.kmax = (int)((maxchunk + PAIRS_PER_TILE - 1) / PAIRS_PER_TILE) + 1;
     const size_t tiled_bytes = (size_t)D.ntiles * GL_TILE_ELEMS * sizeof(double);
-    auto alloc = [&](double **p, size_t bytes) -> int {
-        hipError_t e = hipMalloc((void **)p, bytes);
+    auto alloc = [&](void **p, size_t bytes) -> int {
+        hipError_t e = hipMalloc(p, bytes);
         if (e != hipSuccess) return gl_set_error(ctx, GL_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         return GL_OK;
     };
     int rc = GL_OK;
     double *zbuf = nullptr;
-    if ((rc = alloc(&D.w[0], tiled_bytes)) || (rc = alloc(&D.w[1], tiled_bytes)) || (rc = alloc(&zbuf, tiled_bytes)) ||
-        (rc = alloc(&D.dvar, D.n_pad * 8)) || (rc = alloc(&D.ybar, D.n_pad * 8)) || (rc = alloc(&D.pbar, D.n_pad * 8)) ||
-        (rc = alloc(&D.part_p, (size_t)D.nb * D.n_pad * 8)) || (rc = alloc(&D.part_w, (size_t)D.nb * D.n_pad * 8)) ||
-        (rc = alloc(&D.tnorm, (size_t)D.ntiles * 2 * 8)) || (rc = alloc(&D.bnorm, (size_t)2 * D.nb * 4 * 8)) ||
-        (rc = alloc(&D.status, 8 * 8)) || (rc = alloc(&s->stage, (size_t)s->n_edges * 8))) {
+    if ((rc = alloc((void **)&D.w[0], tiled_bytes)) || (rc = alloc((void **)&D.w[1], tiled_bytes)) ||
+        (rc = alloc((void **)&zbuf, tiled_bytes)) || (rc = alloc((void **)&D.dvar, D.n_pad * 8)) ||
+        (rc = alloc((void **)&D.ybar, D.n_pad * 8)) || (rc = alloc((void **)&D.pbar, D.n_pad * 8)) ||
+        (rc = alloc((void **)&D.rowslab_p, (size_t)D.nb * D.n_pad * 8)) ||
+        (rc = alloc((void **)&D.rowslab_w, (size_t)D.nb * D.n_pad * 8)) ||
+        (rc = alloc((void **)&D.tnorm, (size_t)D.G * 2 * 8)) || (rc = alloc((void **)&D.bnorm, (size_t)2 * D.nb * 4 * 8)) ||
+        (rc = alloc((void **)&D.dstat, 8 * 8)) || (rc = alloc((void **)&D.ctr, 8 * 8)) ||
+        (rc = alloc((void **)&s->stage, (size_t)s->n_edges * 8))) {
         D.z = zbuf;
         gl_logdeg_destroy(s);
         return rc;
     }
     D.z = zbuf;
+    if ((rc = build_column_index(s)) != GL_OK) {
+        gl_logdeg_destroy(s);
+        return rc;
+    }
     *out = s;
     return GL_OK;
 }
@@ -487,10 +708,12 @@ GL_API int gl_logdeg_destroy(gl_logdeg *s) {
         (void)hipSetDevice(s->ctx->device);
         (void)hipStreamSynchronize(s->ctx->stream);
     }
+    drop_graph(s);
     LogdegDev &D = s->dev;
-    double *ptrs[] = {D.w[0], D.w[1], const_cast<double *>(D.z), D.dvar, D.ybar, D.pbar, D.part_p, D.part_w,
-                      D.tnorm, D.bnorm, D.status, s->stage, s->zsq, s->xdev, s->theta_terms};
-    for (double *p : ptrs)
+    void *ptrs[] = {D.w[0], D.w[1], const_cast<double *>(D.z), D.dvar, D.ybar, D.pbar, D.rowslab_p, D.rowslab_w,
+                    D.colslab, D.tnorm, D.bnorm, D.dstat, D.ctr, s->stage, s->zsq, s->xdev, s->theta_terms,
+                    s->col_ptr, s->seg_dest};
+    for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete s;
     return GL_OK;
@@ -570,12 +793,12 @@ GL_API int gl_logdeg_init(gl_logdeg *s, double alpha, double beta, double step_s
     if (!s->have_z) return gl_set_error(ctx, GL_E_STATE, "init needs set_signals or set_distances first");
     GL_HIP(ctx, hipSetDevice(ctx->device));
     LogdegDev &D = s->dev;
+    drop_graph(s);  // the scalars below are baked into captured launches
     // :135-137
     D.gamma = step_size / (2 * beta + sqrt((double)(2 * (s->n - 1))));
     D.c = 1 - D.gamma * 2 * beta;
     D.g2 = 2 * D.gamma;
     D.a4g = 4 * alpha * D.gamma;
-    D.tol = 0.0;
     const size_t tiled_bytes = (size_t)D.ntiles * GL_TILE_ELEMS * sizeof(double);
     if (edge_init) {
         GL_HIP(ctx, hipMemcpyAsync(s->stage, edge_init, (size_t)s->n_edges * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -586,34 +809,28 @@ GL_API int gl_logdeg_init(gl_logdeg *s, double alpha, double beta, double step_s
     }
     GL_HIP(ctx, hipMemsetAsync(D.w[1], 0, tiled_bytes, ctx->stream));
     GL_HIP(ctx, hipMemsetAsync(D.bnorm, 0, (size_t)2 * D.nb * 4 * 8, ctx->stream));
+    GL_HIP(ctx, hipMemsetAsync(D.ctr, 0, 8 * 8, ctx->stream));
     const double inf = std::numeric_limits<double>::infinity();
     double *st = (double *)ctx->pinned;
-    st[0] = 0.0;
-    st[1] = 0.0;
-    st[2] = inf;
-    st[3] = inf;
-    st[4] = st[5] = st[6] = st[7] = 0.0;
-    GL_HIP(ctx, hipMemcpyAsync(D.status, st, 8 * 8, hipMemcpyHostToDevice, ctx->stream));
+    st[0] = inf;  // rel_primal
+    st[1] = inf;  // rel_dual
+    st[2] = 0.0;  // tol
+    GL_HIP(ctx, hipMemcpyAsync(D.dstat, st, 3 * 8, hipMemcpyHostToDevice, ctx->stream));
     s->it = 0;
-    k_edge<true><<<dim3((unsigned)D.ntiles), dim3(EDGE_THREADS), 0, ctx->stream>>>(D, 0);
+    k_edge<true><<<dim3((unsigned)D.G), dim3(64), 0, ctx->stream>>>(D);
     GL_HIP(ctx, hipGetLastError());
-    k_node<true><<<dim3((unsigned)D.nb), dim3(256), 0, ctx->stream>>>(D, 0);
+    k_node<true><<<dim3((unsigned)D.nb), dim3(NODE_WAVES * 64), 0, ctx->stream>>>(D);
     GL_HIP(ctx, hipGetLastError());
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     s->inited = true;
     return GL_OK;
 }
 
-static int launch_iterations(gl_logdeg *s, int64_t count) {
+static int set_tol(gl_logdeg *s, double tol) {
     gl_ctx *ctx = s->ctx;
-    LogdegDev &D = s->dev;
-    for (int64_t k = 0; k < count; ++k) {
-        const int64_t it = s->it + k;
-        k_edge<false><<<dim3((unsigned)D.ntiles), dim3(EDGE_THREADS), 0, ctx->stream>>>(D, it);
-        k_node<false><<<dim3((unsigned)D.nb), dim3(256), 0, ctx->stream>>>(D, it);
-    }
-    GL_HIP(ctx, hipGetLastError());
-    s->it += count;
+    double *slot = (double *)ctx->pinned + 16;
+    *slot = tol;
+    GL_HIP(ctx, hipMemcpyAsync(s->dev.dstat + 2, slot, 8, hipMemcpyHostToDevice, ctx->stream));
     return GL_OK;
 }
 
@@ -623,7 +840,8 @@ GL_API int gl_logdeg_iterate_async(gl_logdeg *s, int64_t n_iter) {
     if (!s->inited) return gl_set_error(ctx, GL_E_STATE, "iterate needs init first");
     if (n_iter < 0) return gl_set_error(ctx, GL_E_INVALID, "n_iter < 0");
     GL_HIP(ctx, hipSetDevice(ctx->device));
-    s->dev.tol = 0.0;
+    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the pinned tol slot may still be in flight
+    GL_TRY(set_tol(s, 0.0));
     return launch_iterations(s, n_iter);
 }
 
@@ -634,37 +852,38 @@ GL_API int gl_logdeg_iterate(gl_logdeg *s, int64_t maxit, double tol, int64_t *n
     if (!s->inited) return gl_set_error(ctx, GL_E_STATE, "iterate needs init first");
     if (maxit < 0) return gl_set_error(ctx, GL_E_INVALID, "maxit < 0");
     GL_HIP(ctx, hipSetDevice(ctx->device));
+    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     LogdegDev &D = s->dev;
-    D.tol = tol;
+    GL_TRY(set_tol(s, tol));
     const int64_t start = s->it;
     const int64_t end = start + maxit;
-    double *st = (double *)ctx->pinned;
+    double *st = (double *)ctx->pinned;          // [0..2]  dstat
+    long long *ct = (long long *)(st + 8);       // [8..11] ctr
     bool done = false;
-    st[2] = st[3] = std::numeric_limits<double>::infinity();
-    // poll period: ~1% of the work wasted at most once, and a bounded launch queue
-    const int64_t chunk = 64;
+    st[0] = st[1] = std::numeric_limits<double>::infinity();
     while (!done && s->it < end) {
-        const int64_t todo = std::min<int64_t>(chunk, end - s->it);
+        const int64_t todo = std::min<int64_t>(ITER_BATCH, end - s->it);
         GL_TRY(launch_iterations(s, todo));
-        k_status<<<dim3(1), dim3(64), 0, ctx->stream>>>(D, s->it);
+        k_status<<<dim3(1), dim3(64), 0, ctx->stream>>>(D);
         GL_HIP(ctx, hipGetLastError());
-        GL_HIP(ctx, hipMemcpyAsync(st, D.status, 8 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        GL_HIP(ctx, hipMemcpyAsync(st, D.dstat, 2 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        GL_HIP(ctx, hipMemcpyAsync(ct, D.ctr, 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
         GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (st[0] != 0.0) {
+        if (ct[0] != 0) {
             done = true;
-            s->it = (int64_t)st[1];
+            s->it = (int64_t)ct[1];
         }
     }
     if (done) {
         // re-arm the session: the flag belongs to this call's stopping rule
-        GL_HIP(ctx, hipMemsetAsync(D.status, 0, 2 * 8, ctx->stream));
+        GL_HIP(ctx, hipMemsetAsync(D.ctr, 0, 2 * 8, ctx->stream));
         GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     if (n_iter_out) *n_iter_out = s->it - start;
     if (converged_out) *converged_out = done ? 1 : 0;
     if (rel_out) {
-        rel_out[0] = st[2];
-        rel_out[1] = st[3];
+        rel_out[0] = st[0];
+        rel_out[1] = st[1];
     }
     return GL_OK;
 }
