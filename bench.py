@@ -80,14 +80,13 @@ def main():
     from graph_learning_amd import _lib
     from graph_learning_amd.synth import logmodel_problem
 
+    n, d = args.nodes, args.samples
+    ctx = _lib.Context(local_rank)
     comm = None
     if world > 1:
         from graph_learning_amd.batch import make_comm
 
-        comm = make_comm(rank, world, local_rank)
-
-    n, d = args.nodes, args.samples
-    ctx = _lib.Context(local_rank)
+        comm = make_comm(rank, world, local_rank, ctx)  # RCCL over xGMI; bootstrap via /tmp file
     x, _ = logmodel_problem(n, d, seed=rank)
 
     sess = _lib.LogDegreeSession(n, ctx)

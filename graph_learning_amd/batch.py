@@ -1,0 +1,254 @@
+"""Batch of independent graph problems across the GPUs of one node.
+
+The path shards by problem: rank r solves problems r, r + W,
+r + 2W, ... on its own GPU with no collective on the iteration path; at the end
+the learned adjacencies are gathered (BASELINE config 4).  Two communicators
+with the same small interface:
+
+  * ``RcclComm``  -- RCCL over xGMI through the C ABI (``gl_comm_*``); bootstrap of
+    the 128-byte unique id goes through a file in /tmp (single node), keyed by
+    MASTER_PORT and the launcher's pid, so no PyTorch is needed;
+  * ``GlooComm``  -- ``torch.distributed`` with the gloo backend, host buffers
+    only; used by the CPU tests of the sharding / gather logic (and usable where
+    no RCCL is available).
+
+Launch one process per GPU (``python -m torch.distributed.run --nproc-per-node N``
+or any launcher that sets RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+
+import numpy as np
+
+from . import _lib
+
+
+class SingleComm:
+    """World of one: the same interface, nothing to exchange."""
+
+    rank, world = 0, 1
+
+    def barrier(self):
+        pass
+
+    def max_over_ranks(self, x: float) -> float:
+        return float(x)
+
+    def allgather_arrays(self, arr: np.ndarray) -> np.ndarray:
+        return np.asarray(arr)[None]
+
+    def allgather_condensed(self, session, edge_tol=1e-3) -> np.ndarray:
+        return session.weights_condensed(edge_tol)[None]
+
+    def close(self):
+        pass
+
+
+class RcclComm:
+    """RCCL communicator bound to a ``_lib.Context`` (one rank per GPU)."""
+
+    def __init__(self, ctx: _lib.Context, rank: int, world: int, rendezvous_key: str | None = None,
+                 timeout_s: float = 120.0):
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        self._lib = ctx._lib
+        uid = (C.c_char * 128)()
+        path = self._rendezvous_path(rendezvous_key)
+        if self.rank == 0:
+            rc = self._lib.gl_comm_unique_id(uid)
+            if rc != _lib.GL_OK:
+                raise _lib.GraphLearnError("gl_comm_unique_id failed: RCCL is not available")
+            tmp = f"{path}.{os.getpid()}.tmp"
+            with open(tmp, "wb") as f:
+                f.write(bytes(uid))
+            os.replace(tmp, path)  # atomic publish
+        else:
+            deadline = time.monotonic() + timeout_s
+            while True:
+                try:
+                    with open(path, "rb") as f:
+                        data = f.read()
+                    if len(data) == 128:
+                        break
+                except FileNotFoundError:
+                    pass
+                if time.monotonic() > deadline:
+                    raise TimeoutError(f"rank {self.rank}: no RCCL unique id at {path} after {timeout_s}s")
+                time.sleep(0.01)
+            C.memmove(uid, data, 128)
+        self._path = path
+        h = C.c_void_p()
+        ctx.check(self._lib.gl_comm_create(ctx.handle, self.rank, self.world, uid, C.byref(h)), "comm_create")
+        self._h = h
+        self.barrier()
+        if self.rank == 0:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+
+    @staticmethod
+    def _rendezvous_path(key):
+        if key is None:
+            key = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+        return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"graphlearn_amd_{key}.rcclid")
+
+    def barrier(self):
+        self.ctx.check(self._lib.gl_comm_barrier(self._h), "comm_barrier")
+
+    def max_over_ranks(self, x: float) -> float:
+        v = C.c_double(float(x))
+        self.ctx.check(self._lib.gl_comm_allreduce_max(self._h, C.byref(v)), "comm_allreduce_max")
+        return v.value
+
+    def allgather_condensed(self, session, edge_tol=1e-3) -> np.ndarray:
+        """(world, E) array: every rank's condensed, thresholded weights, gathered device-to-device."""
+        out = np.empty((self.world, session.n_edges))
+        self.ctx.check(self._lib.gl_comm_allgather_weights(self._h, session._h, float(edge_tol), _lib.ptr(out)),
+                       "comm_allgather_weights")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gl_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GlooComm:
+    """torch.distributed (gloo) communicator over host buffers -- CPU tests / fallback."""
+
+    def __init__(self, rank: int, world: int, init_method: str | None = None):
+        import torch.distributed as dist
+
+        self._dist = dist
+        self.rank, self.world = int(rank), int(world)
+        self._own = not dist.is_initialized()
+        if self._own:
+            if init_method is None:
+                addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+                port = os.environ.get("MASTER_PORT", "29500")
+                init_method = f"tcp://{addr}:{port}"
+            dist.init_process_group("gloo", init_method=init_method, rank=self.rank, world_size=self.world)
+
+    def barrier(self):
+        self._dist.barrier()
+
+    def max_over_ranks(self, x: float) -> float:
+        import torch
+
+        t = torch.tensor([float(x)], dtype=torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def allgather_arrays(self, arr: np.ndarray) -> np.ndarray:
+        import torch
+
+        a = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64))
+        outs = [torch.empty_like(a) for _ in range(self.world)]
+        self._dist.all_gather(outs, a)
+        return np.stack([o.numpy() for o in outs])
+
+    def allgather_condensed(self, session, edge_tol=1e-3) -> np.ndarray:
+        return self.allgather_arrays(session.weights_condensed(edge_tol))
+
+    def close(self):
+        if self._own and self._dist.is_initialized():
+            self._dist.destroy_process_group()
+
+
+def make_comm(rank: int, world: int, local_rank: int = 0, ctx: _lib.Context | None = None, backend: str = "rccl"):
+    if world <= 1:
+        return SingleComm()
+    if backend == "gloo":
+        return GlooComm(rank, world)
+    return RcclComm(ctx or _lib.Context(local_rank), rank, world)
+
+
+def shard(n_items: int, rank: int, world: int) -> list[int]:
+    """Items of rank r: r, r + W, r + 2W, ... (independent problems, no exchange)."""
+    return list(range(rank, n_items, world))
+
+
+def fit_batch(problems, fit_one, comm=None):
+    """Solve ``problems`` (a sequence) sharded over the ranks of ``comm`` and return, on every
+    rank, the list of all results in problem order.
+
+    ``fit_one(problem) -> 1-D float64 array`` (e.g. condensed weights); all results must have the
+    same length.  Ranks with fewer problems contribute zero-filled rows that are dropped again.
+    """
+    comm = comm or SingleComm()
+    n = len(problems)
+    mine = shard(n, comm.rank, comm.world)
+    local = [np.asarray(fit_one(problems[i]), dtype=np.float64) for i in mine]
+    rounds = (n + comm.world - 1) // comm.world
+    width = comm.max_over_ranks(float(local[0].size if local else 0))
+    width = int(width)
+    out = [None] * n
+    for r in range(rounds):
+        row = local[r] if r < len(local) else np.zeros(width)
+        if row.size != width:
+            raise ValueError("fit_batch: results must all have the same length")
+        gathered = comm.allgather_arrays(row) if hasattr(comm, "allgather_arrays") else None
+        if gathered is None:
+            raise TypeError("fit_batch needs a communicator with allgather_arrays (GlooComm / SingleComm); "
+                            "use LogModelBatch for device-resident RCCL gathers")
+        for src in range(comm.world):
+            idx = r * comm.world + src
+            if idx < n:
+                out[idx] = gathered[src]
+    return out
+
+
+class LogModelBatch:
+    """``LogModel`` over a batch of signal matrices, one problem per GPU at a time.
+
+    Every rank passes the same list ``xs`` (each (n_samples, n_nodes), same n_nodes); rank r fits
+    xs[r], xs[r + W], ...; after each round the condensed weights are all-gathered with RCCL
+    straight from device memory.  ``weights_`` is the (len(xs), E) array on every rank.
+    """
+
+    def __init__(self, avg_degree=None, *, maxit=1000, tol=1e-5, step_size=0.5, edge_tol=1e-3):
+        self.avg_degree, self.maxit, self.tol, self.step_size, self.edge_tol = avg_degree, maxit, tol, step_size, edge_tol
+
+    def fit(self, xs, comm=None, ctx: _lib.Context | None = None):
+        comm = comm or SingleComm()
+        ctx = ctx or getattr(comm, "ctx", None) or _lib.default_context()
+        n_items = len(xs)
+        n_nodes = np.asarray(xs[0]).shape[1]
+        n_edges = n_nodes * (n_nodes - 1) // 2
+        rounds = (n_items + comm.world - 1) // comm.world
+        self.weights_ = np.zeros((n_items, n_edges))
+        self.theta_ = np.ones(n_items)
+        self.n_iter_ = np.zeros(n_items, dtype=np.int64)
+        with _lib.LogDegreeSession(n_nodes, ctx) as s:
+            for r in range(rounds):
+                idx = r * comm.world + comm.rank
+                if idx < n_items:
+                    theta = s.set_signals(xs[idx], self.avg_degree)
+                    s.init(1, 1, self.step_size, None)
+                    n_it, _, _ = s.iterate(self.maxit, self.tol)
+                else:  # idle rank in the last round: contribute the zero iterate
+                    theta, n_it = 1.0, 0
+                    s.set_distances(np.zeros(n_edges))
+                    s.init(1, 1, self.step_size, None)
+                gathered = comm.allgather_condensed(s, self.edge_tol)
+                meta = np.array([theta, float(n_it)])
+                metas = comm.allgather_arrays(meta) if hasattr(comm, "allgather_arrays") else None
+                for src in range(comm.world):
+                    j = r * comm.world + src
+                    if j < n_items:
+                        self.weights_[j] = gathered[src]
+                        if metas is not None:
+                            self.theta_[j], self.n_iter_[j] = metas[src][0], int(metas[src][1])
+                        elif src == comm.rank:
+                            self.theta_[j], self.n_iter_[j] = theta, n_it
+        return self

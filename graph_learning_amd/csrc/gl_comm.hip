@@ -1,0 +1,176 @@
+// RCCL over xGMI, used ONLY as barrier / reduce-of-a-scalar / gather for the
+// batch-of-graphs case (one independent problem per GPU): nothing here is on the
+// iteration path.  librccl is opened lazily (dlopen) so that single-GPU users never
+// load it.
+//
+// The reference has no communication layer at all; this is the
+// one collective step BASELINE config 4 adds: gather the learned adjacencies.
+#include <dlfcn.h>
+
+#include "gl_logdeg.h"
+
+namespace {
+
+// Minimal subset of the RCCL API (ABI-compatible with rccl.h of ROCm 7.x).
+typedef struct ncclComm *ncclComm_t;
+typedef struct {
+    char internal[128];
+} ncclUniqueId;
+typedef int ncclResult_t;
+enum { ncclSuccess = 0 };
+enum { ncclInt32 = 2, ncclFloat64 = 8 };  // ncclDataType_t
+enum { ncclSum = 0, ncclMax = 2 };         // ncclRedOp_t
+
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi *rccl() {
+    static RcclApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *nm : names) {
+            api.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+            if (api.handle) break;
+        }
+        if (api.handle) {
+            api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.handle, "ncclGetUniqueId");
+            api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
+            api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
+            api.AllGather = (decltype(api.AllGather))dlsym(api.handle, "ncclAllGather");
+            api.AllReduce = (decltype(api.AllReduce))dlsym(api.handle, "ncclAllReduce");
+            api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
+            if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.AllReduce) {
+                dlclose(api.handle);
+                api.handle = nullptr;
+            }
+        }
+    }
+    return api.handle ? &api : nullptr;
+}
+
+}  // namespace
+
+struct gl_comm {
+    gl_ctx *ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    double *scratch = nullptr;  // a few device words for barrier / scalar reductions
+    double *gather = nullptr;   // device receive buffer of the last gather
+    size_t gather_bytes = 0;
+};
+
+#define GL_NCCL(ctx, call)                                                                        \
+    do {                                                                                          \
+        ncclResult_t r_ = (call);                                                                 \
+        if (r_ != ncclSuccess)                                                                    \
+            return gl_set_error((ctx), GL_E_COMM, "%s failed: %s", #call,                         \
+                                rccl()->GetErrorString ? rccl()->GetErrorString(r_) : "rccl error"); \
+    } while (0)
+
+GL_API int gl_comm_unique_id(void *out128) {
+    if (!out128) return GL_E_INVALID;
+    RcclApi *api = rccl();
+    if (!api) return GL_E_COMM;
+    ncclUniqueId id;
+    if (api->GetUniqueId(&id) != ncclSuccess) return GL_E_COMM;
+    memcpy(out128, id.internal, sizeof id.internal);
+    return GL_OK;
+}
+
+GL_API int gl_comm_create(gl_ctx *ctx, int rank, int nranks, const void *unique_id128, gl_comm **out) {
+    if (!ctx || !out || !unique_id128) return GL_E_INVALID;
+    *out = nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return gl_set_error(ctx, GL_E_INVALID, "bad rank %d of %d", rank, nranks);
+    RcclApi *api = rccl();
+    if (!api) return gl_set_error(ctx, GL_E_COMM, "librccl could not be loaded: %s", dlerror());
+    GL_HIP(ctx, hipSetDevice(ctx->device));
+    gl_comm *c = new (std::nothrow) gl_comm();
+    if (!c) return GL_E_NOMEM;
+    c->ctx = ctx;
+    c->rank = rank;
+    c->nranks = nranks;
+    ncclUniqueId id;
+    memcpy(id.internal, unique_id128, sizeof id.internal);
+    ncclResult_t r = api->CommInitRank(&c->comm, nranks, id, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return gl_set_error(ctx, GL_E_COMM, "ncclCommInitRank failed: %s",
+                            api->GetErrorString ? api->GetErrorString(r) : "rccl error");
+    }
+    if (hipMalloc((void **)&c->scratch, 64) != hipSuccess) {
+        api->CommDestroy(c->comm);
+        delete c;
+        return gl_set_error(ctx, GL_E_NOMEM, "hipMalloc failed");
+    }
+    *out = c;
+    return GL_OK;
+}
+
+GL_API int gl_comm_destroy(gl_comm *c) {
+    if (!c) return GL_OK;
+    if (c->ctx) {
+        (void)hipSetDevice(c->ctx->device);
+        (void)hipStreamSynchronize(c->ctx->stream);
+    }
+    if (c->comm && rccl()) rccl()->CommDestroy(c->comm);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->gather) (void)hipFree(c->gather);
+    delete c;
+    return GL_OK;
+}
+
+// Device-side barrier: every rank's stream has reached this point when it returns.
+GL_API int gl_comm_barrier(gl_comm *c) {
+    if (!c) return GL_E_INVALID;
+    gl_ctx *ctx = c->ctx;
+    GL_HIP(ctx, hipSetDevice(ctx->device));
+    GL_HIP(ctx, hipMemsetAsync(c->scratch, 0, 8, ctx->stream));
+    GL_NCCL(ctx, rccl()->AllReduce(c->scratch, c->scratch + 1, 1, ncclInt32, ncclSum, c->comm, ctx->stream));
+    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GL_OK;
+}
+
+GL_API int gl_comm_allreduce_max(gl_comm *c, double *value) {
+    if (!c || !value) return GL_E_INVALID;
+    gl_ctx *ctx = c->ctx;
+    GL_HIP(ctx, hipSetDevice(ctx->device));
+    GL_HIP(ctx, hipMemcpyAsync(c->scratch + 2, value, 8, hipMemcpyHostToDevice, ctx->stream));
+    GL_NCCL(ctx, rccl()->AllReduce(c->scratch + 2, c->scratch + 3, 1, ncclFloat64, ncclMax, c->comm, ctx->stream));
+    GL_HIP(ctx, hipMemcpyAsync(value, c->scratch + 3, 8, hipMemcpyDeviceToHost, ctx->stream));
+    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GL_OK;
+}
+
+// Gather of the learned adjacencies (BASELINE config 4): every rank contributes its
+// condensed, thresholded edge vector (E doubles, device-resident, straight from the
+// solver session) and receives all of them; host_out (nranks x E) may be NULL to
+// keep the result on the device only.
+GL_API int gl_comm_allgather_weights(gl_comm *c, gl_logdeg *s, double edge_tol, double *host_out) {
+    if (!c || !s) return GL_E_INVALID;
+    gl_ctx *ctx = c->ctx;
+    if (s->ctx != ctx) return gl_set_error(ctx, GL_E_INVALID, "session and communicator live on different contexts");
+    GL_HIP(ctx, hipSetDevice(ctx->device));
+    // the session's staging buffer receives the condensed, thresholded weights (device only)
+    GL_TRY(gl_logdeg_get_weights_condensed(s, edge_tol, nullptr));
+    const size_t bytes = (size_t)c->nranks * s->n_edges * 8;
+    if (c->gather_bytes < bytes) {
+        if (c->gather) (void)hipFree(c->gather);
+        c->gather = nullptr;
+        c->gather_bytes = 0;
+        GL_HIP(ctx, hipMalloc((void **)&c->gather, bytes));
+        c->gather_bytes = bytes;
+    }
+    GL_NCCL(ctx, rccl()->AllGather(s->stage, c->gather, (size_t)s->n_edges, ncclFloat64, c->comm, ctx->stream));
+    if (host_out) GL_HIP(ctx, hipMemcpyAsync(host_out, c->gather, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GL_OK;
+}

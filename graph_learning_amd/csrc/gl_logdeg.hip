@@ -890,16 +890,18 @@ GL_API int gl_logdeg_iterate(gl_logdeg *s, int64_t maxit, double tol, int64_t *n
 
 GL_API int64_t gl_logdeg_total_iterations(gl_logdeg *s) { return s ? s->it : -1; }
 
+// w_out == NULL: only produce the condensed vector in the session's device staging buffer
+// (used by the RCCL gather, which sends it device-to-device).
 GL_API int gl_logdeg_get_weights_condensed(gl_logdeg *s, double edge_tol, double *w_out) {
     GL_TRY(check(s));
     gl_ctx *ctx = s->ctx;
-    if (!w_out) return gl_set_error(ctx, GL_E_INVALID, "w_out is NULL");
     if (!s->inited) return gl_set_error(ctx, GL_E_STATE, "no iterate yet: call init first");
     GL_HIP(ctx, hipSetDevice(ctx->device));
     k_to_condensed<<<dim3((unsigned)s->dev.ntiles), dim3(256), 0, ctx->stream>>>(s->dev.w[s->it & 1], s->stage, s->n,
                                                                               s->dev.nb, edge_tol);
     GL_HIP(ctx, hipGetLastError());
-    GL_HIP(ctx, hipMemcpyAsync(w_out, s->stage, (size_t)s->n_edges * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (w_out)
+        GL_HIP(ctx, hipMemcpyAsync(w_out, s->stage, (size_t)s->n_edges * 8, hipMemcpyDeviceToHost, ctx->stream));
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GL_OK;
 }

@@ -42,6 +42,7 @@ enum {
 
 typedef struct gl_ctx gl_ctx;
 typedef struct gl_logdeg gl_logdeg;
+typedef struct gl_comm gl_comm;
 
 /* ---- library / context ------------------------------------------------- */
 int gl_version(void);
@@ -98,7 +99,8 @@ int gl_logdeg_iterate_async(gl_logdeg *s, int64_t n_iter);
 
 /* A10: w[w < edge_tol] = 0 (:169) applied on the way out (the resident
  * iterate is not modified); condensed (E) or symmetric square (n x n, zero
- * diagonal, = squareform(w), :171-172).  edge_tol = -inf disables it. */
+ * diagonal, = squareform(w), :171-172).  edge_tol = -inf disables it.
+ * get_weights_condensed(w_out = NULL) only stages the vector on the device. */
 int gl_logdeg_get_weights_condensed(gl_logdeg *s, double edge_tol, double *w_out);
 int gl_logdeg_get_weights_square(gl_logdeg *s, double edge_tol, double *w_out);
 /* Dual variable dvar (n) -- for checkpoint/resume and the parity tests. */
@@ -135,6 +137,21 @@ int gl_squared_pdiffs(gl_ctx *ctx, const double *x, int64_t T, int64_t n_nodes, 
 /* get_theta, blocks=None (graph_learn/smooth_learning.py:201-219) on a host
  * (n,n) matrix of squared distances (zero diagonal included in the ranking). */
 int gl_theta_from_distances(gl_ctx *ctx, const double *zsq, int64_t n_nodes, int avg_degree, double *theta_out);
+
+/* ---- batch of graphs across GPUs (BASELINE config 4) ----------------------
+ * One independent problem per GPU/rank; RCCL over xGMI is used only as a barrier,
+ * a scalar max-reduction (timing) and the final gather of the learned adjacencies.
+ * The reference has no counterpart (it has no communication layer).  Bootstrap:
+ * rank 0 calls gl_comm_unique_id and ships the 128 bytes to the other ranks by any
+ * host channel; then every rank calls gl_comm_create. */
+int gl_comm_unique_id(void *out128);
+int gl_comm_create(gl_ctx *ctx, int rank, int nranks, const void *unique_id128, gl_comm **out);
+int gl_comm_destroy(gl_comm *c);
+int gl_comm_barrier(gl_comm *c);
+int gl_comm_allreduce_max(gl_comm *c, double *value);
+/* All-gather of the condensed, thresholded weights (E doubles per rank) straight
+ * from device memory; host_out is (nranks, E) or NULL. */
+int gl_comm_allgather_weights(gl_comm *c, gl_logdeg *s, double edge_tol, double *host_out);
 
 #ifdef __cplusplus
 }
