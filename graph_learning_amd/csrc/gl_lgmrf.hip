@@ -1,0 +1,602 @@
+// Laplacian-constrained GMRF (Egilmez GGL): block-coordinate descent on MI355X.
+//
+// Reference: graph_learn/lgmrf.py
+//   nonnegative_qp_solver :19-71   -> ADMM kernels below (gl_nonneg_qp_solve)
+//   LGMRF._initialize     :152-167 -> k_lg_prepare
+//   LGMRF._ggl_fit        :169-226 -> lgmrf_fit (per-node loop)
+//   LGMRF.fit             :228-235 -> gl_lgmrf_fit
+//   relative_error, graph_learn/evaluation.py:8-25 -> gl_relative_error
+//
+// State on the device (n x n fp64, row-major): K (scaled input + H), Theta
+// (laplacian_), C = Theta^-1 (inv_laplacian_).  Per node u the reference forms
+// M = C[m,m] - c c'/c_uu (m = all nodes but u), solves a non-negative QP on it by
+// ADMM with the explicit inverse inv(I + rho M[nz,nz]) and applies two rank-1
+// corrections.  Nothing is gathered here: all vectors are length n with entry u
+// (and masked-out entries) pinned to 0, and M is applied as C x - c (c.x)/c_uu.
+//
+// Two ways to apply inv(I + rho Q) inside the ADMM loop:
+//   general path (any adj_mask): W = I + rho M on the active set is built densely and
+//     inverted in place by Gauss-Jordan (SPD, no pivoting) -- O(n^3) per node, like the
+//     reference, for small problems and masked priors;
+//   fast path (default full mask): M = (Theta_mm)^-1, hence
+//         inv(I + rho M) = I - rho (Theta_mm + rho I)^-1,
+//     and (Theta_mm + rho I)^-1 = G_mm - g g'/G_uu with G = (Theta + rho I)^-1 kept up to
+//     date by a rank-2 Woodbury correction per node (row/column u of Theta changes) and
+//     re-computed from scratch once per cycle -- O(n^2) per ADMM step and per node.
+// Both produce the reference's iterates up to rounding; the stopping rules are the
+// reference's.
+#include <vector>
+
+#include "gl_common.h"
+
+namespace {
+
+constexpr int VT = 1024;  // threads of the single-workgroup vector kernels
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ double wmax(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+// block-wide sum / max over VT threads (deterministic order); result in every thread
+__device__ double block_sum(double v, double *sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wsum(v);
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double t = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += sh[k];
+    return t;
+}
+__device__ double block_max(double v, double *sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wmax(v);
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double t = sh[0];
+    for (int k = 1; k < (int)(blockDim.x >> 6); ++k) t = fmax(t, sh[k]);
+    return t;
+}
+
+struct LgDev {
+    double *K, *Th, *C, *G, *W, *ThPrev;  // n x n
+    const double *mask;                   // n x n or null (full)
+    double *p, *x, *z, *uu, *v, *y;       // QP vectors (n)
+    double *act;                          // 1.0 where the entry takes part in the QP of node u
+    double *beta, *t, *a, *h, *gcol;      // post-QP vectors (n)
+    double *scal;                         // scalars: [0] done, [1] qp iterations, [2..] scratch
+    int64_t n;
+    double rho, qp_tol;
+};
+
+// y = A x, one wave per row (rows contiguous); skipped once the QP has stopped (chk_done)
+__global__ __launch_bounds__(256) void k_matvec(const double *__restrict__ A, const double *__restrict__ x,
+                                                double *__restrict__ y, int64_t n, const double *done, int chk_done) {
+    if (chk_done && done[0] != 0.0) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const double *a = A + row * n;
+    double acc = 0;
+    for (int64_t j = lane; j < n; j += 64) acc += a[j] * x[j];
+    acc = wsum(acc);
+    if (lane == 0) y[row] = acc;
+}
+
+// K = x / mean * norm_par + H,  Theta = diag(1 / diag K),  C = diag(diag K)   (lgmrf.py:229,156-164)
+__global__ void k_lg_prepare(const double *__restrict__ x, LgDev D, double mean, double norm_par, double hdiag) {
+    const int64_t i = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= D.n) return;
+    const double h = (i == j ? hdiag : 0.0) - 1.0;  // (2 or 1) * eye - ones
+    const double k = x[i * D.n + j] / mean * norm_par + h;
+    D.K[i * D.n + j] = k;
+    D.Th[i * D.n + j] = (i == j) ? 1.0 / k : 0.0;
+    D.C[i * D.n + j] = (i == j) ? k : 0.0;
+}
+
+// QP of node u: active set, p = k_u / k_uu, ADMM start (x = z = u = 0, v = rho p)   (lgmrf.py:177-202,55)
+__global__ __launch_bounds__(VT) void k_lg_qp_setup(LgDev D, int64_t u) {
+    const double kuu = D.K[u * D.n + u];
+    for (int64_t i = threadIdx.x; i < D.n; i += VT) {
+        const bool on = i != u && (D.mask == nullptr || D.mask[i * D.n + u] == 1.0);
+        const double pi = on ? D.K[i * D.n + u] / kuu : 0.0;
+        D.act[i] = on ? 1.0 : 0.0;
+        D.p[i] = pi;
+        D.x[i] = 0.0;
+        D.z[i] = 0.0;
+        D.uu[i] = 0.0;
+        D.v[i] = on ? (0.0 - 0.0) + D.rho * pi : 0.0;
+        D.gcol[i] = D.G ? D.G[i * D.n + u] : 0.0;
+    }
+    if (threadIdx.x == 0) {
+        D.scal[0] = 0.0;
+        D.scal[1] = 0.0;
+    }
+}
+
+// general path: W = I + rho * M on the active set (identity elsewhere), M = C - c c'/c_uu
+__global__ void k_lg_build_w(LgDev D, int64_t u) {
+    const int64_t i = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= D.n) return;
+    double w = (i == j) ? 1.0 : 0.0;
+    if (D.act[i] != 0.0 && D.act[j] != 0.0) {
+        const double m = D.C[i * D.n + j] - (D.C[i * D.n + u] * D.C[j * D.n + u]) / D.C[u * D.n + u];
+        w += D.rho * m;
+    }
+    D.W[i * D.n + j] = w;
+}
+
+// In-place Gauss-Jordan step k (no pivoting: the matrix is SPD).  After n steps A holds A^-1.
+__global__ void k_gj_pivot(const double *A, int64_t n, int64_t k, double *pivrow, double *pivcol) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const double piv = A[k * n + k];
+    pivrow[j] = (j == k) ? 1.0 / piv : A[k * n + j] / piv;  // scaled pivot row
+    pivcol[j] = A[j * n + k];                               // pivot column before it is overwritten
+}
+__global__ void k_gj_eliminate(double *A, int64_t n, int64_t k, const double *__restrict__ pivrow,
+                               const double *__restrict__ pivcol) {
+    const int64_t i = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    if (i == k) {
+        A[i * n + j] = pivrow[j];
+        return;
+    }
+    const double cur = (j == k) ? 0.0 : A[i * n + j];
+    A[i * n + j] = cur - pivcol[i] * pivrow[j];
+}
+
+// One ADMM step on the vectors (single workgroup), given y = A v:
+//   MODE 0: x' = y                                  (A = explicit inverse)
+//   MODE 1: x' = v - rho (y - g (g.v) / G_uu)        (A = G, fast path)
+// then z' = max(x' + u, 0), u += x' - z', the two relative changes and the stopping rule
+// (lgmrf.py:57-69).  Writes the next right-hand side v = (z' - u) + rho p.
+template <int MODE>
+__global__ __launch_bounds__(VT) void k_lg_admm(LgDev D, int64_t u, int it) {
+    __shared__ double sh[VT / 64];
+    if (D.scal[0] != 0.0) return;
+    const int64_t n = D.n;
+    double s = 0;
+    if (MODE == 1) {
+        double part = 0;
+        for (int64_t i = threadIdx.x; i < n; i += VT) part += D.gcol[i] * D.v[i];  // v_u = 0
+        s = block_sum(part, sh) / D.gcol[u];
+    }
+    double dx2 = 0, x2 = 0, xm = 0, dz2 = 0, z2 = 0, zm = 0;
+    for (int64_t i = threadIdx.x; i < n; i += VT) {
+        const bool on = D.act[i] != 0.0;
+        const double xo = D.x[i], zo = D.z[i], uo = D.uu[i];
+        double xn = 0.0;
+        if (on) xn = (MODE == 0) ? D.y[i] : D.v[i] - D.rho * (D.y[i] - D.gcol[i] * s);
+        double zn = xn + uo;
+        zn = zn < 0 ? 0.0 : zn;
+        const double un = uo + (xn - zn);
+        if (on) {
+            dx2 += (xn - xo) * (xn - xo);
+            x2 += xo * xo;
+            xm = fmax(xm, fabs(xo));
+            dz2 += (zn - zo) * (zn - zo);
+            z2 += zo * zo;
+            zm = fmax(zm, fabs(zo));
+        }
+        D.x[i] = xn;
+        D.z[i] = on ? zn : 0.0;
+        D.uu[i] = on ? un : 0.0;
+        D.v[i] = on ? (zn - un) + D.rho * D.p[i] : 0.0;
+    }
+    dx2 = block_sum(dx2, sh);
+    x2 = block_sum(x2, sh);
+    xm = block_max(xm, sh);
+    dz2 = block_sum(dz2, sh);
+    z2 = block_sum(z2, sh);
+    zm = block_max(zm, sh);
+    if (threadIdx.x == 0) {
+        // relative_error(prev, new): plain norm when prev is allclose to 0 (atol 1e-8)
+        const double rx = (xm <= 1e-8) ? sqrt(dx2) : sqrt(dx2) / sqrt(x2);
+        const double rz = (zm <= 1e-8) ? sqrt(dz2) : sqrt(dz2) / sqrt(z2);
+        D.scal[1] = (double)(it + 1);
+        if (it > 0 && rx < D.qp_tol && rz < D.qp_tol) D.scal[0] = 1.0;
+    }
+}
+
+// beta = -z ; prepares the M beta product: (M beta)_i = (C beta)_i - c_i (c.beta)/c_uu
+__global__ __launch_bounds__(VT) void k_lg_beta(LgDev D, int64_t u) {
+    for (int64_t i = threadIdx.x; i < D.n; i += VT) D.beta[i] = (D.act[i] != 0.0) ? -D.z[i] : 0.0;
+}
+
+// after t = C beta:  t <- M beta (entry u = 0), Theta row/col u, the C row/col u, and the
+// Theta-change vector `a` for the Woodbury correction of G   (lgmrf.py:207-215)
+__global__ __launch_bounds__(VT) void k_lg_node_update(LgDev D, int64_t u) {
+    __shared__ double sh[VT / 64];
+    const int64_t n = D.n;
+    const double cuu = D.C[u * n + u], kuu = D.K[u * n + u];
+    double part = 0;
+    for (int64_t i = threadIdx.x; i < n; i += VT)
+        if (i != u) part += D.C[i * n + u] * D.beta[i];
+    const double cb = block_sum(part, sh);
+    double quad = 0;
+    for (int64_t i = threadIdx.x; i < n; i += VT) {
+        double ti = 0.0;
+        if (i != u) ti = D.t[i] - D.C[i * n + u] * cb / cuu;
+        D.t[i] = ti;  // (M beta)_i
+        quad += D.beta[i] * ti;
+    }
+    quad = block_sum(quad, sh);
+    const double th_uu_old = D.Th[u * n + u];
+    const double th_uu_new = 1.0 / kuu + quad;
+    for (int64_t i = threadIdx.x; i < n; i += VT) {
+        if (i == u) {
+            D.a[i] = 0.5 * (th_uu_new - th_uu_old);
+            continue;
+        }
+        D.a[i] = D.beta[i] - D.Th[i * n + u];
+        D.Th[i * n + u] = D.beta[i];
+        D.Th[u * n + i] = D.beta[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        D.Th[u * n + u] = th_uu_new;
+        D.scal[2] = kuu;
+        D.scal[3] = cuu;
+    }
+}
+
+// C[m,m] = (C[m,m] - c c'/c_uu) + g g'/k_uu with g = (M beta) k_uu; C[u,m] = C[m,u] = -g; C[u,u] = k_uu.
+// Needs the OLD column c for every entry, so the old column is snapshot into `h` first.
+__global__ __launch_bounds__(VT) void k_lg_snap_col(LgDev D, int64_t u) {
+    for (int64_t i = threadIdx.x; i < D.n; i += VT) D.h[i] = D.C[i * D.n + u];
+}
+__global__ void k_lg_update_c(LgDev D, int64_t u) {
+    const int64_t i = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = D.n;
+    if (j >= n) return;
+    const double kuu = D.scal[2], cuu = D.scal[3];
+    const double gi = D.t[i] * kuu, gj = D.t[j] * kuu;
+    double out;
+    if (i == u && j == u)
+        out = kuu;
+    else if (i == u)
+        out = -gj;
+    else if (j == u)
+        out = -gi;
+    else {
+        const double m = D.C[i * n + j] - (D.h[i] * D.h[j]) / cuu;  // lapl_u_inv (lgmrf.py:186-188)
+        out = m + (gi * gj) / kuu;                                  // Sherman-Morrison (:217-219)
+    }
+    D.C[i * n + j] = out;
+}
+
+// Woodbury rank-2 correction of G = (Theta + rho I)^-1 after Theta changed by e_u a' + a e_u':
+//   G <- G - [g h] S^-1 [h g]',  S = [[1 + a.g, a.h], [G_uu, 1 + h_u]],  g = G e_u, h = G a.
+__global__ __launch_bounds__(VT) void k_lg_wood_scal(LgDev D, int64_t u) {
+    __shared__ double sh[VT / 64];
+    const int64_t n = D.n;
+    double ag = 0, ah = 0;
+    for (int64_t i = threadIdx.x; i < n; i += VT) {
+        const double gi = D.G[i * n + u];
+        D.gcol[i] = gi;
+        ag += D.a[i] * gi;
+        ah += D.a[i] * D.h[i];
+    }
+    ag = block_sum(ag, sh);
+    ah = block_sum(ah, sh);
+    if (threadIdx.x == 0) {
+        const double s11 = 1.0 + ag, s12 = ah, s21 = D.G[u * n + u], s22 = 1.0 + D.h[u];
+        const double det = s11 * s22 - s12 * s21;
+        D.scal[4] = s22 / det;   // inverse of S
+        D.scal[5] = -s12 / det;
+        D.scal[6] = -s21 / det;
+        D.scal[7] = s11 / det;
+    }
+}
+__global__ void k_lg_update_g(LgDev D) {
+    const int64_t i = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = D.n;
+    if (j >= n) return;
+    const double i11 = D.scal[4], i12 = D.scal[5], i21 = D.scal[6], i22 = D.scal[7];
+    const double gi = D.gcol[i], hi = D.h[i], gj = D.gcol[j], hj = D.h[j];
+    // [g_i h_i] S^-1 [h_j ; g_j]
+    const double corr = gi * (i11 * hj + i12 * gj) + hi * (i21 * hj + i22 * gj);
+    D.G[i * n + j] -= corr;
+}
+
+// G0 = Theta + rho I (then inverted in place by Gauss-Jordan)
+__global__ void k_lg_shift(const double *__restrict__ Th, double *__restrict__ G, int64_t n, double rho) {
+    const int64_t i = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) G[i * n + j] = Th[i * n + j] + (i == j ? rho : 0.0);
+}
+
+// partial sums of ||a - b||^2, ||a||^2 and max|a| over a flat array (deterministic two-stage reduce)
+__global__ __launch_bounds__(256) void k_relerr_part(const double *__restrict__ a, const double *__restrict__ b,
+                                                     int64_t count, double *__restrict__ part) {
+    __shared__ double sh[4];
+    double d2 = 0, a2 = 0, am = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        const double da = b[i] - a[i];
+        d2 += da * da;
+        a2 += a[i] * a[i];
+        am = fmax(am, fabs(a[i]));
+    }
+    d2 = block_sum(d2, sh);
+    a2 = block_sum(a2, sh);
+    am = block_max(am, sh);
+    if (threadIdx.x == 0) {
+        part[3 * blockIdx.x + 0] = d2;
+        part[3 * blockIdx.x + 1] = a2;
+        part[3 * blockIdx.x + 2] = am;
+    }
+}
+
+// numpy's pairwise summation (np.add.reduce on a contiguous float64 array), exactly
+double np_pairwise_sum(const double *a, int64_t n) {
+    if (n < 8) {
+        double s = 0;
+        for (int64_t i = 0; i < n; ++i) s += a[i];
+        return s;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int k = 0; k < 8; ++k) r[k] = a[k];
+        int64_t i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+        double s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) s += a[i];
+        return s;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+struct Buf {
+    void *p = nullptr;
+    ~Buf() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+// pivrow: 2 n doubles of scratch (scaled pivot row, then the pivot column)
+int invert_spd_inplace(gl_ctx *ctx, double *A, int64_t n, double *pivrow) {
+    const dim3 g1((unsigned)((n + 255) / 256)), g2((unsigned)((n + 255) / 256), (unsigned)n);
+    double *pivcol = pivrow + n;
+    for (int64_t k = 0; k < n; ++k) {
+        k_gj_pivot<<<g1, 256, 0, ctx->stream>>>(A, n, k, pivrow, pivcol);
+        k_gj_eliminate<<<g2, 256, 0, ctx->stream>>>(A, n, k, pivrow, pivcol);
+    }
+    GL_HIP(ctx, hipGetLastError());
+    return GL_OK;
+}
+
+int relative_error_dev(gl_ctx *ctx, const double *a_dev, const double *b_dev, int64_t count, double *part_dev,
+                       double *out) {
+    const int blocks = (int)std::min<int64_t>(256, (count + 255) / 256);
+    k_relerr_part<<<blocks, 256, 0, ctx->stream>>>(a_dev, b_dev, count, part_dev);
+    GL_HIP(ctx, hipGetLastError());
+    std::vector<double> host((size_t)3 * blocks);
+    GL_HIP(ctx, hipMemcpyAsync(host.data(), part_dev, host.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double d2 = 0, a2 = 0, am = 0;
+    for (int b = 0; b < blocks; ++b) {
+        d2 += host[3 * b];
+        a2 += host[3 * b + 1];
+        am = std::max(am, host[3 * b + 2]);
+    }
+    *out = (am <= 1e-8) ? sqrt(d2) : sqrt(d2) / sqrt(a2);  // evaluation.py:21-25
+    return GL_OK;
+}
+
+}  // namespace
+
+// relative_error(y_true, y_pred) of graph_learn/evaluation.py:8-25 on host buffers.
+GL_API int gl_relative_error(gl_ctx *ctx, const double *y_true, const double *y_pred, int64_t count, double *out) {
+    if (!ctx) return GL_E_INVALID;
+    if (!y_true || !y_pred || !out || count < 1) return gl_set_error(ctx, GL_E_INVALID, "bad argument");
+    GL_HIP(ctx, hipSetDevice(ctx->device));
+    Buf a, b, part;
+    GL_HIP(ctx, hipMalloc(&a.p, (size_t)count * 8));
+    GL_HIP(ctx, hipMalloc(&b.p, (size_t)count * 8));
+    GL_HIP(ctx, hipMalloc(&part.p, 3 * 256 * 8));
+    GL_HIP(ctx, hipMemcpyAsync(a.p, y_true, (size_t)count * 8, hipMemcpyHostToDevice, ctx->stream));
+    GL_HIP(ctx, hipMemcpyAsync(b.p, y_pred, (size_t)count * 8, hipMemcpyHostToDevice, ctx->stream));
+    return relative_error_dev(ctx, (double *)a.p, (double *)b.p, count, (double *)part.p, out);
+}
+
+// nonnegative_qp_solver(mat, vec, step, tol, max_iter) of graph_learn/lgmrf.py:19-71 on host buffers:
+// explicit inverse of I + step*mat (Gauss-Jordan on the device), then ADMM.
+GL_API int gl_nonneg_qp_solve(gl_ctx *ctx, const double *mat, const double *vec, int64_t m, double step, double tol,
+                              int max_iter, double *z_out, int *iters_out) {
+    if (!ctx) return GL_E_INVALID;
+    if (!mat || !vec || !z_out || m < 1 || max_iter < 0) return gl_set_error(ctx, GL_E_INVALID, "bad argument");
+    GL_HIP(ctx, hipSetDevice(ctx->device));
+    Buf W, vecs, scal;
+    GL_HIP(ctx, hipMalloc(&W.p, (size_t)m * m * 8));
+    GL_HIP(ctx, hipMalloc(&vecs.p, (size_t)16 * m * 8));
+    GL_HIP(ctx, hipMalloc(&scal.p, 16 * 8));
+    double *V = (double *)vecs.p;
+    LgDev D{};
+    D.n = m;
+    D.W = (double *)W.p;
+    D.p = V;
+    D.x = V + m;
+    D.z = V + 2 * m;
+    D.uu = V + 3 * m;
+    D.v = V + 4 * m;
+    D.y = V + 5 * m;
+    D.act = V + 6 * m;
+    D.gcol = V + 7 * m;
+    double *pivrow = V + 8 * m;
+    D.scal = (double *)scal.p;
+    D.rho = step;
+    D.qp_tol = tol;
+    // W = I + step * mat ; p = vec ; v0 = step * vec ; everything active
+    std::vector<double> hw((size_t)m * m), hv((size_t)9 * m, 0.0);
+    for (int64_t i = 0; i < m; ++i)
+        for (int64_t j = 0; j < m; ++j) hw[(size_t)(i * m + j)] = (i == j ? 1.0 : 0.0) + step * mat[i * m + j];
+    for (int64_t i = 0; i < m; ++i) {
+        hv[(size_t)i] = vec[i];
+        hv[(size_t)(4 * m + i)] = (0.0 - 0.0) + step * vec[i];
+        hv[(size_t)(6 * m + i)] = 1.0;
+    }
+    GL_HIP(ctx, hipMemcpyAsync(D.W, hw.data(), hw.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    GL_HIP(ctx, hipMemcpyAsync(V, hv.data(), hv.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    GL_HIP(ctx, hipMemsetAsync(D.scal, 0, 16 * 8, ctx->stream));
+    GL_TRY(invert_spd_inplace(ctx, D.W, m, pivrow));
+    const unsigned mvb = (unsigned)((m + 3) / 4);
+    for (int it = 0; it < max_iter; ++it) {
+        k_matvec<<<mvb, 256, 0, ctx->stream>>>(D.W, D.v, D.y, m, D.scal, 1);
+        k_lg_admm<0><<<1, VT, 0, ctx->stream>>>(D, /*u=*/-1, it);
+    }
+    GL_HIP(ctx, hipGetLastError());
+    double sc[2];
+    GL_HIP(ctx, hipMemcpyAsync(z_out, D.z, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GL_HIP(ctx, hipMemcpyAsync(sc, D.scal, 16, hipMemcpyDeviceToHost, ctx->stream));
+    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (iters_out) *iters_out = (int)sc[1];
+    return GL_OK;
+}
+
+// LGMRF(norm_par, prob_tol, max_cycle, qp_step, qp_tol, regularization_type, adj_mask).fit(x)
+// for the generalized Laplacian set (lgmrf.py:228-235).  x is n x n (not modified).
+// path: 0 = automatic (fast when the mask is all ones / NULL), 1 = force general, 2 = force fast.
+GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par, double prob_tol, int max_cycle,
+                        double qp_step, double qp_tol, int regularization_type, const double *adj_mask, int path,
+                        double *laplacian_out, double *inv_laplacian_out, int *converged_out, int *cycles_out) {
+    if (!ctx) return GL_E_INVALID;
+    if (!x || !laplacian_out || !inv_laplacian_out || n < 2) return gl_set_error(ctx, GL_E_INVALID, "bad argument");
+    if (regularization_type != 1 && regularization_type != 2)
+        return gl_set_error(ctx, GL_E_INVALID, "regularization type can be either 1 or 2, got %d", regularization_type);
+    GL_HIP(ctx, hipSetDevice(ctx->device));
+
+    bool full_mask = true;
+    if (adj_mask)
+        for (int64_t i = 0; i < n * n && full_mask; ++i) full_mask = adj_mask[i] == 1.0;
+    if (path == 2 && !full_mask) return gl_set_error(ctx, GL_E_INVALID, "the fast path needs an all-ones adj_mask");
+    const bool fast = (path == 2) || (path == 0 && full_mask);
+
+    const size_t nn = (size_t)n * n * 8;
+    Buf bx, bK, bTh, bC, bG, bW, bPrev, bMask, bVec, bScal, bPart;
+    GL_HIP(ctx, hipMalloc(&bx.p, nn));
+    GL_HIP(ctx, hipMalloc(&bK.p, nn));
+    GL_HIP(ctx, hipMalloc(&bTh.p, nn));
+    GL_HIP(ctx, hipMalloc(&bC.p, nn));
+    GL_HIP(ctx, hipMalloc(&bPrev.p, nn));
+    if (fast)
+        GL_HIP(ctx, hipMalloc(&bG.p, nn));
+    else
+        GL_HIP(ctx, hipMalloc(&bW.p, nn));
+    if (adj_mask && !full_mask) {
+        GL_HIP(ctx, hipMalloc(&bMask.p, nn));
+        GL_HIP(ctx, hipMemcpyAsync(bMask.p, adj_mask, nn, hipMemcpyHostToDevice, ctx->stream));
+    }
+    GL_HIP(ctx, hipMalloc(&bVec.p, (size_t)16 * n * 8));
+    GL_HIP(ctx, hipMalloc(&bScal.p, 16 * 8));
+    GL_HIP(ctx, hipMalloc(&bPart.p, 3 * 256 * 8));
+    GL_HIP(ctx, hipMemsetAsync(bVec.p, 0, (size_t)16 * n * 8, ctx->stream));
+    GL_HIP(ctx, hipMemsetAsync(bScal.p, 0, 16 * 8, ctx->stream));
+
+    LgDev D{};
+    D.n = n;
+    D.K = (double *)bK.p;
+    D.Th = (double *)bTh.p;
+    D.C = (double *)bC.p;
+    D.G = (double *)bG.p;
+    D.W = (double *)bW.p;
+    D.ThPrev = (double *)bPrev.p;
+    D.mask = (const double *)bMask.p;
+    double *V = (double *)bVec.p;
+    D.p = V;
+    D.x = V + n;
+    D.z = V + 2 * n;
+    D.uu = V + 3 * n;
+    D.v = V + 4 * n;
+    D.y = V + 5 * n;
+    D.act = V + 6 * n;
+    D.beta = V + 7 * n;
+    D.t = V + 8 * n;
+    D.a = V + 9 * n;
+    D.h = V + 10 * n;
+    D.gcol = V + 11 * n;
+    double *pivrow = V + 12 * n;
+    D.scal = (double *)bScal.p;
+    D.rho = qp_step;
+    D.qp_tol = qp_tol;
+
+    // x = x / np.mean(x) * norm_par   (lgmrf.py:229; the mean uses numpy's pairwise summation)
+    const double mean = np_pairwise_sum(x, n * n) / (double)(n * n);
+    GL_HIP(ctx, hipMemcpyAsync(bx.p, x, nn, hipMemcpyHostToDevice, ctx->stream));
+    const dim3 g2((unsigned)((n + 255) / 256), (unsigned)n);
+    k_lg_prepare<<<g2, 256, 0, ctx->stream>>>((const double *)bx.p, D, mean, norm_par,
+                                              regularization_type == 1 ? 2.0 : 1.0);
+    GL_HIP(ctx, hipGetLastError());
+
+    const unsigned mvb = (unsigned)((n + 3) / 4);
+    const int max_qp_iter = 100;  // default of nonnegative_qp_solver (lgmrf.py:24)
+    int converged = -1, cycles = 0;
+    for (int cycle = 0; cycle < max_cycle; ++cycle) {
+        GL_HIP(ctx, hipMemcpyAsync(D.ThPrev, D.Th, nn, hipMemcpyDeviceToDevice, ctx->stream));  // l_pre (:173)
+        if (fast) {  // fresh G = (Theta + rho I)^-1 once per cycle; rank-2 corrections in between
+            k_lg_shift<<<g2, 256, 0, ctx->stream>>>(D.Th, D.G, n, D.rho);
+            GL_TRY(invert_spd_inplace(ctx, D.G, n, pivrow));
+        }
+        for (int64_t u = 0; u < n; ++u) {
+            k_lg_qp_setup<<<1, VT, 0, ctx->stream>>>(D, u);
+            if (!fast) {
+                k_lg_build_w<<<g2, 256, 0, ctx->stream>>>(D, u);
+                GL_TRY(invert_spd_inplace(ctx, D.W, n, pivrow));
+            }
+            for (int it = 0; it < max_qp_iter; ++it) {
+                if (fast) {
+                    k_matvec<<<mvb, 256, 0, ctx->stream>>>(D.G, D.v, D.y, n, D.scal, 1);
+                    k_lg_admm<1><<<1, VT, 0, ctx->stream>>>(D, u, it);
+                } else {
+                    k_matvec<<<mvb, 256, 0, ctx->stream>>>(D.W, D.v, D.y, n, D.scal, 1);
+                    k_lg_admm<0><<<1, VT, 0, ctx->stream>>>(D, u, it);
+                }
+            }
+            k_lg_beta<<<1, VT, 0, ctx->stream>>>(D, u);
+            k_matvec<<<mvb, 256, 0, ctx->stream>>>(D.C, D.beta, D.t, n, D.scal, 0);
+            k_lg_snap_col<<<1, VT, 0, ctx->stream>>>(D, u);
+            k_lg_node_update<<<1, VT, 0, ctx->stream>>>(D, u);
+            k_lg_update_c<<<g2, 256, 0, ctx->stream>>>(D, u);
+            if (fast) {
+                k_matvec<<<mvb, 256, 0, ctx->stream>>>(D.G, D.a, D.h, n, D.scal, 0);
+                k_lg_wood_scal<<<1, VT, 0, ctx->stream>>>(D, u);
+                k_lg_update_g<<<g2, 256, 0, ctx->stream>>>(D);
+            }
+            GL_HIP(ctx, hipGetLastError());
+            if ((u & 15) == 15) GL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // bound the launch queue
+        }
+        cycles = cycle + 1;
+        if (cycle > 4) {  // :221
+            double rel = 0;
+            GL_TRY(relative_error_dev(ctx, D.ThPrev, D.Th, n * n, (double *)bPart.p, &rel));
+            if (rel < prob_tol) {
+                converged = cycle;
+                break;
+            }
+        } else {
+            GL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // bound the launch queue
+        }
+    }
+    GL_HIP(ctx, hipMemcpyAsync(laplacian_out, D.Th, nn, hipMemcpyDeviceToHost, ctx->stream));
+    GL_HIP(ctx, hipMemcpyAsync(inv_laplacian_out, D.C, nn, hipMemcpyDeviceToHost, ctx->stream));
+    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (converged_out) *converged_out = converged;
+    if (cycles_out) *cycles_out = cycles;
+    return GL_OK;
+}

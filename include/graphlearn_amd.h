@@ -153,6 +153,23 @@ int gl_comm_allreduce_max(gl_comm *c, double *value);
  * from device memory; host_out is (nranks, E) or NULL. */
 int gl_comm_allgather_weights(gl_comm *c, gl_logdeg *s, double edge_tol, double *host_out);
 
+/* ---- Laplacian-constrained GMRF (graph_learn/lgmrf.py, graph_learn/evaluation.py) ---- */
+/* relative_error(y_true, y_pred) (evaluation.py:8-25): ||pred-true||_F / ||true||_F, or the
+ * plain norm when y_true is allclose to 0. */
+int gl_relative_error(gl_ctx *ctx, const double *y_true, const double *y_pred, int64_t count, double *out);
+/* nonnegative_qp_solver(mat, vec, step, tol, max_iter) (lgmrf.py:19-71): ADMM for
+ * min 1/2 b'Qb - b'p, b >= 0; mat is m x m, z_out is m; iters_out = ADMM iterations run. */
+int gl_nonneg_qp_solve(gl_ctx *ctx, const double *mat, const double *vec, int64_t m, double step, double tol,
+                       int max_iter, double *z_out, int *iters_out);
+/* LGMRF(norm_par, prob_tol, max_cycle, qp_step, qp_tol, regularization_type, adj_mask).fit(x) for the
+ * generalized Laplacian set (lgmrf.py:109-235).  x is n x n (covariance / kernel, not modified);
+ * adj_mask is n x n or NULL (fully connected); outputs: laplacian_, inv_laplacian_ (n x n each),
+ * converged_ (cycle index or -1) and the number of cycles run.
+ * path: 0 automatic, 1 general (explicit inverse per node), 2 fast (needs an all-ones mask). */
+int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n_nodes, double norm_par, double prob_tol, int max_cycle,
+                 double qp_step, double qp_tol, int regularization_type, const double *adj_mask, int path,
+                 double *laplacian_out, double *inv_laplacian_out, int *converged_out, int *cycles_out);
+
 #ifdef __cplusplus
 }
 #endif

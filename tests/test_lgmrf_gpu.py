@@ -1,0 +1,100 @@
+"""LGMRF on the GPU (through the C ABI) against the reference's golden vectors and the oracle.
+
+Tolerances: the device applies the same iteration as the reference but inverts I + rho M by
+Gauss-Jordan (general path) or through the Woodbury-maintained (Theta + rho I)^-1 (fast path)
+instead of LAPACK's inv, and sums in a different order: iterates agree to rounding times the
+conditioning; the ADMM / cycle stopping rules are discontinuous at their tolerances (1e-6 / 1e-3),
+so final matrices are compared to 1e-6 relative to their scale, and `converged_` exactly.
+"""
+
+import numpy as np
+import pytest
+
+from graph_learning_amd import LGMRF, nonnegative_qp_solver, relative_error
+from oracle import lgmrf as olg
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rel=1e-6):
+    return np.abs(a - b).max() <= rel * max(np.abs(b).max(), 1e-300)
+
+
+def test_relative_error(golden):
+    g = golden("lgmrf")
+    assert relative_error(g["re_a"], g["re_b"]) == pytest.approx(float(g["re_ab"]), rel=1e-13)
+    assert relative_error(np.zeros((5, 5)), g["re_b"]) == pytest.approx(float(g["re_0b"]), rel=1e-13)
+    with pytest.raises(ValueError):
+        relative_error(np.zeros(3), np.zeros(4))
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_qp_solver_golden(golden, tag):
+    g = golden("lgmrf")
+    q, p = g[f"qp_{tag}_Q"], g[f"qp_{tag}_p"]
+    tol, mi = float(g[f"qp_{tag}_tol"]), int(g[f"qp_{tag}_maxit"])
+    z, iters = nonnegative_qp_solver(q, p, step=0.1, tol=tol, max_iter=mi, return_iters=True)
+    _, ref_iters = olg.nonneg_qp_admm(q, p, step=0.1, tol=tol, max_iter=mi, return_iters=True)
+    assert abs(iters - ref_iters) <= 1
+    np.testing.assert_allclose(z, g[f"qp_{tag}_z"], rtol=0, atol=1e-7 if iters != ref_iters else 1e-11)
+    assert (z >= 0).all()
+
+
+@pytest.mark.parametrize("path", [1, 2])
+@pytest.mark.parametrize("n,npar,rt", [(8, 1, 1), (8, 1, 2), (8, 10, 1), (8, 10, 2), (16, 1, 1), (16, 10, 2), (32, 1, 1)])
+def test_lgmrf_fit_golden(golden, n, npar, rt, path):
+    g = golden("lgmrf")
+    cov = g[f"cov_{n}"].copy()
+    m = LGMRF(norm_par=npar, regularization_type=rt).fit(cov, path=path)
+    assert np.array_equal(cov, g[f"cov_{n}"])                      # input not modified
+    assert m.n_nodes_ == n and m.converged_ == int(g[f"conv_{n}_np{npar}_rt{rt}"])
+    assert close(m.laplacian_, g[f"lapl_{n}_np{npar}_rt{rt}"])
+    assert close(m.inv_laplacian_, g[f"inv_{n}_np{npar}_rt{rt}"])
+    # structure: symmetric, non-positive off-diagonals (generalized Laplacian), inverse consistent
+    assert np.allclose(m.laplacian_, m.laplacian_.T, rtol=0, atol=1e-12)
+    off = m.laplacian_[~np.eye(n, dtype=bool)]
+    assert (off <= 0).all()
+    assert np.allclose(m.laplacian_ @ m.inv_laplacian_, np.eye(n), atol=1e-8)
+
+
+def test_lgmrf_mask_and_cycle_cap(golden):
+    g = golden("lgmrf")
+    m = LGMRF(adj_mask=g["mask_16"].copy()).fit(g["cov_16"].copy())
+    assert m.converged_ == int(g["conv_16_mask"])
+    assert close(m.laplacian_, g["lapl_16_mask"]) and close(m.inv_laplacian_, g["inv_16_mask"])
+    assert (m.laplacian_[g["mask_16"] == 0] == 0).all()            # masked-out pairs stay disconnected
+    m = LGMRF(max_cycle=3).fit(g["cov_16"].copy())
+    assert m.converged_ == -1 == int(g["conv_16_cyc3"]) and m.n_cycles_ == 3
+    assert close(m.laplacian_, g["lapl_16_cyc3"])
+
+
+def test_lgmrf_errors():
+    x = np.eye(4) + 1.0
+    with pytest.raises(ValueError):
+        LGMRF(laplacian_set="nope").fit(x.copy())
+    with pytest.raises(ValueError):
+        LGMRF(regularization_type=3).fit(x.copy())
+    with pytest.raises(ValueError):
+        LGMRF(adj_mask=np.ones((3, 3))).fit(x.copy())
+    with pytest.raises(NotImplementedError):
+        LGMRF(laplacian_set="c").fit(x.copy())
+    assert LGMRF().get_params()["qp_step"] == 0.1
+
+
+def test_fast_path_matches_general_path_and_oracle_n96():
+    """Beyond the golden sizes: n=96, precision L + I, both device paths vs the oracle."""
+    rng = np.random.default_rng(3)
+    n = 96
+    e = n * (n - 1) // 2
+    w = (rng.uniform(size=e) < 6.0 / n) * rng.uniform(0.3, 2.0, size=e)
+    lap = np.zeros((n, n))
+    lap[np.triu_indices(n, 1)] = -w
+    lap = lap + lap.T
+    lap[np.arange(n), np.arange(n)] = -lap.sum(1)
+    x = rng.multivariate_normal(np.zeros(n), np.linalg.inv(lap + np.eye(n)), size=30 * n)
+    cov = x.T @ x / x.shape[0]
+    o = olg.LGMRFOracle().fit(cov.copy())
+    for path in (1, 2):
+        m = LGMRF().fit(cov.copy(), path=path)
+        assert m.converged_ == o.converged_
+        assert close(m.laplacian_, o.laplacian_) and close(m.inv_laplacian_, o.inv_laplacian_)
