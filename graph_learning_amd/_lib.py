@@ -58,6 +58,7 @@ SIGNATURES = {
     "gl_logdeg_get_weights_square": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p]),
     "gl_logdeg_get_dual": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gl_logdeg_total_iterations": (C.c_int64, [C.c_void_p]),
+    "gl_logdeg_batch_gram": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "gl_log_degrees_fit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p,
                                      C.c_int64, C.c_double, C.c_double, C.c_double, C.c_void_p, _c_int64_p,
                                      _c_double_p]),

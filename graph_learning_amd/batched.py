@@ -1,0 +1,73 @@
+"""Batched (2-D) path of ``gsp_learn_graph_log_degrees`` -- B graphs with a COUPLED stopping rule.
+
+Reference semantics (graph_learn/smooth_learning.py:128-129,158-159,174): with ``distances`` of
+shape (B, E) every array in the loop is (E, B) / (n, B), ``np.linalg.norm(M, ord=2)`` is then the
+SPECTRAL norm of the matrix, and all B graphs stop at the same iteration.  Used by
+``WindowLogModel`` (temporal/smooth.py) and by the clustering M-steps.
+
+Here each graph is a device-resident solver session advancing in lockstep; after every iteration
+the four B x B Gram matrices of the updates are reduced on the GPU (``gl_logdeg_batch_gram``) and
+the spectral norms are ``sqrt(lambda_max)`` of them.  The per-iteration host round trip makes this
+path latency-bound; it is meant for the many-small-graphs regime the reference uses it in.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _n_nodes_from_edges(n_edges: int) -> int:
+    return int(np.round((1 + np.sqrt(1 + 8 * n_edges)) / 2))
+
+
+def _spectral(gram: np.ndarray) -> float:
+    """Largest singular value of a matrix given the Gram matrix of its columns."""
+    return float(np.sqrt(max(np.linalg.eigvalsh(gram)[-1], 0.0)))
+
+
+def learn_log_degrees_batch(distances, alpha, beta, edge_init=None, maxit=1000, tol=1e-5, step_size=0.5,
+                            edge_tol=1e-3, ctx=None, return_info=False):
+    distances = _lib.as_f64(distances)
+    if distances.ndim != 2:
+        raise ValueError("Distances must be vector or matrix")
+    n_batch, n_edges = distances.shape
+    n = _n_nodes_from_edges(n_edges)
+    if edge_init is not None:
+        # the reference uses edge_init as the (E, B) iterate directly
+        edge_init = _lib.as_f64(edge_init)
+        if edge_init.shape != (n_edges, n_batch):
+            raise ValueError(f"edge_init must have shape ({n_edges}, {n_batch}) for batched input")
+    ctx = ctx or _lib.default_context()
+    lib = ctx._lib
+    sessions = [_lib.LogDegreeSession(n, ctx) for _ in range(n_batch)]
+    try:
+        for b, s in enumerate(sessions):
+            s.set_distances(distances[b])
+            s.init(alpha, beta, step_size, None if edge_init is None else np.ascontiguousarray(edge_init[:, b]))
+        handles = (C.c_void_p * n_batch)(*[s._h for s in sessions])
+        gram = np.empty((4, n_batch, n_batch))
+        rel_p = rel_d = np.inf
+        n_iter, converged = 0, False
+        for i in range(int(maxit)):
+            for s in sessions:
+                s.iterate_async(1)
+            n_iter = i + 1
+            if i > 0:  # :156-161
+                ctx.check(lib.gl_logdeg_batch_gram(handles, n_batch, _lib.ptr(gram)), "batch_gram")
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    rel_p = np.float64(_spectral(gram[0])) / np.float64(_spectral(gram[1]))
+                    rel_d = np.float64(_spectral(gram[2])) / np.float64(_spectral(gram[3]))
+            if rel_p < tol and rel_d < tol:  # :166-167 (after the update, like the reference)
+                converged = True
+                break
+        out = np.stack([s.weights_condensed(edge_tol) for s in sessions])  # (B, E) == edge_w.T (:174)
+    finally:
+        for s in sessions:
+            s.close()
+    if return_info:
+        return out, {"n_iter": n_iter, "rel_primal": float(rel_p), "rel_dual": float(rel_d), "converged": converged}
+    return out

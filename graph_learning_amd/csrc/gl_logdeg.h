@@ -8,6 +8,7 @@ struct LogdegDev {
     double *w[2];          // edge iterate, tiled layout, ping-pong: iterate `it` lives in w[it & 1]
     const double *z;       // scaled squared distances, tiled layout
     double *dvar;          // dual variable d            (n_pad)
+    double *dprev;         // d of the previous iteration (for the coupled stopping rule of the batched path)
     double *ybar;          // forward dual point  ybar   (n_pad)
     double *pbar;          // prox dual point     pbar   (n_pad)
     double *rowslab_p;     // row-degree partials of p:     [J][node i],  J >= I(i)      (nb x n_pad)

@@ -396,6 +396,7 @@ __global__ __launch_bounds__(NODE_WAVES * 64) void k_node(LogdegDev P) {
         // next iteration's forward + prox on the dual side (:148, :151)
         const double ybn = dnew + P.gamma * sw;
         const double pbn = (ybn - sqrt(ybn * ybn + P.a4g)) / 2;
+        if (!INIT) P.dprev[i] = d_old;
         P.dvar[i] = real ? dnew : 0.0;
         P.ybar[i] = real ? ybn : 0.0;
         P.pbar[i] = real ? pbn : 0.0;
@@ -553,6 +554,45 @@ __global__ void k_fill(double *p, int64_t count, double v) {
     if (i < count) p[i] = v;
 }
 
+// Inner products between two problems' last updates (batched path, smooth_learning.py:158-159
+// with 2-D input: the norms there are SPECTRAL norms of the (E x B) / (n x B) matrices, which
+// only need the B x B Gram matrices of their columns).  Per pair (a, b):
+//   out[0] = <dw_a, dw_b>, dw = w_new - w_old (== q - y)     out[1] = <w_old_a, w_old_b>
+//   out[2] = <dd_a, dd_b>, dd = d_new - d_old (== qbar-ybar)  out[3] = <d_old_a, d_old_b>
+__global__ __launch_bounds__(256) void k_pair_dots(const double *__restrict__ wa_new, const double *__restrict__ wa_old,
+                                                   const double *__restrict__ wb_new, const double *__restrict__ wb_old,
+                                                   const double *__restrict__ da, const double *__restrict__ dpa,
+                                                   const double *__restrict__ db, const double *__restrict__ dpb,
+                                                   int64_t n_tiled, int64_t n_nodes, double *__restrict__ part) {
+    __shared__ double sh[4][4];
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_tiled; i += (int64_t)gridDim.x * 256) {
+        const double ao = wa_old[i], bo = wb_old[i];
+        s0 += (wa_new[i] - ao) * (wb_new[i] - bo);
+        s1 += ao * bo;
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = threadIdx.x; i < n_nodes; i += 256) {
+            s2 += (da[i] - dpa[i]) * (db[i] - dpb[i]);
+            s3 += dpa[i] * dpb[i];
+        }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    s3 = wave_sum(s3);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        sh[0][wave] = s0;
+        sh[1][wave] = s1;
+        sh[2][wave] = s2;
+        sh[3][wave] = s3;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        part[4 * blockIdx.x + threadIdx.x] =
+            ((sh[threadIdx.x][0] + sh[threadIdx.x][1]) + sh[threadIdx.x][2]) + sh[threadIdx.x][3];
+}
+
 int check(gl_logdeg *s) { return (s && s->ctx) ? GL_OK : GL_E_INVALID; }
 
 // Where the column partials go.  The partition of the flat row-pair list over the
@@ -682,7 +722,7 @@ GL_API int gl_logdeg_create(gl_ctx *ctx, int64_t n_nodes, gl_logdeg **out) {
     int rc = GL_OK;
     double *zbuf = nullptr;
     if ((rc = alloc((void **)&D.w[0], tiled_bytes)) || (rc = alloc((void **)&D.w[1], tiled_bytes)) ||
-        (rc = alloc((void **)&zbuf, tiled_bytes)) || (rc = alloc((void **)&D.dvar, D.n_pad * 8)) ||
+        (rc = alloc((void **)&zbuf, tiled_bytes)) || (rc = alloc((void **)&D.dvar, D.n_pad * 8)) || (rc = alloc((void **)&D.dprev, D.n_pad * 8)) ||
         (rc = alloc((void **)&D.ybar, D.n_pad * 8)) || (rc = alloc((void **)&D.pbar, D.n_pad * 8)) ||
         (rc = alloc((void **)&D.rowslab_p, (size_t)D.nb * D.n_pad * 8)) ||
         (rc = alloc((void **)&D.rowslab_w, (size_t)D.nb * D.n_pad * 8)) ||
@@ -710,7 +750,7 @@ GL_API int gl_logdeg_destroy(gl_logdeg *s) {
     }
     drop_graph(s);
     LogdegDev &D = s->dev;
-    void *ptrs[] = {D.w[0], D.w[1], const_cast<double *>(D.z), D.dvar, D.ybar, D.pbar, D.rowslab_p, D.rowslab_w,
+    void *ptrs[] = {D.w[0], D.w[1], const_cast<double *>(D.z), D.dvar, D.dprev, D.ybar, D.pbar, D.rowslab_p, D.rowslab_w,
                     D.colslab, D.tnorm, D.bnorm, D.dstat, D.ctr, s->stage, s->zsq, s->xdev, s->theta_terms,
                     s->col_ptr, s->seg_dest};
     for (void *p : ptrs)
@@ -809,6 +849,7 @@ GL_API int gl_logdeg_init(gl_logdeg *s, double alpha, double beta, double step_s
     }
     GL_HIP(ctx, hipMemsetAsync(D.w[1], 0, tiled_bytes, ctx->stream));
     GL_HIP(ctx, hipMemsetAsync(D.bnorm, 0, (size_t)2 * D.nb * 4 * 8, ctx->stream));
+    GL_HIP(ctx, hipMemsetAsync(D.dprev, 0, (size_t)D.n_pad * 8, ctx->stream));
     GL_HIP(ctx, hipMemsetAsync(D.ctr, 0, 8 * 8, ctx->stream));
     const double inf = std::numeric_limits<double>::infinity();
     double *st = (double *)ctx->pinned;
@@ -966,3 +1007,51 @@ GL_API int gl_logmodel_fit_signals(gl_ctx *ctx, const double *x, int64_t d, int6
     gl_logdeg_destroy(s);
     return rc;
 }
+
+// Gram matrices of the last iteration across B sessions (same context, same n):
+// out is 4 x B x B (row-major): [dw.dw, w_old.w_old, dd.dd, d_old.d_old].
+GL_API int gl_logdeg_batch_gram(gl_logdeg **sessions, int B, double *out) {
+    if (!sessions || B < 1 || !out) return GL_E_INVALID;
+    for (int a = 0; a < B; ++a) GL_TRY(check(sessions[a]));
+    gl_ctx *ctx = sessions[0]->ctx;
+    for (int a = 0; a < B; ++a) {
+        if (sessions[a]->ctx != ctx || sessions[a]->n != sessions[0]->n)
+            return gl_set_error(ctx, GL_E_INVALID, "batched sessions must share the context and n_nodes");
+        if (!sessions[a]->inited || sessions[a]->it < 1 || sessions[a]->it != sessions[0]->it)
+            return gl_set_error(ctx, GL_E_STATE, "batched sessions must have run the same number (>= 1) of iterations");
+    }
+    GL_HIP(ctx, hipSetDevice(ctx->device));
+    const LogdegDev &D0 = sessions[0]->dev;
+    const int64_t n_tiled = D0.ntiles * GL_TILE_ELEMS;
+    const int blocks = (int)std::min<int64_t>(512, (n_tiled + 255) / 256);
+    const int npairs = B * (B + 1) / 2;
+    double *part = nullptr;
+    GL_HIP(ctx, hipMalloc((void **)&part, (size_t)npairs * blocks * 4 * 8));
+    int pi = 0;
+    for (int a = 0; a < B; ++a)
+        for (int b = a; b < B; ++b, ++pi) {
+            const gl_logdeg *sa = sessions[a], *sb = sessions[b];
+            const int64_t it = sa->it;
+            k_pair_dots<<<blocks, 256, 0, ctx->stream>>>(sa->dev.w[it & 1], sa->dev.w[(it + 1) & 1], sb->dev.w[it & 1],
+                                                         sb->dev.w[(it + 1) & 1], sa->dev.dvar, sa->dev.dprev,
+                                                         sb->dev.dvar, sb->dev.dprev, n_tiled, sa->n,
+                                                         part + (size_t)pi * blocks * 4);
+        }
+    std::vector<double> host((size_t)npairs * blocks * 4);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(host.data(), part, host.size() * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(part);
+    if (e != hipSuccess) return gl_set_error(ctx, GL_E_HIP, "batch_gram: %s", hipGetErrorString(e));
+    pi = 0;
+    for (int a = 0; a < B; ++a)
+        for (int b = a; b < B; ++b, ++pi)
+            for (int q = 0; q < 4; ++q) {
+                double acc = 0;
+                for (int k = 0; k < blocks; ++k) acc += host[((size_t)pi * blocks + k) * 4 + q];
+                out[((size_t)q * B + a) * B + b] = acc;
+                out[((size_t)q * B + b) * B + a] = acc;
+            }
+    return GL_OK;
+}
+

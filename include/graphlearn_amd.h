@@ -107,6 +107,14 @@ int gl_logdeg_get_weights_square(gl_logdeg *s, double edge_tol, double *w_out);
 int gl_logdeg_get_dual(gl_logdeg *s, double *d_out);
 int64_t gl_logdeg_total_iterations(gl_logdeg *s);
 
+/* Batched (2-D) path of gsp_learn_graph_log_degrees (smooth_learning.py:128-129,158-159):
+ * with (B, E) input the reference's norms are spectral norms of (E x B) / (n x B) matrices and
+ * all B graphs stop together.  This returns the four B x B Gram matrices of the last iteration
+ * over B sessions that advanced in lockstep (out: 4 x B x B =
+ * [<dw_a,dw_b>, <w_old_a,w_old_b>, <dd_a,dd_b>, <d_old_a,d_old_b>]); the caller takes
+ * sqrt(lambda_max) of each for the stopping rule. */
+int gl_logdeg_batch_gram(gl_logdeg **sessions, int B, double *out);
+
 /* One-shot forms (what the reference-side binding calls). */
 /* gsp_learn_graph_log_degrees(distances, alpha, beta, edge_init, maxit, tol,
  * step_size, edge_tol) for 1-D input -> condensed weights (E). */

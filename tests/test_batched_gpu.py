@@ -1,0 +1,58 @@
+"""2-D (batched) path of the solver and WindowLogModel against the reference's golden vectors:
+spectral-norm coupled stopping rule (smooth_learning.py:158-159 on 2-D arrays) and the
+reference's own smoke test shapes (tests/test_models.py:26-28)."""
+
+from itertools import product
+
+import numpy as np
+import pytest
+from numpy.random import default_rng
+
+from graph_learning_amd import gsp_learn_graph_log_degrees
+from graph_learning_amd.temporal import WindowLogModel
+from oracle import logdeg as old
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batched_fixed_iterations(golden):
+    g = golden("batched_B3_n12")
+    out = gsp_learn_graph_log_degrees(g["z"].copy(), 1, 1, maxit=40, tol=0.0, edge_tol=-np.inf)
+    assert out.shape == g["z"].shape
+    np.testing.assert_allclose(out, g["raw_w_it40"], rtol=0, atol=1e-10)
+
+
+def test_batched_coupled_stopping_rule(golden):
+    g = golden("batched_B3_n12")
+    out, info = gsp_learn_graph_log_degrees(g["z"].copy(), 1, 1, maxit=5000, tol=1e-4, edge_tol=1e-3, return_info=True)
+    assert info["converged"] and abs(info["n_iter"] - int(g["n_iter_converged"])) <= 1
+    ref = g["w_converged"]
+    raw, _ = old.learn_log_degrees(g["z"].copy(), 1, 1, maxit=int(g["n_iter_converged"]), tol=0.0, edge_tol=-np.inf,
+                                   return_info=True)
+    near = np.abs(raw - 1e-3) < 1e-6
+    np.testing.assert_allclose(out[~near], ref[~near], rtol=0, atol=1e-6)
+
+
+def test_window_log_model_golden(golden):
+    g = golden("batched_B3_n12")
+    m = WindowLogModel(window_size=5, avg_degree=2).fit(g["win_x"])
+    np.testing.assert_allclose(m.theta_, g["win_theta"], rtol=1e-9)
+    assert m.weights_.shape == g["win_weights"].shape
+    z = WindowLogModel(window_size=5, avg_degree=2)._initialize(g["win_x"])
+    np.testing.assert_allclose(z, g["win_z"], rtol=1e-10, atol=1e-12)
+    diff = np.abs(m.weights_ - g["win_weights"])
+    assert (diff > 1e-6).mean() < 0.02      # only entries sitting at the edge_tol threshold may flip
+
+
+@pytest.mark.parametrize("window_size, avg_degree", list(product([5, 10], [2, 5])))
+def test_windowlogmodel_fit_reference_smoke(window_size, avg_degree):
+    """tests/test_models.py:26-28 of the reference, same data and parameters."""
+    data = default_rng(240920).standard_normal((23, 7))
+    m = WindowLogModel(window_size=window_size, avg_degree=avg_degree, random_state=240920).fit(data)
+    n_win = -(-23 // window_size)
+    assert m.weights_.shape == (n_win, 21) and np.isfinite(m.weights_).all() and (m.weights_ >= 0).all()
+
+
+def test_batched_errors():
+    with pytest.raises(ValueError):
+        gsp_learn_graph_log_degrees(np.ones((2, 10)), 1, 1, edge_init=np.ones((2, 10)))
