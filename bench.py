@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--avg-degree", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-converge", action="store_true")
+    ap.add_argument("--converge-maxit", type=int, default=200000)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,6 +111,10 @@ def main():
         wall_s = comm.max_over_ranks(wall_s)
         gpu_ms = comm.max_over_ranks(gpu_ms)
 
+    edge_us = sess.time_edge_pass(200)                   # dominant kernel alone, HIP events on its stream
+    if comm is not None:
+        edge_us = comm.max_over_ranks(edge_us)
+
     gather_s = None
     if comm is not None and not args.no_gather:
         t0 = time.perf_counter()
@@ -116,11 +122,27 @@ def main():
         gather_s = comm.max_over_ranks(time.perf_counter() - t0)
         assert gathered.shape == (world, n * (n - 1) // 2)
 
+    # time-to-converge (the second half of BASELINE's metric): fresh start, reference stopping rule
+    converge = None
+    if not args.no_converge:
+        sess.init(1.0, 1.0, 0.5, None)
+        t0 = time.perf_counter()
+        n_it, conv, rel = sess.iterate(args.converge_maxit, 1e-5)
+        converge = {"tol": 1e-5, "iterations": n_it, "converged": conv, "seconds": time.perf_counter() - t0}
+
     if rank == 0:
         its_per_s = world * args.steps / wall_s
         bytes_it = algorithmic_bytes_per_iteration(n)
-        launch_us = gpu_ms * 1e3 / args.steps
-        achieved = bytes_it / (launch_us * 1e-6) / 1e9
+        iter_us = gpu_ms * 1e3 / args.steps
+        achieved = bytes_it / (edge_us * 1e-6) / 1e9
+        traffic = None
+        try:  # PMC FETCH_SIZE / WRITE_SIZE per launch, collected with rocprofv3 in separate passes
+            with open(os.path.join(ROOT, "profiles", "r01_rocprof_summary.json")) as f:
+                prof = json.load(f)
+            if n == 4096:
+                traffic = next(v["total_bytes"] for k, v in prof["traffic"].items() if k.startswith("k_edge"))
+        except Exception:
+            traffic = None
         out = {
             "metric": "primal-dual iterations/sec, LogModel n=4096 d=1024",
             "value": its_per_s,
@@ -137,11 +159,15 @@ def main():
             "config": {"workload": f"LogModel fixed-iteration loop n={n} d={d} avg_degree={args.avg_degree} "
                                    f"(BASELINE configs[1]); one independent problem per GPU",
                        "edges": n * (n - 1) // 2, "theta": theta, "setup_s_distances_theta": setup_s,
-                       "gather_s": gather_s},
+                       "gather_s": gather_s, "gpu_us_per_iteration": iter_us,
+                       "iteration_level_frac_of_hbm_peak": bytes_it / (iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                       "time_to_converge": converge},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_edge<false> (+ k_node, per iteration)",
-                         "algorithmic_bytes_per_launch": bytes_it, "avg_launch_us": launch_us},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_edge<false> (edge pass: prox update of all edges + degree sums)",
+                         "algorithmic_bytes_per_launch": bytes_it, "avg_launch_us": edge_us,
+                         "traffic_source": "profiles/r01_rocprof_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                           "FETCH x2 per MI355X_MICROARCH.md)" if traffic else None},
         }
         if not args.no_cpu_baseline:
             z = sess.get_distances() * theta

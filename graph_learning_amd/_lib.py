@@ -58,6 +58,7 @@ SIGNATURES = {
     "gl_logdeg_get_weights_square": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p]),
     "gl_logdeg_get_dual": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gl_logdeg_total_iterations": (C.c_int64, [C.c_void_p]),
+    "gl_logdeg_time_edge_pass": (C.c_int, [C.c_void_p, C.c_int, _c_double_p]),
     "gl_logdeg_batch_gram": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "gl_log_degrees_fit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p,
                                      C.c_int64, C.c_double, C.c_double, C.c_double, C.c_void_p, _c_int64_p,
@@ -275,6 +276,12 @@ class LogDegreeSession:
         out = np.empty(self.n)
         self.ctx.check(self._lib.gl_logdeg_get_dual(self._h, ptr(out)), "get_dual")
         return out
+
+    def time_edge_pass(self, reps=200) -> float:
+        """Average edge-pass duration in microseconds (HIP events; state unchanged)."""
+        us = C.c_double(0.0)
+        self.ctx.check(self._lib.gl_logdeg_time_edge_pass(self._h, int(reps), C.byref(us)), "time_edge_pass")
+        return us.value
 
     @property
     def total_iterations(self) -> int:

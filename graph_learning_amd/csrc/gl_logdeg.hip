@@ -1055,3 +1055,25 @@ GL_API int gl_logdeg_batch_gram(gl_logdeg **sessions, int B, double *out) {
     return GL_OK;
 }
 
+// Measurement facility for bench.py: average duration of the edge pass alone, timed with HIP
+// events on the solver's stream over `reps` back-to-back launches.  The iteration counter is not
+// advanced, so every launch recomputes the same pass (reads w[it&1], writes w[(it+1)&1]) and the
+// session state is unchanged.
+GL_API int gl_logdeg_time_edge_pass(gl_logdeg *s, int reps, double *avg_us_out) {
+    GL_TRY(check(s));
+    gl_ctx *ctx = s->ctx;
+    if (!s->inited) return gl_set_error(ctx, GL_E_STATE, "time_edge_pass needs init first");
+    if (reps < 1 || !avg_us_out) return gl_set_error(ctx, GL_E_INVALID, "bad argument");
+    GL_HIP(ctx, hipSetDevice(ctx->device));
+    const LogdegDev &D = s->dev;
+    for (int i = 0; i < 5; ++i) k_edge<false><<<dim3((unsigned)D.G), dim3(64), 0, ctx->stream>>>(D);
+    GL_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < reps; ++i) k_edge<false><<<dim3((unsigned)D.G), dim3(64), 0, ctx->stream>>>(D);
+    GL_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    GL_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    GL_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *avg_us_out = (double)ms * 1e3 / reps;
+    return GL_OK;
+}
+

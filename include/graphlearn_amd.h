@@ -107,6 +107,10 @@ int gl_logdeg_get_weights_square(gl_logdeg *s, double edge_tol, double *w_out);
 int gl_logdeg_get_dual(gl_logdeg *s, double *d_out);
 int64_t gl_logdeg_total_iterations(gl_logdeg *s);
 
+/* Measurement facility (bench.py): average duration in microseconds of the edge pass alone,
+ * HIP events on the solver's stream over `reps` back-to-back launches; session state unchanged. */
+int gl_logdeg_time_edge_pass(gl_logdeg *s, int reps, double *avg_us_out);
+
 /* Batched (2-D) path of gsp_learn_graph_log_degrees (smooth_learning.py:128-129,158-159):
  * with (B, E) input the reference's norms are spectral norms of (E x B) / (n x B) matrices and
  * all B graphs stop together.  This returns the four B x B Gram matrices of the last iteration
