@@ -135,6 +135,84 @@ __global__ __launch_bounds__(64) void k_edge(LogdegDev P) {
     double colp[2] = {0, 0}, colw[2] = {0, 0};
     double nqy = 0, nw = 0;
 
+    // One step (<= 8 row pairs of one tile).  FULL = the tile has no masked entries: the
+    // common case gets its own branch-free arithmetic; diagonal / ragged tiles take the
+    // masked variant.  Everything per-step (base pointers, node rows) is hoisted so that a
+    // slot costs its arithmetic plus immediate-offset loads and stores.
+    auto step = [&](const EdgeStep &cs, const EdgeStep &ns, auto full_tag, double (&rowp)[ROWS_PER_LANE],
+                    double (&roww)[ROWS_PER_LANE]) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int64_t sbase = cs.t * GL_TILE_ELEMS + (int64_t)cs.a * (2 * TB) + lofs;
+        const int64_t nbase = ns.t * GL_TILE_ELEMS + (int64_t)ns.a * (2 * TB) + lofs;
+        double *__restrict__ wq = wdst + sbase;
+        const double *__restrict__ wp = wsrc + nbase;
+        const double *__restrict__ zp = P.z + nbase;
+        const int irow0 = I * TB + 2 * cs.a + half;  // node of slot 0 (this lane's half)
+        const double *__restrict__ dr = P.dvar + irow0;
+        const double *__restrict__ pr_ = P.pbar + irow0;
+        const int jcol0 = J * TB + c0;
+#pragma unroll
+        for (int k = 0; k < ROWS_PER_LANE; ++k) {
+            rowp[k] = 0.0;
+            roww[k] = 0.0;
+            if (k < cs.cnt) {
+                double di = 0, pi = 0;
+                if (!INIT && !(ABL & 1)) {
+                    di = dr[2 * k];
+                    pi = pr_[2 * k];
+                }
+                double wn[2], pp[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const double w = e ? wv[k].y : wv[k].x;
+                    bool valid = true;
+                    if (!FULL) {
+                        const int i = irow0 + 2 * k, j = jcol0 + e;
+                        valid = i < j && j < P.n;
+                    }
+                    if (INIT) {
+                        pp[e] = 0.0;
+                        wn[e] = (FULL || valid) ? w : 0.0;
+                    } else {
+                        const double z = e ? zv[k].y : zv[k].x;
+                        const double y = c * w - g * (di + dj[e]);    // :147
+                        const double tt = y - g2 * z;                 // :150
+                        const double pr = tt > 0 ? tt : 0.0;
+                        const double q = c * pr - g * (pi + pj[e]);   // :153
+                        const double wnew = (w - y) + q;              // :163
+                        const double dq = q - y;                      // == -y + q (:158)
+                        if (FULL) {
+                            pp[e] = pr;
+                            wn[e] = wnew;
+                            if (!(ABL & 16)) {
+                                nqy += dq * dq;
+                                nw += w * w;
+                            }
+                        } else {  // entries outside i < j < n stay exactly 0 and count for nothing
+                            pp[e] = valid ? pr : 0.0;
+                            wn[e] = valid ? wnew : 0.0;
+                            if (!(ABL & 16)) {
+                                nqy += valid ? dq * dq : 0.0;
+                                nw += valid ? w * w : 0.0;
+                            }
+                        }
+                    }
+                    colp[e] += pp[e];
+                    colw[e] += wn[e];
+                }
+                rowp[k] = pp[0] + pp[1];
+                roww[k] = wn[0] + wn[1];
+                if (!INIT && !(ABL & 8)) *reinterpret_cast<double2 *>(wq + k * (2 * TB)) = double2{wn[0], wn[1]};
+                if (ABL & 8) nqy += wn[0] + wn[1];
+            }
+            // prefetch: this slot's registers are free again
+            if (k < ns.cnt) {
+                wv[k] = *reinterpret_cast<const double2 *>(wp + k * (2 * TB));
+                if (!INIT && !(ABL & 32)) zv[k] = *reinterpret_cast<const double2 *>(zp + k * (2 * TB));
+            }
+        }
+    };
+
     while (cur.cnt > 0) {
         if (cur.t != tile_loaded) {
             tile_loaded = cur.t;
@@ -149,81 +227,13 @@ __global__ __launch_bounds__(64) void k_edge(LogdegDev P) {
             }
         }
         const EdgeStep nxt = edge_step_at(p + cur.cnt, pend);
-        const int64_t tbase = cur.t * GL_TILE_ELEMS + lofs;
-        const int64_t nbase = nxt.t * GL_TILE_ELEMS + lofs;
         const int irow0 = I * TB + 2 * cur.a + half;  // node of slot 0
-        const int jcol0 = J * TB + c0;
 
         double rowp[ROWS_PER_LANE], roww[ROWS_PER_LANE];
-#pragma unroll
-        for (int k = 0; k < ROWS_PER_LANE; ++k) {
-            rowp[k] = 0.0;
-            roww[k] = 0.0;
-            if (k < cur.cnt) {
-                const int i = irow0 + 2 * k;
-                double di = 0, pi = 0;
-                if (!INIT && !(ABL & 1)) {
-                    di = P.dvar[i];
-                    pi = P.pbar[i];
-                }
-                double wn[2], pp[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const double w = e ? wv[k].y : wv[k].x;
-                    if (INIT) {
-                        pp[e] = 0.0;
-                        wn[e] = w;
-                    } else {
-                        const double z = e ? zv[k].y : zv[k].x;
-                        // :147  y = (1 - 2 gamma beta) w - gamma (S^T d)
-                        const double y = c * w - g * (di + dj[e]);
-                        // :150  p = max(0, y - 2 gamma z)
-                        const double tt = y - g2 * z;
-                        const double pr = tt > 0 ? tt : 0.0;
-                        // :153  q = (1 - 2 gamma beta) p - gamma (S^T pbar)
-                        const double q = c * pr - g * (pi + pj[e]);
-                        // :163  w <- w - y + q
-                        wn[e] = (w - y) + q;
-                        pp[e] = pr;
-                        if (!(ABL & 16)) {
-                            const double dq = q - y;  // == -y + q (:158)
-                            if (full) {
-                                nqy += dq * dq;
-                                nw += w * w;
-                            } else {
-                                const int j = jcol0 + e;
-                                const bool valid = i < j && j < P.n;
-                                nqy += valid ? dq * dq : 0.0;
-                                nw += valid ? w * w : 0.0;
-                            }
-                        }
-                    }
-                    if (!full) {  // diagonal / ragged tiles: entries outside i < j < n stay exactly 0
-                        const int j = jcol0 + e;
-                        const bool valid = i < j && j < P.n;
-                        pp[e] = valid ? pp[e] : 0.0;
-                        wn[e] = valid ? wn[e] : 0.0;
-                    }
-                    colp[e] += pp[e];
-                    colw[e] += wn[e];
-                }
-                rowp[k] = pp[0] + pp[1];
-                roww[k] = wn[0] + wn[1];
-                if (!INIT && !(ABL & 8)) {
-                    double2 o;
-                    o.x = wn[0];
-                    o.y = wn[1];
-                    *reinterpret_cast<double2 *>(wdst + tbase + (int64_t)(cur.a + k) * (2 * TB)) = o;
-                }
-                if (ABL & 8) nqy += wn[0] + wn[1];
-            }
-            // prefetch: this slot's registers are free again
-            if (k < nxt.cnt) {
-                const int64_t off = nbase + (int64_t)(nxt.a + k) * (2 * TB);
-                wv[k] = *reinterpret_cast<const double2 *>(wsrc + off);
-                if (!INIT && !(ABL & 32)) zv[k] = *reinterpret_cast<const double2 *>(P.z + off);
-            }
-        }
+        if (full)
+            step(cur, nxt, std::true_type{}, rowp, roww);
+        else
+            step(cur, nxt, std::false_type{}, rowp, roww);
 
         // ---- row degree partials of this step: complete inside the wave
         if (ABL & 2) {
