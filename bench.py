@@ -159,7 +159,7 @@ def main():
             "config": {"workload": f"LogModel fixed-iteration loop n={n} d={d} avg_degree={args.avg_degree} "
                                    f"(BASELINE configs[1]); one independent problem per GPU",
                        "edges": n * (n - 1) // 2, "theta": theta, "setup_s_distances_theta": setup_s,
-                       "gather_s": gather_s, "gpu_us_per_iteration": iter_us,
+                       "gather_s": gather_s, "comm": getattr(comm, "kind", None), "gpu_us_per_iteration": iter_us,
                        "iteration_level_frac_of_hbm_peak": bytes_it / (iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                        "time_to_converge": converge},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -134,9 +134,12 @@ class GlooComm:
         self._own = not dist.is_initialized()
         if self._own:
             if init_method is None:
-                addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
-                port = os.environ.get("MASTER_PORT", "29500")
-                init_method = f"tcp://{addr}:{port}"
+                if "TORCHELASTIC_RUN_ID" in os.environ:  # under torch.distributed.run: use the agent's store
+                    init_method = "env://"
+                else:
+                    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+                    port = os.environ.get("MASTER_PORT", "29500")
+                    init_method = f"tcp://{addr}:{port}"
             dist.init_process_group("gloo", init_method=init_method, rank=self.rank, world_size=self.world)
 
     def barrier(self):
@@ -165,12 +168,28 @@ class GlooComm:
             self._dist.destroy_process_group()
 
 
-def make_comm(rank: int, world: int, local_rank: int = 0, ctx: _lib.Context | None = None, backend: str = "rccl"):
+def make_comm(rank: int, world: int, local_rank: int = 0, ctx: _lib.Context | None = None, backend: str | None = None):
+    """RCCL by default; ``GRAPHLEARN_AMD_COMM=gloo`` (or backend="gloo") selects the host-staged
+    torch.distributed/gloo communicator.  If RCCL cannot be brought up at all (library missing,
+    communicator init error on every rank) the gloo communicator is used instead and says so
+    (``comm.kind``) -- a slower gather, never a silent change of the solver."""
     if world <= 1:
         return SingleComm()
+    backend = backend or os.environ.get("GRAPHLEARN_AMD_COMM", "rccl")
     if backend == "gloo":
-        return GlooComm(rank, world)
-    return RcclComm(ctx or _lib.Context(local_rank), rank, world)
+        c = GlooComm(rank, world)
+        c.kind = "gloo"
+        return c
+    try:
+        c = RcclComm(ctx or _lib.Context(local_rank), rank, world)
+        c.kind = "rccl"
+        return c
+    except (_lib.GraphLearnError, TimeoutError, OSError) as exc:
+        print(f"[graph_learning_amd] rank {rank}: RCCL communicator unavailable ({exc}); falling back to gloo",
+              flush=True)
+        c = GlooComm(rank, world)
+        c.kind = "gloo-fallback"
+        return c
 
 
 def shard(n_items: int, rank: int, world: int) -> list[int]:

@@ -22,7 +22,8 @@
 //         inv(I + rho M) = I - rho (Theta_mm + rho I)^-1,
 //     and (Theta_mm + rho I)^-1 = G_mm - g g'/G_uu with G = (Theta + rho I)^-1 kept up to
 //     date by a rank-2 Woodbury correction per node (row/column u of Theta changes) and
-//     re-computed from scratch once per cycle -- O(n^2) per ADMM step and per node.
+//     re-computed from scratch once per cycle -- the explicit inverse of a node is then an
+//     O(n^2) elementwise kernel instead of an O(n^3) factorisation.
 // Both produce the reference's iterates up to rounding; the stopping rules are the
 // reference's.
 #include <vector>
@@ -69,7 +70,8 @@ __device__ double block_max(double v, double *sh) {
 struct LgDev {
     double *K, *Th, *C, *G, *W, *ThPrev;  // n x n
     const double *mask;                   // n x n or null (full)
-    double *p, *x, *z, *uu, *v, *y;       // QP vectors (n)
+    double *p, *x, *z, *uu, *v, *y;       // QP vectors (n); v and y are the ping-pong right-hand sides
+    double *part;                         // ADMM norm partials [2][nblk][6]
     double *act;                          // 1.0 where the entry takes part in the QP of node u
     double *beta, *t, *a, *h, *gcol;      // post-QP vectors (n)
     double *scal;                         // scalars: [0] done, [1] qp iterations, [2..] scratch
@@ -157,58 +159,184 @@ __global__ void k_gj_eliminate(double *A, int64_t n, int64_t k, const double *__
     A[i * n + j] = cur - pivcol[i] * pivrow[j];
 }
 
-// One ADMM step on the vectors (single workgroup), given y = A v:
-//   MODE 0: x' = y                                  (A = explicit inverse)
-//   MODE 1: x' = v - rho (y - g (g.v) / G_uu)        (A = G, fast path)
-// then z' = max(x' + u, 0), u += x' - z', the two relative changes and the stopping rule
-// (lgmrf.py:57-69).  Writes the next right-hand side v = (z' - u) + rho p.
-template <int MODE>
-__global__ __launch_bounds__(VT) void k_lg_admm(LgDev D, int64_t u, int it) {
-    __shared__ double sh[VT / 64];
+// fast path: the explicit inverse for node u from G = (Theta + rho I)^-1,
+//   inv(I + rho M) = I - rho (G_mm - g g'/G_uu)      (g = G[:,u]; identity on row/column u)
+__global__ void k_lg_build_winv(LgDev D, int64_t u) {
+    const int64_t i = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = D.n;
+    if (j >= n) return;
+    double w = (i == j) ? 1.0 : 0.0;
+    if (i != u && j != u) w -= D.rho * (D.G[i * n + j] - (D.G[i * n + u] * D.G[j * n + u]) / D.G[u * n + u]);
+    D.W[i * n + j] = w;
+}
+
+// One ADMM step (lgmrf.py:57-69) in ONE launch: workgroup = 8 rows of the explicit inverse W
+// (2 per wave):  x' = W v,  z' = max(x' + u, 0),  u += x' - z',  next right-hand side
+// v' = (z' - u) + rho p -- all row-local, so they are fused behind the row's dot product.
+// The two relative changes need grid-wide norms: every workgroup leaves 6 partials and the
+// stopping rule of step it-1 is evaluated (redundantly, in fixed order) during step it -- deferred
+// by one launch, which costs nothing because a step that finds the rule satisfied exits before
+// touching z.  Loads that do not depend on each other are issued up front (latency-bound kernel).
+constexpr int ADMM_ROWS = 8;
+
+__global__ __launch_bounds__(256) void k_lg_admm(LgDev D, int it) {
+    __shared__ double sp[4][6];
+    __shared__ int s_stop;
     if (D.scal[0] != 0.0) return;
     const int64_t n = D.n;
-    double s = 0;
-    if (MODE == 1) {
-        double part = 0;
-        for (int64_t i = threadIdx.x; i < n; i += VT) part += D.gcol[i] * D.v[i];  // v_u = 0
-        s = block_sum(part, sh) / D.gcol[u];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = gridDim.x;
+    const double *__restrict__ vin = (it & 1) ? D.y : D.v;
+    double *__restrict__ vout = (it & 1) ? D.v : D.y;
+    const bool chk = it >= 2;  // rule of step it-1 (never for step 0: `it > 0`)
+
+    // (1) loads for the deferred stopping rule (wave 0)
+    double a0 = 0, a1 = 0, a3 = 0, a4 = 0, m2 = 0, m5 = 0;
+    if (chk && wave == 0) {
+        const double *pp = D.part + (size_t)((it - 1) & 1) * nblk * 6;
+        for (int b = lane; b < nblk; b += 64) {
+            a0 += pp[6 * b + 0];
+            a1 += pp[6 * b + 1];
+            m2 = fmax(m2, pp[6 * b + 2]);
+            a3 += pp[6 * b + 3];
+            a4 += pp[6 * b + 4];
+            m5 = fmax(m5, pp[6 * b + 5]);
+        }
     }
+    // (2) my two rows: state of the row (lane r of the wave keeps row r's scalars) and the dot products
+    const int64_t i0 = (int64_t)blockIdx.x * ADMM_ROWS + wave * 2;
+    double xo = 0, zo = 0, uo = 0, pi = 0, on = 0;
+    if (lane < 2 && i0 + lane < n) {
+        const int64_t i = i0 + lane;
+        xo = D.x[i];
+        zo = D.z[i];
+        uo = D.uu[i];
+        pi = D.p[i];
+        on = D.act[i];
+    }
+    double acc0 = 0, acc1 = 0;
+    {
+        const double *r0 = D.W + i0 * n, *r1 = r0 + n;
+        const bool has0 = i0 < n, has1 = i0 + 1 < n;
+        if ((n & 1) == 0) {  // 16-byte loads
+            const double2 *v2 = reinterpret_cast<const double2 *>(vin);
+            const double2 *q0 = reinterpret_cast<const double2 *>(r0), *q1 = reinterpret_cast<const double2 *>(r1);
+#pragma unroll 4
+            for (int64_t j = lane; j < n / 2; j += 64) {
+                const double2 vv = v2[j];
+                if (has0) {
+                    const double2 a = q0[j];
+                    acc0 += a.x * vv.x + a.y * vv.y;
+                }
+                if (has1) {
+                    const double2 a = q1[j];
+                    acc1 += a.x * vv.x + a.y * vv.y;
+                }
+            }
+        } else {
+            for (int64_t j = lane; j < n; j += 64) {
+                const double vv = vin[j];
+                if (has0) acc0 += r0[j] * vv;
+                if (has1) acc1 += r1[j] * vv;
+            }
+        }
+    }
+    acc0 = wsum(acc0);
+    acc1 = wsum(acc1);
+
+    if (tid == 0) s_stop = 0;
+    __syncthreads();
+    if (chk && wave == 0) {
+        a0 = wsum(a0);
+        a1 = wsum(a1);
+        a3 = wsum(a3);
+        a4 = wsum(a4);
+        m2 = wmax(m2);
+        m5 = wmax(m5);
+        // relative_error(prev, new): plain norm when prev is allclose to 0 (atol 1e-8)
+        const double rx = (m2 <= 1e-8) ? sqrt(a0) : sqrt(a0) / sqrt(a1);
+        const double rz = (m5 <= 1e-8) ? sqrt(a3) : sqrt(a3) / sqrt(a4);
+        if (lane == 0 && rx < D.qp_tol && rz < D.qp_tol) {
+            s_stop = 1;
+            if (blockIdx.x == 0) {
+                D.scal[1] = (double)it;  // steps run
+                D.scal[0] = 1.0;
+            }
+        }
+    }
+    if (chk) __syncthreads();
+    if (s_stop) return;
+
     double dx2 = 0, x2 = 0, xm = 0, dz2 = 0, z2 = 0, zm = 0;
-    for (int64_t i = threadIdx.x; i < n; i += VT) {
-        const bool on = D.act[i] != 0.0;
-        const double xo = D.x[i], zo = D.z[i], uo = D.uu[i];
-        double xn = 0.0;
-        if (on) xn = (MODE == 0) ? D.y[i] : D.v[i] - D.rho * (D.y[i] - D.gcol[i] * s);
+    if (lane < 2 && i0 + lane < n) {
+        const int64_t i = i0 + lane;
+        const bool active = on != 0.0;
+        const double xn = active ? (lane == 0 ? acc0 : acc1) : 0.0;
         double zn = xn + uo;
         zn = zn < 0 ? 0.0 : zn;
         const double un = uo + (xn - zn);
-        if (on) {
-            dx2 += (xn - xo) * (xn - xo);
-            x2 += xo * xo;
-            xm = fmax(xm, fabs(xo));
-            dz2 += (zn - zo) * (zn - zo);
-            z2 += zo * zo;
-            zm = fmax(zm, fabs(zo));
+        if (active) {
+            dx2 = (xn - xo) * (xn - xo);
+            x2 = xo * xo;
+            xm = fabs(xo);
+            dz2 = (zn - zo) * (zn - zo);
+            z2 = zo * zo;
+            zm = fabs(zo);
         }
         D.x[i] = xn;
-        D.z[i] = on ? zn : 0.0;
-        D.uu[i] = on ? un : 0.0;
-        D.v[i] = on ? (zn - un) + D.rho * D.p[i] : 0.0;
+        D.z[i] = active ? zn : 0.0;
+        D.uu[i] = active ? un : 0.0;
+        vout[i] = active ? (zn - un) + D.rho * pi : 0.0;
     }
-    dx2 = block_sum(dx2, sh);
-    x2 = block_sum(x2, sh);
-    xm = block_max(xm, sh);
-    dz2 = block_sum(dz2, sh);
-    z2 = block_sum(z2, sh);
-    zm = block_max(zm, sh);
-    if (threadIdx.x == 0) {
-        // relative_error(prev, new): plain norm when prev is allclose to 0 (atol 1e-8)
-        const double rx = (xm <= 1e-8) ? sqrt(dx2) : sqrt(dx2) / sqrt(x2);
-        const double rz = (zm <= 1e-8) ? sqrt(dz2) : sqrt(dz2) / sqrt(z2);
-        D.scal[1] = (double)(it + 1);
-        if (it > 0 && rx < D.qp_tol && rz < D.qp_tol) D.scal[0] = 1.0;
+    // lanes 0 and 1 of each wave hold partials: combine in fixed order (lane 0 + lane 1, then waves)
+    dx2 += __shfl_xor(dx2, 1, 64);
+    x2 += __shfl_xor(x2, 1, 64);
+    xm = fmax(xm, __shfl_xor(xm, 1, 64));
+    dz2 += __shfl_xor(dz2, 1, 64);
+    z2 += __shfl_xor(z2, 1, 64);
+    zm = fmax(zm, __shfl_xor(zm, 1, 64));
+    if (lane == 0) {
+        sp[wave][0] = dx2;
+        sp[wave][1] = x2;
+        sp[wave][2] = xm;
+        sp[wave][3] = dz2;
+        sp[wave][4] = z2;
+        sp[wave][5] = zm;
     }
+    __syncthreads();
+    if (tid < 6) {
+        double v;
+        if (tid == 2 || tid == 5)
+            v = fmax(fmax(sp[0][tid], sp[1][tid]), fmax(sp[2][tid], sp[3][tid]));
+        else
+            v = ((sp[0][tid] + sp[1][tid]) + sp[2][tid]) + sp[3][tid];
+        D.part[((size_t)(it & 1) * nblk + blockIdx.x) * 6 + tid] = v;
+    }
+    if (blockIdx.x == 0 && tid == 0) D.scal[1] = (double)(it + 1);
 }
+
+// The QP's ADMM loop: launches in chunks and polls the device-side stop flag in between, so a
+// QP that stops after ~30 steps does not pay for 100 launches.
+int run_admm(gl_ctx *ctx, const LgDev &D, int max_iter) {
+    const unsigned nblk = (unsigned)((D.n + ADMM_ROWS - 1) / ADMM_ROWS);
+    double *flag = (double *)ctx->pinned + 32;
+    int it = 0;
+    int chunk = 24;
+    while (it < max_iter) {
+        const int end = std::min(max_iter, it + chunk);
+        for (; it < end; ++it) k_lg_admm<<<nblk, 256, 0, ctx->stream>>>(D, it);
+        GL_HIP(ctx, hipGetLastError());
+        if (it >= max_iter) break;
+        GL_HIP(ctx, hipMemcpyAsync(flag, D.scal, 8, hipMemcpyDeviceToHost, ctx->stream));
+        GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (*flag != 0.0) break;
+        chunk = 16;
+    }
+    return GL_OK;
+}
+
+// after the loop: the result z is in D.z; the next right-hand side buffers are scratch again.
 
 // beta = -z ; prepares the M beta product: (M beta)_i = (C beta)_i - c_i (c.beta)/c_uu
 __global__ __launch_bounds__(VT) void k_lg_beta(LgDev D, int64_t u) {
@@ -423,8 +551,9 @@ GL_API int gl_nonneg_qp_solve(gl_ctx *ctx, const double *mat, const double *vec,
     if (!ctx) return GL_E_INVALID;
     if (!mat || !vec || !z_out || m < 1 || max_iter < 0) return gl_set_error(ctx, GL_E_INVALID, "bad argument");
     GL_HIP(ctx, hipSetDevice(ctx->device));
-    Buf W, vecs, scal;
+    Buf W, vecs, scal, part;
     GL_HIP(ctx, hipMalloc(&W.p, (size_t)m * m * 8));
+    GL_HIP(ctx, hipMalloc(&part.p, (size_t)2 * ((m + ADMM_ROWS - 1) / ADMM_ROWS) * 6 * 8));
     GL_HIP(ctx, hipMalloc(&vecs.p, (size_t)16 * m * 8));
     GL_HIP(ctx, hipMalloc(&scal.p, 16 * 8));
     double *V = (double *)vecs.p;
@@ -441,6 +570,7 @@ GL_API int gl_nonneg_qp_solve(gl_ctx *ctx, const double *mat, const double *vec,
     D.gcol = V + 7 * m;
     double *pivrow = V + 8 * m;
     D.scal = (double *)scal.p;
+    D.part = (double *)part.p;
     D.rho = step;
     D.qp_tol = tol;
     // W = I + step * mat ; p = vec ; v0 = step * vec ; everything active
@@ -456,12 +586,7 @@ GL_API int gl_nonneg_qp_solve(gl_ctx *ctx, const double *mat, const double *vec,
     GL_HIP(ctx, hipMemcpyAsync(V, hv.data(), hv.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     GL_HIP(ctx, hipMemsetAsync(D.scal, 0, 16 * 8, ctx->stream));
     GL_TRY(invert_spd_inplace(ctx, D.W, m, pivrow));
-    const unsigned mvb = (unsigned)((m + 3) / 4);
-    for (int it = 0; it < max_iter; ++it) {
-        k_matvec<<<mvb, 256, 0, ctx->stream>>>(D.W, D.v, D.y, m, D.scal, 1);
-        k_lg_admm<0><<<1, VT, 0, ctx->stream>>>(D, /*u=*/-1, it);
-    }
-    GL_HIP(ctx, hipGetLastError());
+    GL_TRY(run_admm(ctx, D, max_iter));
     double sc[2];
     GL_HIP(ctx, hipMemcpyAsync(z_out, D.z, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
     GL_HIP(ctx, hipMemcpyAsync(sc, D.scal, 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -495,10 +620,8 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
     GL_HIP(ctx, hipMalloc(&bTh.p, nn));
     GL_HIP(ctx, hipMalloc(&bC.p, nn));
     GL_HIP(ctx, hipMalloc(&bPrev.p, nn));
-    if (fast)
-        GL_HIP(ctx, hipMalloc(&bG.p, nn));
-    else
-        GL_HIP(ctx, hipMalloc(&bW.p, nn));
+    if (fast) GL_HIP(ctx, hipMalloc(&bG.p, nn));
+    GL_HIP(ctx, hipMalloc(&bW.p, nn));
     if (adj_mask && !full_mask) {
         GL_HIP(ctx, hipMalloc(&bMask.p, nn));
         GL_HIP(ctx, hipMemcpyAsync(bMask.p, adj_mask, nn, hipMemcpyHostToDevice, ctx->stream));
@@ -506,6 +629,8 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
     GL_HIP(ctx, hipMalloc(&bVec.p, (size_t)16 * n * 8));
     GL_HIP(ctx, hipMalloc(&bScal.p, 16 * 8));
     GL_HIP(ctx, hipMalloc(&bPart.p, 3 * 256 * 8));
+    Buf bAdmm;
+    GL_HIP(ctx, hipMalloc(&bAdmm.p, (size_t)2 * ((n + ADMM_ROWS - 1) / ADMM_ROWS) * 6 * 8));
     GL_HIP(ctx, hipMemsetAsync(bVec.p, 0, (size_t)16 * n * 8, ctx->stream));
     GL_HIP(ctx, hipMemsetAsync(bScal.p, 0, 16 * 8, ctx->stream));
 
@@ -533,6 +658,7 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
     D.gcol = V + 11 * n;
     double *pivrow = V + 12 * n;
     D.scal = (double *)bScal.p;
+    D.part = (double *)bAdmm.p;
     D.rho = qp_step;
     D.qp_tol = qp_tol;
 
@@ -555,19 +681,13 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
         }
         for (int64_t u = 0; u < n; ++u) {
             k_lg_qp_setup<<<1, VT, 0, ctx->stream>>>(D, u);
-            if (!fast) {
+            if (fast) {
+                k_lg_build_winv<<<g2, 256, 0, ctx->stream>>>(D, u);
+            } else {
                 k_lg_build_w<<<g2, 256, 0, ctx->stream>>>(D, u);
                 GL_TRY(invert_spd_inplace(ctx, D.W, n, pivrow));
             }
-            for (int it = 0; it < max_qp_iter; ++it) {
-                if (fast) {
-                    k_matvec<<<mvb, 256, 0, ctx->stream>>>(D.G, D.v, D.y, n, D.scal, 1);
-                    k_lg_admm<1><<<1, VT, 0, ctx->stream>>>(D, u, it);
-                } else {
-                    k_matvec<<<mvb, 256, 0, ctx->stream>>>(D.W, D.v, D.y, n, D.scal, 1);
-                    k_lg_admm<0><<<1, VT, 0, ctx->stream>>>(D, u, it);
-                }
-            }
+            GL_TRY(run_admm(ctx, D, max_qp_iter));
             k_lg_beta<<<1, VT, 0, ctx->stream>>>(D, u);
             k_matvec<<<mvb, 256, 0, ctx->stream>>>(D.C, D.beta, D.t, n, D.scal, 0);
             k_lg_snap_col<<<1, VT, 0, ctx->stream>>>(D, u);
@@ -579,7 +699,6 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
                 k_lg_update_g<<<g2, 256, 0, ctx->stream>>>(D);
             }
             GL_HIP(ctx, hipGetLastError());
-            if ((u & 15) == 15) GL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // bound the launch queue
         }
         cycles = cycle + 1;
         if (cycle > 4) {  // :221
