@@ -21,6 +21,7 @@ struct LogdegDev {
     double *bnorm;         // per-node-block norm partials                  [2][nb][4]
     double *dstat;         // {rel_primal, rel_dual, tol}
     long long *ctr;        // {done, final_iter, it_edge, it_node}
+    unsigned long long *dbg;  // development only (tools/edge_ablate.hip): per-wave cycle stamps, else null
     int64_t n, nb, n_pad, ntiles;
     int64_t npairs;        // ntiles * 32 row pairs = the flat work list
     int G;                 // persistent edge grid (single-wave workgroups)

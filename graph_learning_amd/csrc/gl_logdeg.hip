@@ -27,8 +27,15 @@
 namespace {
 
 constexpr int TB = GL_TB;            // 64 x 64 tiles
-constexpr int ROWS_PER_LANE = 8;     // lane: 2 columns x 8 row pairs per segment
+#ifndef GL_ROWS_PER_LANE
+#define GL_ROWS_PER_LANE 8
+#endif
+#ifndef GL_EDGE_WAVES_PER_SIMD
+#define GL_EDGE_WAVES_PER_SIMD 2
+#endif
+constexpr int ROWS_PER_LANE = GL_ROWS_PER_LANE;  // lane: 2 columns x this many row pairs per step
 constexpr int PAIRS_PER_TILE = TB / 2;
+constexpr int LAYOUT_ROWS = 8;        // layout kernels: lane = 2 columns x 8 rows (256 threads per tile)
 constexpr int ITER_BATCH = 64;       // iterations per captured graph / per convergence poll
 
 __device__ __forceinline__ double shfl_xor_d(double v, int mask) { return __shfl_xor(v, mask, 64); }
@@ -60,6 +67,43 @@ __device__ __forceinline__ double halfwave_rows8(const double (&v)[8], int lane)
     c += shfl_xor_d(c, 1);
     return c;
 }
+
+// Same for 4 rows per half-wave: 2+1 halving exchanges, then 3 full ones.
+// On return every lane holds the complete sum of row k = (lane >> 3) & 3.
+__device__ __forceinline__ double halfwave_rows4(const double (&v)[4], int lane) {
+    const bool b4 = lane & 16, b3 = lane & 8;
+    double a[2], c;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        double keep = b4 ? v[m + 2] : v[m];
+        double send = b4 ? v[m] : v[m + 2];
+        a[m] = keep + shfl_xor_d(send, 16);
+    }
+    {
+        double keep = b3 ? a[1] : a[0];
+        double send = b3 ? a[0] : a[1];
+        c = keep + shfl_xor_d(send, 8);
+    }
+    c += shfl_xor_d(c, 4);
+    c += shfl_xor_d(c, 2);
+    c += shfl_xor_d(c, 1);
+    return c;
+}
+
+template <int R>
+struct RowReduce;
+template <>
+struct RowReduce<8> {
+    static __device__ __forceinline__ double run(const double (&v)[8], int lane) { return halfwave_rows8(v, lane); }
+    static __device__ __forceinline__ int row_of(int lane) { return (lane >> 2) & 7; }
+    static __device__ __forceinline__ bool writer(int lane) { return (lane & 3) == 0; }
+};
+template <>
+struct RowReduce<4> {
+    static __device__ __forceinline__ double run(const double (&v)[4], int lane) { return halfwave_rows4(v, lane); }
+    static __device__ __forceinline__ int row_of(int lane) { return (lane >> 3) & 3; }
+    static __device__ __forceinline__ bool writer(int lane) { return (lane & 7) == 0; }
+};
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -95,8 +139,13 @@ __device__ __forceinline__ EdgeStep edge_step_at(int64_t p, int64_t pend) {
     return s;
 }
 
+// dvar / pbar come in as separate noalias arguments: a slot's two row entries have wave-uniform
+// addresses and are fetched with SCALAR loads (s_load, counted by lgkmcnt).  Vector loads for
+// them would sit in the in-order vector-memory queue behind the prefetch just issued by the
+// previous slot, and waiting for them would cost a full memory round trip per slot.
 template <bool INIT, int ABL = 0>
-__global__ __launch_bounds__(64) void k_edge(LogdegDev P) {
+__global__ __launch_bounds__(64, GL_EDGE_WAVES_PER_SIMD) void k_edge(LogdegDev P, const double *__restrict__ dvar,
+                                                                     const double *__restrict__ pbar) {
     if (!INIT && P.ctr[0] != 0) return;  // converged earlier: leave everything as is
     const long long it = INIT ? 0 : P.ctr[2];
 
@@ -127,7 +176,7 @@ __global__ __launch_bounds__(64) void k_edge(LogdegDev P) {
         }
     }
 
-    int seg = 0;
+    int seg = 0, seg_steps = 0;
     int64_t tile_loaded = -1;
     int I = 0, J = 0;
     bool full = false;
@@ -147,9 +196,10 @@ __global__ __launch_bounds__(64) void k_edge(LogdegDev P) {
         double *__restrict__ wq = wdst + sbase;
         const double *__restrict__ wp = wsrc + nbase;
         const double *__restrict__ zp = P.z + nbase;
-        const int irow0 = I * TB + 2 * cs.a + half;  // node of slot 0 (this lane's half)
-        const double *__restrict__ dr = P.dvar + irow0;
-        const double *__restrict__ pr_ = P.pbar + irow0;
+        const int iu0 = __builtin_amdgcn_readfirstlane(I * TB + 2 * cs.a);  // wave-uniform: rows iu0 + 2k (+1)
+        const int irow0 = iu0 + half;                                        // node of slot 0 (this lane's half)
+        const double *__restrict__ dr = dvar + iu0;
+        const double *__restrict__ pr_ = pbar + iu0;
         const int jcol0 = J * TB + c0;
 #pragma unroll
         for (int k = 0; k < ROWS_PER_LANE; ++k) {
@@ -158,8 +208,10 @@ __global__ __launch_bounds__(64) void k_edge(LogdegDev P) {
             if (k < cs.cnt) {
                 double di = 0, pi = 0;
                 if (!INIT && !(ABL & 1)) {
-                    di = dr[2 * k];
-                    pi = pr_[2 * k];
+                    const double d0 = dr[2 * k], d1 = dr[2 * k + 1];
+                    const double q0 = pr_[2 * k], q1 = pr_[2 * k + 1];
+                    di = half ? d1 : d0;
+                    pi = half ? q1 : q0;
                 }
                 double wn[2], pp[2];
 #pragma unroll
@@ -175,11 +227,17 @@ __global__ __launch_bounds__(64) void k_edge(LogdegDev P) {
                         wn[e] = (FULL || valid) ? w : 0.0;
                     } else {
                         const double z = e ? zv[k].y : zv[k].x;
-                        const double y = c * w - g * (di + dj[e]);    // :147
+                        double y = c * w - g * (di + dj[e]);    // :147
                         const double tt = y - g2 * z;                 // :150
-                        const double pr = tt > 0 ? tt : 0.0;
-                        const double q = c * pr - g * (pi + pj[e]);   // :153
-                        const double wnew = (w - y) + q;              // :163
+                        double pr = tt > 0 ? tt : 0.0;
+                        double q = c * pr - g * (pi + pj[e]);   // :153
+                        double wnew = (w - y) + q;              // :163
+                        if (ABL & 128) {  // diagnostic: no arithmetic at all, same memory traffic
+                            wnew = w + z;
+                            pr = z;
+                            q = w;
+                            y = z;
+                        }
                         const double dq = q - y;                      // == -y + q (:158)
                         if (FULL) {
                             pp[e] = pr;
@@ -220,31 +278,38 @@ __global__ __launch_bounds__(64) void k_edge(LogdegDev P) {
             full = (I < J) && ((int64_t)J * TB + TB <= P.n);
             if (!INIT && !(ABL & 1)) {
                 const int64_t j0 = (int64_t)J * TB + c0;
-                dj[0] = P.dvar[j0];
-                dj[1] = P.dvar[j0 + 1];
-                pj[0] = P.pbar[j0];
-                pj[1] = P.pbar[j0 + 1];
+                dj[0] = dvar[j0];
+                dj[1] = dvar[j0 + 1];
+                pj[0] = pbar[j0];
+                pj[1] = pbar[j0 + 1];
             }
         }
         const EdgeStep nxt = edge_step_at(p + cur.cnt, pend);
         const int irow0 = I * TB + 2 * cur.a + half;  // node of slot 0
 
+        unsigned long long st0 = 0, st1 = 0, st2 = 0;
+        if (ABL & 64) {  // diagnostic build only: wait for this step's data, then stamp
+            st0 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0);
+            st1 = __builtin_amdgcn_s_memtime();
+        }
         double rowp[ROWS_PER_LANE], roww[ROWS_PER_LANE];
         if (full)
             step(cur, nxt, std::true_type{}, rowp, roww);
         else
             step(cur, nxt, std::false_type{}, rowp, roww);
+        if (ABL & 64) st2 = __builtin_amdgcn_s_memtime();
 
         // ---- row degree partials of this step: complete inside the wave
         if (ABL & 2) {
 #pragma unroll
             for (int k = 0; k < ROWS_PER_LANE; ++k) nw += rowp[k] + roww[k];
         } else {
-            const double rw = halfwave_rows8(roww, lane);
+            const double rw = RowReduce<ROWS_PER_LANE>::run(roww, lane);
             double rp_ = 0;
-            if (!INIT) rp_ = halfwave_rows8(rowp, lane);
-            const int k = (lane >> 2) & 7;
-            if ((lane & 3) == 0 && k < cur.cnt) {
+            if (!INIT) rp_ = RowReduce<ROWS_PER_LANE>::run(rowp, lane);
+            const int k = RowReduce<ROWS_PER_LANE>::row_of(lane);
+            if (RowReduce<ROWS_PER_LANE>::writer(lane) && k < cur.cnt) {
                 const int64_t idx = (int64_t)J * P.n_pad + irow0 + 2 * k;
                 if (!INIT) P.rowslab_p[idx] = rp_;
                 P.rowslab_w[idx] = rw;
@@ -271,6 +336,15 @@ __global__ __launch_bounds__(64) void k_edge(LogdegDev P) {
             colp[0] = colp[1] = colw[0] = colw[1] = 0.0;
             ++seg;
         }
+        if ((ABL & 64) && P.dbg && lane == 0 && seg_steps < 8) {
+            const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+            unsigned long long *o = P.dbg + ((size_t)b * 8 + seg_steps) * 4;
+            o[0] = st0;
+            o[1] = st1;
+            o[2] = st2;
+            o[3] = st3;
+        }
+        ++seg_steps;
         p += cur.cnt;
         cur = nxt;
     }
@@ -473,7 +547,7 @@ __global__ __launch_bounds__(256) void k_to_tiled(const double *__restrict__ src
     const int r0 = wave * 16 + (lane >> 5);
     const int64_t base = (int64_t)blockIdx.x * GL_TILE_ELEMS + (int64_t)r0 * TB + c0;
 #pragma unroll
-    for (int k = 0; k < ROWS_PER_LANE; ++k) {
+    for (int k = 0; k < LAYOUT_ROWS; ++k) {
         const int64_t i = (int64_t)I * TB + r0 + 2 * k;
         double2 o;
         double v[2];
@@ -502,7 +576,7 @@ __global__ __launch_bounds__(256) void k_to_condensed(const double *__restrict__
     const int r0 = wave * 16 + (lane >> 5);
     const int64_t base = (int64_t)blockIdx.x * GL_TILE_ELEMS + (int64_t)r0 * TB + c0;
 #pragma unroll
-    for (int k = 0; k < ROWS_PER_LANE; ++k) {
+    for (int k = 0; k < LAYOUT_ROWS; ++k) {
         const int64_t i = (int64_t)I * TB + r0 + 2 * k;
         const double2 v = *reinterpret_cast<const double2 *>(src + base + (int64_t)k * 2 * TB);
 #pragma unroll
@@ -660,7 +734,7 @@ void drop_graph(gl_logdeg *s) {
 
 void enqueue_iteration(gl_logdeg *s) {
     const LogdegDev &D = s->dev;
-    k_edge<false><<<dim3((unsigned)D.G), dim3(64), 0, s->ctx->stream>>>(D);
+    k_edge<false><<<dim3((unsigned)D.G), dim3(64), 0, s->ctx->stream>>>(D, D.dvar, D.pbar);
     k_node<false><<<dim3((unsigned)D.nb), dim3(NODE_WAVES * 64), 0, s->ctx->stream>>>(D);
 }
 
@@ -718,7 +792,7 @@ GL_API int gl_logdeg_create(gl_ctx *ctx, int64_t n_nodes, gl_logdeg **out) {
     D.ntiles = gl_num_tiles(n_nodes);
     D.npairs = D.ntiles * PAIRS_PER_TILE;
     // persistent edge grid: `wpc` single-wave workgroups per CU (all co-resident), >= 8 row pairs each
-    s->wpc = 8;
+    s->wpc = 4 * GL_EDGE_WAVES_PER_SIMD;
     if (const char *e = getenv("GRAPHLEARN_AMD_WPC")) s->wpc = std::max(1, std::min(16, atoi(e)));
     D.G = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)s->wpc * ctx->prop.multiProcessorCount, D.npairs / 8));
     const int64_t maxchunk = (D.npairs + D.G - 1) / D.G;
@@ -868,7 +942,7 @@ GL_API int gl_logdeg_init(gl_logdeg *s, double alpha, double beta, double step_s
     st[2] = 0.0;  // tol
     GL_HIP(ctx, hipMemcpyAsync(D.dstat, st, 3 * 8, hipMemcpyHostToDevice, ctx->stream));
     s->it = 0;
-    k_edge<true><<<dim3((unsigned)D.G), dim3(64), 0, ctx->stream>>>(D);
+    k_edge<true><<<dim3((unsigned)D.G), dim3(64), 0, ctx->stream>>>(D, D.dvar, D.pbar);
     GL_HIP(ctx, hipGetLastError());
     k_node<true><<<dim3((unsigned)D.nb), dim3(NODE_WAVES * 64), 0, ctx->stream>>>(D);
     GL_HIP(ctx, hipGetLastError());
@@ -1076,9 +1150,9 @@ GL_API int gl_logdeg_time_edge_pass(gl_logdeg *s, int reps, double *avg_us_out) 
     if (reps < 1 || !avg_us_out) return gl_set_error(ctx, GL_E_INVALID, "bad argument");
     GL_HIP(ctx, hipSetDevice(ctx->device));
     const LogdegDev &D = s->dev;
-    for (int i = 0; i < 5; ++i) k_edge<false><<<dim3((unsigned)D.G), dim3(64), 0, ctx->stream>>>(D);
+    for (int i = 0; i < 5; ++i) k_edge<false><<<dim3((unsigned)D.G), dim3(64), 0, ctx->stream>>>(D, D.dvar, D.pbar);
     GL_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    for (int i = 0; i < reps; ++i) k_edge<false><<<dim3((unsigned)D.G), dim3(64), 0, ctx->stream>>>(D);
+    for (int i = 0; i < reps; ++i) k_edge<false><<<dim3((unsigned)D.G), dim3(64), 0, ctx->stream>>>(D, D.dvar, D.pbar);
     GL_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     GL_HIP(ctx, hipEventSynchronize(ctx->ev1));
     float ms = 0.f;
