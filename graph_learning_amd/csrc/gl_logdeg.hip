@@ -177,7 +177,6 @@ __global__ __launch_bounds__(64, GL_EDGE_WAVES_PER_SIMD) void k_edge(LogdegDev P
     }
 
     int seg = 0, seg_steps = 0;
-    int64_t tile_loaded = -1;
     int I = 0, J = 0;
     bool full = false;
     double dj[2] = {0, 0}, pj[2] = {0, 0};
@@ -271,20 +270,32 @@ __global__ __launch_bounds__(64, GL_EDGE_WAVES_PER_SIMD) void k_edge(LogdegDev P
         }
     };
 
-    while (cur.cnt > 0) {
-        if (cur.t != tile_loaded) {
-            tile_loaded = cur.t;
-            gl_tile_decode(cur.t, P.nb, I, J);
-            full = (I < J) && ((int64_t)J * TB + TB <= P.n);
-            if (!INIT && !(ABL & 1)) {
-                const int64_t j0 = (int64_t)J * TB + c0;
-                dj[0] = dvar[j0];
-                dj[1] = dvar[j0 + 1];
-                pj[0] = pbar[j0];
-                pj[1] = pbar[j0 + 1];
-            }
+    // column entries (dvar / pbar of this lane's two columns) of the current tile; those of the
+    // next tile are requested one step ahead, BEFORE that step's ring refills, so that they are
+    // older in the in-order vector-memory queue than anything the next tile's first step waits for
+    double djn[2] = {0, 0}, pjn[2] = {0, 0};
+    int In = 0, Jn = 0;
+    auto fetch_tile = [&](int64_t t, int &Io, int &Jo, double (&dd)[2], double (&pp)[2]) {
+        gl_tile_decode(t, P.nb, Io, Jo);
+        Io = __builtin_amdgcn_readfirstlane(Io);
+        Jo = __builtin_amdgcn_readfirstlane(Jo);
+        if (!INIT && !(ABL & 1)) {
+            const int64_t j0 = (int64_t)Jo * TB + c0;
+            dd[0] = dvar[j0];
+            dd[1] = dvar[j0 + 1];
+            pp[0] = pbar[j0];
+            pp[1] = pbar[j0 + 1];
         }
+    };
+    if (cur.cnt > 0) {
+        fetch_tile(cur.t, I, J, dj, pj);
+        full = (I < J) && ((int64_t)J * TB + TB <= P.n);
+    }
+
+    while (cur.cnt > 0) {
         const EdgeStep nxt = edge_step_at(p + cur.cnt, pend);
+        const bool tile_change = nxt.cnt > 0 && nxt.t != cur.t;
+        if (tile_change) fetch_tile(nxt.t, In, Jn, djn, pjn);
         const int irow0 = I * TB + 2 * cur.a + half;  // node of slot 0
 
         unsigned long long st0 = 0, st1 = 0, st2 = 0;
@@ -347,6 +358,15 @@ __global__ __launch_bounds__(64, GL_EDGE_WAVES_PER_SIMD) void k_edge(LogdegDev P
         ++seg_steps;
         p += cur.cnt;
         cur = nxt;
+        if (tile_change) {
+            I = In;
+            J = Jn;
+            dj[0] = djn[0];
+            dj[1] = djn[1];
+            pj[0] = pjn[0];
+            pj[1] = pjn[1];
+            full = (I < J) && ((int64_t)J * TB + TB <= P.n);
+        }
     }
 
     if (!INIT) {

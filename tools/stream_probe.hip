@@ -53,6 +53,39 @@ __global__ __launch_bounds__(256) void k_chunk(const double2* __restrict__ w, co
     }
 }
 
+// wave-autonomous chunk kernel: each WAVE streams its own contiguous range (like k_edge), block size BS.
+// ORDER 0: 16 loads, then 8 stores per step.  ORDER 1: per slot store(prev) + 2 loads (rolling, like k_edge).
+template <int BS, int ORDER>
+__global__ __launch_bounds__(BS) void k_wave_chunk(const double2* __restrict__ w, const double2* __restrict__ z,
+                                                   double2* __restrict__ o, long n2, double c, double g) {
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * BS + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * BS) >> 6;
+    const long units = n2 / 64;                 // 1 KiB units
+    long u = wave * units / nwaves; const long uend = (wave + 1) * units / nwaves;
+    if (ORDER == 0) {
+        for (; u < uend; u += 8) {
+            double2 a[8], b[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (u + k < uend) { a[k] = w[(u + k) * 64 + lane]; b[k] = z[(u + k) * 64 + lane]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (u + k < uend) { double2 r; double t = c * a[k].x - g * b[k].x; r.x = t > 0 ? t : 0.0;
+                t = c * a[k].y - g * b[k].y; r.y = t > 0 ? t : 0.0; o[(u + k) * 64 + lane] = r; }
+        }
+    } else {
+        double2 a[8], b[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (u + k < uend) { a[k] = w[(u + k) * 64 + lane]; b[k] = z[(u + k) * 64 + lane]; }
+        for (; u < uend; u += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (u + k < uend) { double2 r; double t = c * a[k].x - g * b[k].x; r.x = t > 0 ? t : 0.0;
+                    t = c * a[k].y - g * b[k].y; r.y = t > 0 ? t : 0.0; o[(u + k) * 64 + lane] = r; }
+                if (u + 8 + k < uend) { a[k] = w[(u + 8 + k) * 64 + lane]; b[k] = z[(u + 8 + k) * 64 + lane]; }
+            }
+        }
+    }
+}
+
 __global__ void k_empty(double* p) { if (threadIdx.x == 1234567) p[0] = 1; }
 
 int main(int argc, char** argv) {
@@ -102,6 +135,20 @@ int main(int argc, char** argv) {
         run(nm, [&](int i) { k_chunk<8><<<G, 256, 0, st>>>((double2*)(i & 1 ? w1 : w0), (double2*)z, (double2*)(i & 1 ? w0 : w1), n2, 0.9, 0.1); });
         snprintf(nm, 64, "chunk inplace U8 G%d", G);
         run(nm, [&](int i) { k_chunk<8><<<G, 256, 0, st>>>((double2*)w0, (double2*)z, (double2*)w0, n2, 0.9, 0.1); });
+    }
+    for (int wpc : {8, 16}) {
+        char nm[64];
+        const int waves = wpc * 256;
+        snprintf(nm, 64, "wavechunk bs64 batch wpc%d", wpc);
+        run(nm, [&](int i) { k_wave_chunk<64, 0><<<waves, 64, 0, st>>>((double2*)(i & 1 ? w1 : w0), (double2*)z, (double2*)(i & 1 ? w0 : w1), n2, 0.9, 0.1); });
+        snprintf(nm, 64, "wavechunk bs64 rolling wpc%d", wpc);
+        run(nm, [&](int i) { k_wave_chunk<64, 1><<<waves, 64, 0, st>>>((double2*)(i & 1 ? w1 : w0), (double2*)z, (double2*)(i & 1 ? w0 : w1), n2, 0.9, 0.1); });
+        snprintf(nm, 64, "wavechunk bs256 batch wpc%d", wpc);
+        run(nm, [&](int i) { k_wave_chunk<256, 0><<<waves / 4, 256, 0, st>>>((double2*)(i & 1 ? w1 : w0), (double2*)z, (double2*)(i & 1 ? w0 : w1), n2, 0.9, 0.1); });
+        snprintf(nm, 64, "wavechunk bs256 rolling wpc%d", wpc);
+        run(nm, [&](int i) { k_wave_chunk<256, 1><<<waves / 4, 256, 0, st>>>((double2*)(i & 1 ? w1 : w0), (double2*)z, (double2*)(i & 1 ? w0 : w1), n2, 0.9, 0.1); });
+        snprintf(nm, 64, "wavechunk bs512 rolling wpc%d", wpc);
+        run(nm, [&](int i) { k_wave_chunk<512, 1><<<waves / 8, 512, 0, st>>>((double2*)(i & 1 ? w1 : w0), (double2*)z, (double2*)(i & 1 ? w0 : w1), n2, 0.9, 0.1); });
     }
     int saved = reps;
     for (int r : {100, 500, 1000, 2000, 4000}) { reps = r; char nm[64]; snprintf(nm, 64, "empty kernel x%d", r);
