@@ -24,6 +24,13 @@ import os
 import sys
 import time
 
+# One BLAS thread: the synthetic-data Cholesky would otherwise leave a pool of spinning OpenBLAS
+# workers behind that starve the HIP runtime's submission thread during the timed region
+# (observed: 2x longer GPU-side span for the same kernels).  torch.distributed.run sets
+# OMP_NUM_THREADS=1 itself; this makes the single-process run behave the same.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -29,7 +29,7 @@ for r in rows:
     by.setdefault(short(r["Kernel_Name"]), []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 total = sum(sum(v) for v in by.values())
 lines = [f"# rocprofv3 --kernel-trace --stats summary ({tag})", "",
-         "command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline`", "",
+         "command: `GRAPHLEARN_AMD_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-converge` (eager launches: the profiler serialises graph replays)", "",
          "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---:|---:|---:|---:|---:|---:|"]
 summary = {}
 for k, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
