@@ -118,7 +118,8 @@ def main():
         wall_s = comm.max_over_ranks(wall_s)
         gpu_ms = comm.max_over_ranks(gpu_ms)
 
-    edge_us = sess.time_edge_pass(200)                   # dominant kernel alone, HIP events on its stream
+    engine = sess.engine                                 # "resident" (n=4096 default) or "stream"
+    edge_us = sess.time_edge_pass(200)                   # streaming edge pass alone, HIP events on its stream
     if comm is not None:
         edge_us = comm.max_over_ranks(edge_us)
 
@@ -141,13 +142,24 @@ def main():
         its_per_s = world * args.steps / wall_s
         bytes_it = algorithmic_bytes_per_iteration(n)
         iter_us = gpu_ms * 1e3 / args.steps
-        achieved = bytes_it / (edge_us * 1e-6) / 1e9
+        # Dominant kernel of the timed region.  Resident engine: ONE launch of k_resident runs all
+        # `steps` iterations (HIP events on its stream bracket exactly that launch), so a launch
+        # processes steps x 24 E algorithmic bytes.  Streaming engine: k_edge<false>, one launch per
+        # iteration, timed alone by gl_logdeg_time_edge_pass.
+        if engine == "resident":
+            kernel, kprefix = "k_resident (persistent: edge phase + node phase + stopping rule, iterate in registers/LDS)", "k_resident"
+            launch_us, launch_bytes, its_per_launch = gpu_ms * 1e3, bytes_it * args.steps, args.steps
+        else:
+            kernel, kprefix = "k_edge<false> (edge pass: prox update of all edges + degree sums)", "k_edge"
+            launch_us, launch_bytes, its_per_launch = edge_us, bytes_it, 1
+        achieved = launch_bytes / (launch_us * 1e-6) / 1e9
         traffic = None
-        try:  # PMC FETCH_SIZE / WRITE_SIZE per launch, collected with rocprofv3 in separate passes
+        try:  # PMC FETCH_SIZE / WRITE_SIZE, collected with rocprofv3 in separate passes, per iteration
             with open(os.path.join(ROOT, "profiles", "r01_rocprof_summary.json")) as f:
                 prof = json.load(f)
             if n == 4096:
-                traffic = next(v["total_bytes"] for k, v in prof["traffic"].items() if k.startswith("k_edge"))
+                per_it = next(v["total_bytes_per_iteration"] for k, v in prof["traffic"].items() if k.startswith(kprefix))
+                traffic = per_it * its_per_launch
         except Exception:
             traffic = None
         out = {
@@ -167,12 +179,13 @@ def main():
                                    f"(BASELINE configs[1]); one independent problem per GPU",
                        "edges": n * (n - 1) // 2, "theta": theta, "setup_s_distances_theta": setup_s,
                        "gather_s": gather_s, "comm": getattr(comm, "kind", None), "gpu_us_per_iteration": iter_us,
+                       "engine": engine, "streaming_edge_pass_us": edge_us,
                        "iteration_level_frac_of_hbm_peak": bytes_it / (iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                        "time_to_converge": converge},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_edge<false> (edge pass: prox update of all edges + degree sums)",
-                         "algorithmic_bytes_per_launch": bytes_it, "avg_launch_us": edge_us,
+                         "kernel": kernel, "iterations_per_launch": its_per_launch,
+                         "algorithmic_bytes_per_launch": launch_bytes, "avg_launch_us": launch_us,
                          "traffic_source": "profiles/r01_rocprof_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                            "FETCH x2 per MI355X_MICROARCH.md)" if traffic else None},
         }

@@ -59,6 +59,7 @@ SIGNATURES = {
     "gl_logdeg_get_dual": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gl_logdeg_total_iterations": (C.c_int64, [C.c_void_p]),
     "gl_logdeg_time_edge_pass": (C.c_int, [C.c_void_p, C.c_int, _c_double_p]),
+    "gl_logdeg_engine": (C.c_int, [C.c_void_p]),
     "gl_logdeg_batch_gram": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "gl_log_degrees_fit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p,
                                      C.c_int64, C.c_double, C.c_double, C.c_double, C.c_void_p, _c_int64_p,
@@ -276,6 +277,11 @@ class LogDegreeSession:
         out = np.empty(self.n)
         self.ctx.check(self._lib.gl_logdeg_get_dual(self._h, ptr(out)), "get_dual")
         return out
+
+    @property
+    def engine(self) -> str:
+        """"resident" or "stream": the engine long iterate calls of this session run on."""
+        return "resident" if self._lib.gl_logdeg_engine(self._h) == 1 else "stream"
 
     def time_edge_pass(self, reps=200) -> float:
         """Average edge-pass duration in microseconds (HIP events; state unchanged)."""

@@ -32,6 +32,8 @@ struct LogdegDev {
     double a4g;            // 4*alpha*gamma
 };
 
+struct gl_resident;
+
 struct gl_logdeg {
     gl_ctx *ctx = nullptr;
     LogdegDev dev{};
@@ -51,6 +53,9 @@ struct gl_logdeg {
     hipGraphExec_t graph = nullptr;
     int graph_iters = 0;
     int wpc = 8;                  // edge waves per CU
+    gl_resident *res = nullptr;   // resident engine (register-held iterate), null when not applicable
+    bool res_unchecked = false;   // an asynchronous resident launch has not had its error word read yet
+    int64_t res_pending = 0;      // ... and this many iterations were asked of it
 };
 
 // gl_gram.hip
@@ -58,3 +63,8 @@ int gl_gram_distances(gl_ctx *ctx, const double *x_dev, int64_t d, int64_t n, do
 // gl_theta.hip
 int gl_theta_from_square(gl_ctx *ctx, const double *zsq_dev, int64_t n, int k, double *terms_dev,
                          double *theta_out);
+// gl_resident.hip
+int gl_resident_prepare(gl_logdeg *s);
+void gl_resident_free(gl_logdeg *s);
+int gl_resident_launch(gl_logdeg *s, int64_t iters, double tol);
+int gl_resident_finish(gl_logdeg *s, int64_t *iters_done, bool *stopped, bool *not_resident);

@@ -838,7 +838,7 @@ GL_API int gl_logdeg_create(gl_ctx *ctx, int64_t n_nodes, gl_logdeg **out) {
         return rc;
     }
     D.z = zbuf;
-    if ((rc = build_column_index(s)) != GL_OK) {
+    if ((rc = build_column_index(s)) != GL_OK || (rc = gl_resident_prepare(s)) != GL_OK) {
         gl_logdeg_destroy(s);
         return rc;
     }
@@ -853,6 +853,7 @@ GL_API int gl_logdeg_destroy(gl_logdeg *s) {
         (void)hipStreamSynchronize(s->ctx->stream);
     }
     drop_graph(s);
+    gl_resident_free(s);
     LogdegDev &D = s->dev;
     void *ptrs[] = {D.w[0], D.w[1], const_cast<double *>(D.z), D.dvar, D.dprev, D.ybar, D.pbar, D.rowslab_p, D.rowslab_w,
                     D.colslab, D.tnorm, D.bnorm, D.dstat, D.ctr, s->stage, s->zsq, s->xdev, s->theta_terms,
@@ -971,6 +972,29 @@ GL_API int gl_logdeg_init(gl_logdeg *s, double alpha, double beta, double step_s
     return GL_OK;
 }
 
+// The resident engine (gl_resident.hip) takes over when it applies and the call is long enough
+// to amortise loading / storing the register-held iterate.  GRAPHLEARN_AMD_ENGINE=stream disables it.
+static bool use_resident(const gl_logdeg *s, int64_t iters) { return s->res != nullptr && iters >= 16; }
+
+// error word of an earlier asynchronous resident launch (read at the next synchronising call)
+static int resident_check(gl_logdeg *s) {
+    if (!s->res_unchecked) return GL_OK;
+    gl_ctx *ctx = s->ctx;
+    long long *ct = (long long *)((double *)ctx->pinned + 8);
+    GL_HIP(ctx, hipMemcpyAsync(ct, s->dev.ctr, 5 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    s->res_unchecked = false;
+    if (ct[4] == 0) return GL_OK;
+    const int64_t it_before = s->it - s->res_pending;
+    if ((int64_t)ct[2] != it_before)
+        return gl_set_error(ctx, GL_E_HIP, "resident engine: grid barrier timed out in mid-run");
+    // the workgroups never met (shared GPU): nothing was modified -- redo the call on the streaming engine
+    GL_HIP(ctx, hipMemsetAsync(s->dev.ctr + 4, 0, 8, ctx->stream));
+    gl_resident_free(s);
+    s->it = it_before;
+    return launch_iterations(s, s->res_pending);
+}
+
 static int set_tol(gl_logdeg *s, double tol) {
     gl_ctx *ctx = s->ctx;
     double *slot = (double *)ctx->pinned + 16;
@@ -986,7 +1010,23 @@ GL_API int gl_logdeg_iterate_async(gl_logdeg *s, int64_t n_iter) {
     if (n_iter < 0) return gl_set_error(ctx, GL_E_INVALID, "n_iter < 0");
     GL_HIP(ctx, hipSetDevice(ctx->device));
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the pinned tol slot may still be in flight
+    GL_TRY(resident_check(s));
     GL_TRY(set_tol(s, 0.0));
+    if (use_resident(s, n_iter)) {
+        // tol = 0 never stops: the iteration count and the parity of the final buffer are known now
+        GL_TRY(gl_resident_launch(s, n_iter, 0.0));
+        const int64_t itf = s->it + n_iter;
+        if ((itf & 1) != (s->it & 1)) {
+            const size_t bytes = (size_t)s->dev.ntiles * GL_TILE_ELEMS * sizeof(double);
+            GL_HIP(ctx, hipMemcpyAsync(s->dev.w[itf & 1], s->dev.w[s->it & 1], bytes, hipMemcpyDeviceToDevice,
+                                       ctx->stream));
+        }
+        GL_HIP(ctx, hipMemsetAsync(s->dev.ctr, 0, 2 * 8, ctx->stream));
+        s->it = itf;
+        s->res_unchecked = true;
+        s->res_pending = n_iter;
+        return GL_OK;
+    }
     return launch_iterations(s, n_iter);
 }
 
@@ -998,8 +1038,29 @@ GL_API int gl_logdeg_iterate(gl_logdeg *s, int64_t maxit, double tol, int64_t *n
     if (maxit < 0) return gl_set_error(ctx, GL_E_INVALID, "maxit < 0");
     GL_HIP(ctx, hipSetDevice(ctx->device));
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GL_TRY(resident_check(s));
     LogdegDev &D = s->dev;
     GL_TRY(set_tol(s, tol));
+    if (use_resident(s, maxit)) {
+        double *st = (double *)ctx->pinned;
+        int64_t ran = 0;
+        bool stopped = false;
+        bool not_resident = false;
+        GL_TRY(gl_resident_launch(s, maxit, tol));
+        GL_TRY(gl_resident_finish(s, &ran, &stopped, &not_resident));
+        if (!not_resident) {
+            GL_HIP(ctx, hipMemcpyAsync(st, D.dstat, 2 * 8, hipMemcpyDeviceToHost, ctx->stream));
+            GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (n_iter_out) *n_iter_out = ran;
+            if (converged_out) *converged_out = stopped ? 1 : 0;
+            if (rel_out) {
+                rel_out[0] = st[0];
+                rel_out[1] = st[1];
+            }
+            return GL_OK;
+        }
+        gl_resident_free(s);  // shared GPU: this session stays on the streaming engine
+    }
     const int64_t start = s->it;
     const int64_t end = start + maxit;
     double *st = (double *)ctx->pinned;          // [0..2]  dstat
@@ -1042,6 +1103,7 @@ GL_API int gl_logdeg_get_weights_condensed(gl_logdeg *s, double edge_tol, double
     gl_ctx *ctx = s->ctx;
     if (!s->inited) return gl_set_error(ctx, GL_E_STATE, "no iterate yet: call init first");
     GL_HIP(ctx, hipSetDevice(ctx->device));
+    GL_TRY(resident_check(s));
     k_to_condensed<<<dim3((unsigned)s->dev.ntiles), dim3(256), 0, ctx->stream>>>(s->dev.w[s->it & 1], s->stage, s->n,
                                                                               s->dev.nb, edge_tol);
     GL_HIP(ctx, hipGetLastError());
@@ -1057,6 +1119,7 @@ GL_API int gl_logdeg_get_weights_square(gl_logdeg *s, double edge_tol, double *w
     if (!w_out) return gl_set_error(ctx, GL_E_INVALID, "w_out is NULL");
     if (!s->inited) return gl_set_error(ctx, GL_E_STATE, "no iterate yet: call init first");
     GL_HIP(ctx, hipSetDevice(ctx->device));
+    GL_TRY(resident_check(s));
     // the square result (n^2) is staged in zsq-sized scratch; allocate on demand
     double *sq = nullptr;
     GL_HIP(ctx, hipMalloc((void **)&sq, (size_t)s->n * s->n * 8));
@@ -1076,6 +1139,7 @@ GL_API int gl_logdeg_get_dual(gl_logdeg *s, double *d_out) {
     if (!d_out) return gl_set_error(ctx, GL_E_INVALID, "d_out is NULL");
     if (!s->inited) return gl_set_error(ctx, GL_E_STATE, "no iterate yet: call init first");
     GL_HIP(ctx, hipSetDevice(ctx->device));
+    GL_TRY(resident_check(s));
     GL_HIP(ctx, hipMemcpyAsync(d_out, s->dev.dvar, (size_t)s->n * 8, hipMemcpyDeviceToHost, ctx->stream));
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GL_OK;
@@ -1163,6 +1227,8 @@ GL_API int gl_logdeg_batch_gram(gl_logdeg **sessions, int B, double *out) {
 // events on the solver's stream over `reps` back-to-back launches.  The iteration counter is not
 // advanced, so every launch recomputes the same pass (reads w[it&1], writes w[(it+1)&1]) and the
 // session state is unchanged.
+GL_API int gl_logdeg_engine(gl_logdeg *s) { return s && s->res ? 1 : 0; }
+
 GL_API int gl_logdeg_time_edge_pass(gl_logdeg *s, int reps, double *avg_us_out) {
     GL_TRY(check(s));
     gl_ctx *ctx = s->ctx;

@@ -25,6 +25,15 @@ ATOL = 1e-10
 CASES = ["logmodel_n7_d23", "logmodel_n16_d40", "logmodel_n64_d256"]
 
 
+@pytest.fixture(autouse=True, params=["stream", "resident"])
+def engine(request, monkeypatch):
+    """Every test of this file runs on both iteration engines: the streaming one (one edge-pass +
+    one node-pass launch per iteration) and the resident one (iterate held in registers / LDS,
+    grid barriers; by default only chosen for n >~ 3400, forced here)."""
+    monkeypatch.setenv("GRAPHLEARN_AMD_ENGINE", request.param)
+    return request.param
+
+
 def raw_iterate(z, alpha, beta, k, step_size=0.5, edge_init=None):
     n = old.n_nodes_from_edges(z.size)
     with _lib.LogDegreeSession(n) as s:
@@ -117,8 +126,13 @@ def test_resume_equals_single_run(golden):
         s.iterate_async(30)
         assert s.total_iterations == 50
         w = s.weights_condensed()
-    np.testing.assert_array_equal(w, raw_iterate(zt, 1, 1, 50)[0])  # bit-identical: deterministic
+    # with the resident engine forced, short calls (< 16 iterations) still run on the streaming
+    # engine: same iterates up to the order of the degree sums
+    np.testing.assert_allclose(w, raw_iterate(zt, 1, 1, 50)[0], rtol=0, atol=1e-13)
     np.testing.assert_allclose(w, g["raw_w_it50"], rtol=0, atol=ATOL)
+    # each engine by itself is bit-reproducible run to run
+    np.testing.assert_array_equal(raw_iterate(zt, 1, 1, 50)[0], raw_iterate(zt, 1, 1, 50)[0])
+    np.testing.assert_array_equal(raw_iterate(zt, 1, 1, 12)[0], raw_iterate(zt, 1, 1, 12)[0])
 
 
 @pytest.mark.parametrize("n", [2, 3, 5, 63, 64, 65, 129, 200])
@@ -213,3 +227,31 @@ def test_c2_size_properties_after_many_iterations():
     assert np.array_equal(sq[i, j], wt)
     raw_deg = squareform(w).sum(1)
     assert (raw_deg > 0).all()                 # log barrier: every node keeps positive (raw) degree
+
+
+def test_resident_engine_falls_back_when_workgroups_do_not_meet(golden, engine, monkeypatch):
+    """The resident engine's workgroups must all be on the chip at once.  When they are not (shared
+    GPU), the start-up rendezvous times out before anything is modified and the call is served by
+    the streaming engine -- synchronously and for an asynchronous call at its next sync point."""
+    if engine != "resident":
+        pytest.skip("resident engine only")
+    g = golden("logmodel_n64_d256")
+    zt = g["z"] * float(g["theta_deg6"])
+    monkeypatch.setenv("GRAPHLEARN_AMD_RES_TEST_NOT_RESIDENT", "1")  # rendezvous expects one workgroup too many
+    with _lib.LogDegreeSession(64) as s:
+        s.set_distances(zt)
+        s.init(1, 1, 0.5, None)
+        assert s.engine == "resident"
+        n_it, conv, _ = s.iterate(20, 0.0)
+        assert n_it == 20 and not conv and s.engine == "stream"
+        s.iterate_async(30)
+        w = s.weights_condensed()
+        assert s.total_iterations == 50
+    np.testing.assert_allclose(w, g["raw_w_it50"], rtol=0, atol=ATOL)
+    with _lib.LogDegreeSession(64) as s:
+        s.set_distances(zt)
+        s.init(1, 1, 0.5, None)
+        s.iterate_async(50)            # falls back at the next synchronising call
+        w = s.weights_condensed()
+        assert s.engine == "stream" and s.total_iterations == 50
+    np.testing.assert_allclose(w, g["raw_w_it50"], rtol=0, atol=ATOL)
