@@ -233,6 +233,84 @@ def gen_operators():
     save("operators", **arrays)
 
 
+def gen_graphdict():
+    """GraphDictLog (dictionary/log_model.py + base_model.py): fitted state on small seeded inputs,
+    the state after the first steps (through the reference's own callback hook), every
+    initialisation strategy, predict and score."""
+    import warnings
+
+    from graph_learn.dictionary import GraphDictLog
+
+    warnings.simplefilter("ignore")
+    arrays = {}
+
+    def snap(store, tag, steps):
+        def cb(model, i):
+            if i in steps:
+                store[f"{tag}_c_it{i}"] = model.coefficients_.copy()
+                store[f"{tag}_w_it{i}"] = model.weights_.copy()
+                store[f"{tag}_dual_it{i}"] = model.dual_.copy()
+        return cb
+
+    # A: the shapes of the reference's own test (tests/test_models.py:11-23)
+    data = default_rng(240920).standard_normal((23, 7))
+    arrays["A_x"] = data
+    for k in (1, 3):
+        for l1 in (0.0, 0.01):
+            tag = f"A_k{k}_l1w{l1}"
+            m = GraphDictLog(n_atoms=k, l1_w=l1, random_state=240920, max_iter=100)
+            m.fit(data, callback=snap(arrays, tag, {0, 1, 2, 10}))
+            arrays[f"{tag}_c"], arrays[f"{tag}_w"], arrays[f"{tag}_dual"] = m.coefficients_, m.weights_, m.dual_
+            arrays[f"{tag}_converged"] = np.int64(m.converged_)
+            arrays[f"{tag}_history"] = m.history_.to_numpy()
+
+    # B: windows (with padding), every regulariser on, separate steps
+    rng = default_rng(77)
+    xb = rng.standard_normal((50, 12)) * 0.7
+    arrays["B_x"] = xb
+    kw = dict(n_atoms=3, window_size=4, l1_w=0.02, ortho_w=0.1, l1_c=0.01, log_c=0.05, l1_diff_c=0.001,
+              step_c=0.5, step_w=0.3, step_dual=0.7, tol=1e-12, max_iter=60, random_state=5)
+    m = GraphDictLog(**kw)
+    m.fit(xb, callback=snap(arrays, "B", {0, 1, 2, 3, 20}))
+    arrays["B_c"], arrays["B_w"], arrays["B_dual"] = m.coefficients_, m.weights_, m.dual_
+    arrays["B_converged"] = np.int64(m.converged_)
+    arrays["B_history"] = m.history_.to_numpy()
+
+    # C: two ER graphs, smooth signals, step 0.5: stops on the tolerance (step 466)
+    rng = default_rng(2024)
+    laps = [sample_er_laplacian(16, 0.3, 0.3, 2.0, seed=rng) for _ in range(2)]
+    xc = np.concatenate([sample_lgmrf(lap, 32, seed=rng) for lap in laps])
+    arrays["C_x"] = xc
+    m = GraphDictLog(n_atoms=2, random_state=11, l1_w=0.05, step=0.5, max_iter=1000)
+    m.fit(xc, callback=snap(arrays, "C", {0}))
+    arrays["C_c"], arrays["C_w"], arrays["C_dual"] = m.coefficients_, m.weights_, m.dual_
+    arrays["C_converged"] = np.int64(m.converged_)
+    arrays["C_history"] = m.history_.to_numpy()
+    arrays["C_score"] = np.float64(m.score(xc))
+    xp = np.concatenate([sample_lgmrf(lap, 8, seed=rng) for lap in laps])
+    arrays["C_predict_x"] = xp
+    m.random_state = np.random.RandomState(3)
+    m.max_iter = 50
+    arrays["C_predict"] = m.predict(xp)
+
+    # D: every initialisation strategy (state right after _initialize)
+    xd = default_rng(9).standard_normal((24, 6))
+    arrays["D_x"] = xd
+    for tag, kwd in {
+        "uniform_prior": dict(init_strategy="uniform", weight_prior=0.5, coefficient_prior=0.8),
+        "discrete": dict(init_strategy="discrete", weight_prior=0.3),
+        "exp": dict(init_strategy="exp", weight_prior=0.2, coefficient_prior=0.4),
+        "exact": dict(init_strategy="exact", weight_prior=0.25, coefficient_prior=0.6),
+        "kmd_corr_a": dict(init_strategy_c="k-means++d", init_strategy_w="correlation_a"),
+        "kmc_corr_a_pinv": dict(init_strategy_c="k-means++c", init_strategy_w="correlation_a_pinv"),
+        "window_uniform": dict(init_strategy="uniform", window_size=3),
+    }.items():
+        m = GraphDictLog(n_atoms=3, random_state=42, **kwd)
+        m._initialize(xd)
+        arrays[f"D_{tag}_c"], arrays[f"D_{tag}_w"] = m.coefficients_, m.weights_
+    save("graphdict", **arrays)
+
+
 if __name__ == "__main__":
     gen_sum_squareform()
     gen_theta()
@@ -240,3 +318,4 @@ if __name__ == "__main__":
     gen_batched()
     gen_lgmrf()
     gen_operators()
+    gen_graphdict()
