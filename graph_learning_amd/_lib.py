@@ -77,6 +77,17 @@ SIGNATURES = {
                                      C.c_void_p, _c_int_p]),
     "gl_lgmrf_fit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_double,
                                C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _c_int_p, _c_int_p]),
+    "gl_graphdict_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "gl_graphdict_destroy": (None, [C.c_void_p]),
+    "gl_graphdict_set_signals": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gl_graphdict_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gl_graphdict_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gl_graphdict_set_params": (C.c_int, [C.c_void_p] + [C.c_double] * 8),
+    "gl_graphdict_get_steps": (C.c_int, [C.c_void_p, _c_double_p]),
+    "gl_graphdict_fit": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_void_p, _c_int64_p, _c_int64_p,
+                                   _c_int_p]),
+    "gl_graphdict_predict": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_void_p, _c_int64_p, _c_int_p]),
+    "gl_graphdict_time_gradients": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p]),
     "gl_comm_unique_id": (C.c_int, [C.c_void_p]),
     "gl_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "gl_comm_destroy": (C.c_int, [C.c_void_p]),
@@ -309,3 +320,88 @@ class LogDegreeSession:
 
     def __exit__(self, *exc):
         self.close()
+
+
+class GraphDictSession:
+    """Device-resident graph-dictionary problem (gl_graphdict_*): signals, (C, W, dual) state."""
+
+    def __init__(self, n_nodes: int, n_samples: int, n_atoms: int, window_size: int = 1, ctx: Context | None = None):
+        self.ctx = ctx or default_context()
+        self._lib = self.ctx._lib
+        self.n, self.t, self.k, self.window = int(n_nodes), int(n_samples), int(n_atoms), int(window_size)
+        self.n_edges = self.n * (self.n - 1) // 2
+        h = C.c_void_p()
+        self.ctx.check(self._lib.gl_graphdict_create(self.ctx.handle, self.n, self.t, self.k, self.window, C.byref(h)),
+                       "graphdict_create")
+        self._h = h
+
+    def set_signals(self, x):
+        x = as_f64(x)
+        if x.shape != (self.t, self.n):
+            raise ValueError(f"x must be ({self.t}, {self.n}), got {x.shape}")
+        self.ctx.check(self._lib.gl_graphdict_set_signals(self._h, ptr(x)), "graphdict_set_signals")
+
+    def set_state(self, coefficients, weights, dual=None):
+        c, w = as_f64(coefficients), as_f64(weights)
+        if c.shape != (self.k, self.t) or w.shape != (self.k, self.n_edges):
+            raise ValueError(f"state shapes: coefficients {(self.k, self.t)}, weights {(self.k, self.n_edges)}; "
+                             f"got {c.shape}, {w.shape}")
+        if dual is not None:
+            dual = as_f64(dual)
+            if dual.shape != (self.t // self.window, self.n):
+                raise ValueError(f"dual must be {(self.t // self.window, self.n)}, got {dual.shape}")
+        self.ctx.check(self._lib.gl_graphdict_set_state(self._h, ptr(c), ptr(w), ptr(dual)), "graphdict_set_state")
+
+    def get_state(self):
+        c, w = np.empty((self.k, self.t)), np.empty((self.k, self.n_edges))
+        d = np.empty((self.t // self.window, self.n))
+        self.ctx.check(self._lib.gl_graphdict_get_state(self._h, ptr(c), ptr(w), ptr(d)), "graphdict_get_state")
+        return c, w, d
+
+    def set_params(self, l1_w=0.0, ortho_w=0.0, l1_c=0.0, log_c=0.0, l1_diff_c=0.0, step_c=1.0, step_w=1.0,
+                   step_dual=1.0):
+        self.ctx.check(self._lib.gl_graphdict_set_params(self._h, *[float(v) for v in (
+            l1_w, ortho_w, l1_c, log_c, l1_diff_c, step_c, step_w, step_dual)]), "graphdict_set_params")
+
+    def steps(self):
+        out = (C.c_double * 3)()
+        self.ctx.check(self._lib.gl_graphdict_get_steps(self._h, out), "graphdict_get_steps")
+        return out[0], out[1], out[2]
+
+    def fit(self, max_iter, tol, reduce_step_on_plateau=False):
+        """-> (history (max_iter, 2), steps_run, converged_, flags)."""
+        hist = np.empty((max(int(max_iter), 0), 2))
+        ran, conv, flags = C.c_int64(0), C.c_int64(-1), C.c_int(0)
+        self.ctx.check(self._lib.gl_graphdict_fit(self._h, int(max_iter), float(tol), int(bool(reduce_step_on_plateau)),
+                                                  ptr(hist), C.byref(ran), C.byref(conv), C.byref(flags)), "graphdict_fit")
+        return hist, ran.value, conv.value, flags.value
+
+    def predict(self, max_iter, tol):
+        out = np.empty((self.k, self.t))
+        ran, flags = C.c_int64(0), C.c_int(0)
+        self.ctx.check(self._lib.gl_graphdict_predict(self._h, int(max_iter), float(tol), ptr(out), C.byref(ran),
+                                                      C.byref(flags)), "graphdict_predict")
+        return out, ran.value, flags.value
+
+    def time_gradients(self, reps=20):
+        a, b = C.c_double(0), C.c_double(0)
+        self.ctx.check(self._lib.gl_graphdict_time_gradients(self._h, int(reps), C.byref(a), C.byref(b)),
+                       "graphdict_time_gradients")
+        return a.value, b.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gl_graphdict_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -189,6 +189,42 @@ int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n_nodes, double norm_par,
                  double qp_step, double qp_tol, int regularization_type, const double *adj_mask, int path,
                  double *laplacian_out, double *inv_laplacian_out, int *converged_out, int *cycles_out);
 
+/* ---- graph dictionary with log-barrier degrees (graph_learn/dictionary/log_model.py:14-50 over
+ * dictionary/base_model.py:355-676) -- SURVEY.md section 8 row f-1 ---------------------------
+ * K atoms (graphs, condensed weights K x E), coefficients K x T (constant over windows of
+ * window_size samples), one dual vector per window (T/window x n).  A session owns the device
+ * state; the (T x E) matrix of squared pairwise differences of the reference is never formed.
+ * n_samples is the padded sample count (a multiple of window_size, base_model.py:603-608);
+ * n_atoms <= 16. */
+typedef struct gl_graphdict gl_graphdict;
+int gl_graphdict_create(gl_ctx *ctx, int64_t n_nodes, int64_t n_samples, int n_atoms, int window_size,
+                        gl_graphdict **out);
+void gl_graphdict_destroy(gl_graphdict *s);
+/* x: (n_samples, n_nodes) row-major. */
+int gl_graphdict_set_signals(gl_graphdict *s, const double *x);
+/* coefficients_ (K x T), weights_ (K x E), dual_ (T/window x n, NULL = zeros) as the reference
+ * holds them after _initialize (base_model.py:313-333) or after any step. */
+int gl_graphdict_set_state(gl_graphdict *s, const double *coefficients, const double *weights, const double *dual);
+int gl_graphdict_get_state(gl_graphdict *s, double *coefficients, double *weights, double *dual);
+/* l1_w, ortho_w, l1_c, log_c, l1_diff_c, step_c, step_w, step_dual (base_model.py:95-117). */
+int gl_graphdict_set_params(gl_graphdict *s, double l1_w, double ortho_w, double l1_c, double log_c,
+                            double l1_diff_c, double step_c, double step_w, double step_dual);
+/* current (step_c, step_w, step_dual): reduce_step_on_plateau shrinks them (base_model.py:571-573) */
+int gl_graphdict_get_steps(gl_graphdict *s, double *steps3_out);
+/* The loop of _single_fit (base_model.py:552-581): up to max_iter steps of _fit_step (:485-527);
+ * history_out is (max_iter, 2) = relative change of coefficients / weights per step (-1 where not
+ * run); converged_out = converged_ (step index or -1; the loop stops only at an index > 0, :578);
+ * flags_out: bit 0 "All coefficients dropped to 0" (:406-408), bit 1 step sizes were reduced. */
+int gl_graphdict_fit(gl_graphdict *s, int64_t max_iter, double tol, int reduce_step_on_plateau,
+                     double *history_out, int64_t *steps_run_out, int64_t *converged_out, int *flags_out);
+/* predict (base_model.py:647-676): weights fixed, coefficients start from the session's state,
+ * dual from zero; coefficients_out is (K x T). */
+int gl_graphdict_predict(gl_graphdict *s, int64_t max_iter, double tol, double *coefficients_out,
+                         int64_t *steps_run_out, int *flags_out);
+/* Measurement facility: average microseconds of the coefficient-gradient and the weight-gradient
+ * kernel alone (HIP events on the session's stream, `reps` launches each); state unchanged. */
+int gl_graphdict_time_gradients(gl_graphdict *s, int reps, double *grad_c_us_out, double *grad_w_us_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,160 @@
+"""Parity of the HIP GraphDictLog path (through the C ABI) against the golden vectors of the
+reference and against the oracle.  Needs an MI355X.
+
+Tolerances (fp64): one step differs from NumPy only in the summation order of the two gradient
+contractions (BLAS GEMM there, fixed strip / sample order here) and in forming the overshoot
+degrees as 2 S w_new - S w_old instead of S (2 w_new - w_old): ~1e-15 relative per step.  The
+iteration is not contractive (the reference's own runs oscillate for hundreds of steps), so the
+bound is stated per case: 1e-10 for a few steps, 1e-7 after a hundred.
+"""
+
+import warnings
+
+import numpy as np
+import pytest
+
+from graph_learning_amd import _lib
+from graph_learning_amd.dictionary import GraphDictLog
+from oracle.graphdict import GraphDictLogOracle
+
+pytestmark = pytest.mark.gpu
+
+CASE_B = dict(n_atoms=3, window_size=4, l1_w=0.02, ortho_w=0.1, l1_c=0.01, log_c=0.05, l1_diff_c=0.001,
+              step_c=0.5, step_w=0.3, step_dual=0.7, tol=1e-12, max_iter=60, random_state=5)
+CASE_C = dict(n_atoms=2, random_state=11, l1_w=0.05, step=0.5, max_iter=1000)
+
+
+@pytest.fixture(autouse=True)
+def quiet():
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        yield
+
+
+def close(a, b, tol):
+    np.testing.assert_allclose(a, b, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("k", [1, 3])
+@pytest.mark.parametrize("l1", [0.0, 0.01])
+def test_reference_test_shapes_golden(golden, k, l1):
+    """tests/test_models.py:21-23 of the reference, with its outputs pinned."""
+    g = golden("graphdict")
+    tag = f"A_k{k}_l1w{l1}"
+    for steps in (1, 2, 10):
+        m = GraphDictLog(n_atoms=k, l1_w=l1, random_state=240920, max_iter=steps).fit(g["A_x"])
+        close(m.coefficients_, g[f"{tag}_c_it{steps}"], 1e-10)
+        close(m.weights_, g[f"{tag}_w_it{steps}"], 1e-10)
+        close(m.dual_, g[f"{tag}_dual_it{steps}"], 1e-10)
+    m = GraphDictLog(n_atoms=k, l1_w=l1, random_state=240920, max_iter=100).fit(g["A_x"])
+    # One atom on this input is a chaotic orbit: in the reference's own arithmetic a 1e-15 relative
+    # perturbation of the start grows to 1e-15 / 1e-10 / 2e-8 / 6e-4 after 10 / 30 / 50 / 100 steps
+    # (measured with the oracle); three atoms stay at 1e-14.  The bounds follow that.
+    hist = m.history_.to_numpy()
+    close(hist[:30], g[tag + "_history"][:30], 1e-8)
+    end = 1e-9 if k == 3 else 2e-2
+    close(m.coefficients_, g[tag + "_c"], end)
+    close(m.weights_, g[tag + "_w"], end)
+    close(m.dual_, g[tag + "_dual"], end)
+    close(hist, g[tag + "_history"], end * 10)
+    assert m.converged_ == int(g[tag + "_converged"])
+    assert m.n_nodes_ == 7 and m.fit_time_ > 0
+
+
+def test_windows_padding_all_regularisers_golden(golden):
+    g = golden("graphdict")
+    t = g["B_x"].shape[0]
+    for steps in (1, 2, 3, 20):
+        m = GraphDictLog(**{**CASE_B, "max_iter": steps}).fit(g["B_x"])
+        close(m.coefficients_, g[f"B_c_it{steps}"][:, :t], 1e-10)
+        close(m.weights_, g[f"B_w_it{steps}"], 1e-10)
+        close(m.dual_, g[f"B_dual_it{steps}"], 1e-10)
+    m = GraphDictLog(**CASE_B).fit(g["B_x"])
+    close(m.coefficients_, g["B_c"], 1e-9)
+    close(m.weights_, g["B_w"], 1e-9)
+    close(m.history_.to_numpy(), g["B_history"], 1e-9)
+
+
+def test_runs_to_tolerance_predict_score_golden(golden):
+    g = golden("graphdict")
+    m = GraphDictLog(**CASE_C).fit(g["C_x"])
+    assert abs(m.converged_ - int(g["C_converged"])) <= 1
+    if m.converged_ == int(g["C_converged"]):
+        close(m.coefficients_, g["C_c"], 1e-7)
+        close(m.weights_, g["C_w"], 1e-7)
+    # score (host) from the reference's fitted state; from the GPU state it is only finite: the
+    # log-determinant term counts the +-1e-16 null eigenvalue of each Laplacian when it comes out
+    # positive (-37 each), so it jumps with the last bit of the weights (base_model.py:722-729)
+    assert np.isfinite(m.score(g["C_x"]))
+    ref_state = GraphDictLog(**CASE_C)
+    ref_state.n_nodes_, ref_state.weights_, ref_state.coefficients_ = 16, g["C_w"], g["C_c"]
+    assert ref_state.score(g["C_x"]) == pytest.approx(float(g["C_score"]), rel=1e-12)
+    m.weights_ = g["C_w"].copy()  # predict from the reference's atoms exactly
+    m.random_state = np.random.RandomState(3)
+    m.max_iter = 50
+    close(m.predict(g["C_predict_x"]), g["C_predict"], 1e-9)
+    with pytest.raises(ValueError):
+        m.predict(np.zeros((4, 3)))
+
+
+def test_callback_path_equals_fused_loop(golden):
+    g = golden("graphdict")
+    seen = []
+    a = GraphDictLog(**{**CASE_B, "max_iter": 12}).fit(g["B_x"], callback=lambda mdl, i: seen.append(i))
+    b = GraphDictLog(**{**CASE_B, "max_iter": 12}).fit(g["B_x"])
+    assert seen == list(range(13))
+    np.testing.assert_array_equal(a.weights_, b.weights_)
+    np.testing.assert_array_equal(a.coefficients_, b.coefficients_)
+    np.testing.assert_array_equal(a.history_.to_numpy(), b.history_.to_numpy())
+
+
+@pytest.mark.parametrize("n,t,k,window", [(70, 200, 5, 1), (130, 96, 12, 3), (64, 128, 8, 2), (33, 50, 16, 5)])
+def test_ragged_sizes_against_oracle(n, t, k, window):
+    """n off the 64-wide blocks, T off the 128-sample blocks, every atom padding (4 / 8 / 16)."""
+    x = np.random.default_rng(n + t).standard_normal((t, n)) * 0.5
+    kw = dict(n_atoms=k, window_size=window, l1_w=0.01, l1_c=0.002, ortho_w=0.05, step=0.4, max_iter=4, tol=0.0,
+              random_state=n)
+    o = GraphDictLogOracle(**kw).fit(x)
+    m = GraphDictLog(**kw).fit(x)
+    close(m.coefficients_, o.coefficients_, 1e-10)
+    close(m.weights_, o.weights_, 1e-10)
+    close(m.dual_, o.dual_, 1e-10)
+    close(m.history_.to_numpy(), o.history_, 1e-9)
+
+
+def test_all_coefficients_dropped_guard():
+    """base_model.py:406-408: a huge l1_c drives every coefficient to 0 -> refilled with log_c."""
+    x = np.random.default_rng(0).standard_normal((20, 6))
+    kw = dict(n_atoms=2, l1_c=10.0, log_c=0.3, max_iter=2, random_state=1)
+    with pytest.warns(UserWarning, match="All coefficients dropped to 0"):
+        m = GraphDictLog(**kw).fit(x)
+    o = GraphDictLogOracle(**kw).fit(x)
+    close(m.coefficients_, o.coefficients_, 1e-12)
+    close(m.weights_, o.weights_, 1e-10)
+
+
+def test_reduce_step_on_plateau_against_oracle(golden):
+    g = golden("graphdict")
+    kw = dict(n_atoms=3, l1_w=0.0, random_state=240920, max_iter=130, reduce_step_on_plateau=True, tol=1e-9)
+    o = GraphDictLogOracle(**kw).fit(g["A_x"])
+    m = GraphDictLog(**kw).fit(g["A_x"])
+    assert (m.step_c, m.step_w, m.step_dual) == pytest.approx((o.step_c, o.step_w, o.step_dual))
+    close(m.history_.to_numpy(), o.history_, 1e-6)
+
+
+def test_errors():
+    with pytest.raises(ValueError):
+        GraphDictLog(n_atoms=17).fit(np.zeros((8, 5)))
+    with pytest.raises(ValueError):
+        GraphDictLog(init_strategy_c="nope").fit(np.zeros((8, 5)))
+    with pytest.raises(ValueError):
+        GraphDictLog().fit(np.zeros(5))
+    with _lib.GraphDictSession(5, 8, 2) as s:
+        with pytest.raises(_lib.GraphLearnError):
+            s.fit(3, 0.0)  # no signals / state yet
+
+
+def test_sklearn_surface():
+    m = GraphDictLog(n_atoms=2, l1_w=0.1, window_size=2)
+    p = m.get_params()
+    assert p["n_atoms"] == 2 and p["l1_w"] == 0.1 and p["window_size"] == 2
