@@ -8,7 +8,7 @@
 // With K <= 16 these are not GEMM-shaped work: forming D[t,e] on the fly costs 2 flops against
 // 2 K flops of use, and nothing has to be stored.  Two kernels do that:
 //
-//   k_gd_grad_c   lane <-> sample (two per lane), wave walks pairs (i, j): x_i, x_j come from the
+//   k_gd_grad_c   lane <-> sample (four per lane), wave walks pairs (i, j): x_i, x_j come from the
 //                 transposed signal matrix XT (n x T, coalesced), the K weights of the pair are
 //                 wave-uniform -> scalar loads from the pair-major weight array WS[i][j][K].
 //   k_gd_grad_w   lane <-> column j, wave holds a strip of rows i: x_j from X (T x n, coalesced),
@@ -31,7 +31,9 @@
 namespace {
 
 constexpr int GD_MAXK = 16;
-constexpr int GD_SB = 128;       // samples per wave in k_gd_grad_c (two per lane)
+constexpr int GD_SPL = 4;        // samples per lane in k_gd_grad_c
+constexpr int GD_SB = 64 * GD_SPL;  // samples per wave
+static inline int gd_rows_c(int KP) { return KP <= 8 ? 2 : 1; }  // rows per strip in k_gd_grad_c (SGPR budget)
 constexpr int GD_NORM_SLOTS = 8;
 
 struct GdDev {
@@ -49,11 +51,15 @@ struct GdDev {
     double *deg;      // KP x n_pad: S W' of the current weights
     double *deg_new;  // KP x n_pad: of the updated weights
     double *SC;       // NG x KP x Tp: partial coefficient gradients
+    double *SCR;      // KP x Tp: their sum over the strip groups
+    double *cnorm;    // 256 x 3: per-workgroup partials of the coefficient change
     double *GS;       // TS x n_pad x n_pad x KP: partial weight gradients
     double *MSL;      // MS x KP x n_pad: partial sums of C @ dual
     double *M;        // KP x n_pad
     double *cpart;    // Tw: max |c_new| per window
     double *wpart;    // (n * nbj) x 3: sum (w_new - w)^2, sum w^2, max |w| per (row, column block)
+    int2 *wtasks;     // (row strip, column block) tasks of k_gd_grad_w
+    int nwtasks;
     double *stat;     // [0] rel change C, [1] rel change W, [2] flag "all coefficients dropped to 0"
     // parameters of the step
     double l1_w, ortho_w, l1_c, log_c, l1_diff_c, step_c, step_w, step_dual;
@@ -73,82 +79,176 @@ __device__ __forceinline__ double gd_wave_max(double v) {
 // ------------------------------------------------------------------------------------------
 // coefficient gradient: SC[g][k][t] = sum over the pairs of strip group g of W[k,(i,j)] (x_ti - x_tj)^2
 // (base_model.py:375 `self.weights_ @ sq_pdiffs.T`).  grid (Tp / 128, NG), one wave per workgroup.
-template <int KP>
+template <int KP, int RC>
 __global__ __launch_bounds__(64) void k_gd_grad_c(const double *__restrict__ XT, const double *__restrict__ WS,
                                                   double *__restrict__ SC, int n, int n_pad, int Tp, int NG) {
     const int lane = threadIdx.x;
     const int g = blockIdx.y;
-    const int64_t t0 = (int64_t)blockIdx.x * GD_SB + lane;
-    double acc0[KP], acc1[KP];
+    const int64_t t0 = (int64_t)blockIdx.x * GD_SB + lane;  // this lane's samples: t0 + 64 q, q < GD_SPL
+    double acc[GD_SPL][KP];
 #pragma unroll
-    for (int k = 0; k < KP; ++k) acc0[k] = acc1[k] = 0.0;
-    const int nstrips = (n + 3) / 4;
-    for (int s = g; s < nstrips; s += NG) {
-        const int i0 = 4 * s;
-        double xi0[4], xi1[4];
+    for (int q = 0; q < GD_SPL; ++q)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            xi0[a] = XT[(int64_t)(i0 + a) * Tp + t0];
-            xi1[a] = XT[(int64_t)(i0 + a) * Tp + t0 + 64];
-        }
-        for (int j = i0 + 1; j < n; ++j) {
-            const double xj0 = XT[(int64_t)j * Tp + t0], xj1 = XT[(int64_t)j * Tp + t0 + 64];
+        for (int k = 0; k < KP; ++k) acc[q][k] = 0.0;
+    const int nstrips = (n + RC - 1) / RC;
+    // strip s has n - RC s - 1 columns to walk: dealing the strips out in serpentine order
+    // (g, 2 NG - 1 - g, 2 NG + g, ...) gives every group the same amount of work
+    for (int r = 0; r * NG < nstrips; ++r) {
+        const int s = r * NG + ((r & 1) ? NG - 1 - g : g);
+        if (s >= nstrips) continue;
+        const int i0 = RC * s;
+        if (i0 + 1 >= n) continue;
+        double xi[RC][GD_SPL];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                // rows i0 + a >= j carry zeros in WS (lower triangle): no branch needed
-                const double *__restrict__ wp = WS + ((int64_t)(i0 + a) * n_pad + j) * KP;  // wave-uniform
-                const double d0 = xi0[a] - xj0, d1 = xi1[a] - xj1;
-                const double s0 = d0 * d0, s1 = d1 * d1;
+        for (int a = 0; a < RC; ++a)
 #pragma unroll
-                for (int k = 0; k < KP; ++k) {
-                    const double w = wp[k];
-                    acc0[k] = __builtin_fma(w, s0, acc0[k]);
-                    acc1[k] = __builtin_fma(w, s1, acc1[k]);
-                }
+            for (int q = 0; q < GD_SPL; ++q) xi[a][q] = XT[(int64_t)(i0 + a) * Tp + t0 + 64 * q];
+        // software pipeline over the columns j, two operand sets (see k_gd_grad_w); rows i0 + a >= j
+        // carry zeros in WS (lower triangle): no branch needed
+        double wA[RC][KP], xjA[GD_SPL], wB[RC][KP], xjB[GD_SPL];
+        auto request = [&](int j, double (&w)[RC][KP], double (&xj)[GD_SPL]) {
+            const int jc = j < n ? j : n - 1;
+#pragma unroll
+            for (int a = 0; a < RC; ++a) {
+                const double *__restrict__ wp = WS + ((int64_t)(i0 + a) * n_pad + jc) * KP;  // wave-uniform
+#pragma unroll
+                for (int k = 0; k < KP; ++k) w[a][k] = wp[k];
             }
+#pragma unroll
+            for (int q = 0; q < GD_SPL; ++q) xj[q] = XT[(int64_t)jc * Tp + t0 + 64 * q];
+        };
+        auto accumulate = [&](const double (&w)[RC][KP], const double (&xj)[GD_SPL]) {
+#pragma unroll
+            for (int a = 0; a < RC; ++a)
+#pragma unroll
+                for (int q = 0; q < GD_SPL; ++q) {
+                    const double d = xi[a][q] - xj[q];
+                    const double sq = d * d;
+#pragma unroll
+                    for (int k = 0; k < KP; ++k) acc[q][k] = __builtin_fma(w[a][k], sq, acc[q][k]);
+                }
+        };
+        int j = i0 + 1;
+        request(j, wA, xjA);
+        for (; j + 1 < n; j += 2) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): set A is in
+            request(j + 1, wB, xjB);
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate(wA, xjA);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // set B is in
+            request(j + 2, wA, xjA);
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate(wB, xjB);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (j < n) accumulate(wA, xjA);
     }
 #pragma unroll
-    for (int k = 0; k < KP; ++k) {
-        SC[((int64_t)g * KP + k) * Tp + t0] = acc0[k];
-        SC[((int64_t)g * KP + k) * Tp + t0 + 64] = acc1[k];
-    }
+    for (int q = 0; q < GD_SPL; ++q)
+#pragma unroll
+        for (int k = 0; k < KP; ++k) SC[((int64_t)g * KP + k) * Tp + t0 + 64 * q] = acc[q][k];
 }
 
 // ------------------------------------------------------------------------------------------
 // weight gradient: GS[ts][i][j][k] = sum over the samples of split ts of C[k,t] (x_ti - x_tj)^2
-// (base_model.py:447 `self.coefficients_ @ sq_pdiffs`).  grid (n_pad / 64, n_pad / SW, TS).
+// (base_model.py:447 `self.coefficients_ @ sq_pdiffs`).  1-D grid over the compact list of
+// (row strip, column block) tasks that contain a pair i < j, times TS sample splits: workgroup ids
+// go round-robin to the 8 XCDs, so a 3-D grid with the dead below-diagonal blocks left in gives
+// XCD 7 2.4x the work of XCD 0 (measured: the kernel then runs as long as its slowest XCD).
 template <int KP, int SW>
-__global__ __launch_bounds__(64) void k_gd_grad_w(const double *__restrict__ X, const double *__restrict__ CT,
-                                                  double *__restrict__ GS, int n_pad, int Tp, int tchunk) {
-    const int lane = threadIdx.x;
-    const int jb = blockIdx.x, i0 = blockIdx.y * SW, ts = blockIdx.z;
-    if (jb * 64 + 63 <= i0) return;  // no pair with i < j in this block
+__global__ __launch_bounds__(256, 3) void k_gd_grad_w(const double *__restrict__ X, const double *__restrict__ CT,
+                                                   double *__restrict__ GS, const int2 *__restrict__ tasks, int ntasks,
+                                                   int n_pad, int Tp, int tchunk, int exp_, double *dbg) {
+    // the four waves of a workgroup take a quarter of the split's samples each and add their
+    // partial sums through LDS: finer tasks (even load per SIMD) without more slabs in HBM
+    __shared__ double2 s_red[3][KP / 2][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: keeps the operand loads scalar
+    const int2 task = tasks[blockIdx.x % ntasks];
+    const int jb = task.y, i0 = task.x * SW, ts = blockIdx.x / ntasks;
     const int j = jb * 64 + lane;
     double acc[SW][KP];
 #pragma unroll
     for (int a = 0; a < SW; ++a)
 #pragma unroll
         for (int k = 0; k < KP; ++k) acc[a][k] = 0.0;
-    const int tA = ts * tchunk, tB = min(Tp, tA + tchunk);
-#pragma unroll 2
-    for (int t = tA; t < tB; ++t) {
-        const double xj = X[(int64_t)t * n_pad + j];
-        const double *__restrict__ xr = X + (int64_t)t * n_pad + i0;  // wave-uniform
-        const double *__restrict__ cr = CT + (int64_t)t * KP;         // wave-uniform
+    const int tA0 = ts * tchunk, tB0 = min(Tp, tA0 + tchunk);
+    const int sub = (max(tB0 - tA0, 0) + 3) / 4;
+    const int tA = tA0 + wave * sub, tB = min(tB0, tA + sub);
+    const unsigned long long rt0 = (exp_ & 8) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    // Software pipeline over the samples: the wave-uniform operands of sample t + 1 (SW node values,
+    // KP coefficients: scalar loads, which return out of order and can only be waited for all
+    // together) are requested right after the wait for those of sample t and land while t computes.
+    // Two operand sets alternate (no register copies); sched_barrier keeps the requests ahead of
+    // the arithmetic (left alone, the scheduler sinks them into the middle of the FMA block).
+    if (tA < tB) {
+        double xiA[SW], cfA[KP], xjA, xiB[SW], cfB[KP], xjB;
+        auto request = [&](int t, double (&xi)[SW], double (&cf)[KP], double &xj) {
+            const int tc = t < tB ? t : tB - 1;
+            const double *__restrict__ xr = X + (int64_t)tc * n_pad + i0;  // wave-uniform
+            const double *__restrict__ cr = CT + (int64_t)tc * KP;         // wave-uniform
 #pragma unroll
-        for (int a = 0; a < SW; ++a) {
-            const double d = xr[a] - xj;
-            const double sq = d * d;
+            for (int a = 0; a < SW; ++a) xi[a] = xr[a];
 #pragma unroll
-            for (int k = 0; k < KP; ++k) acc[a][k] = __builtin_fma(cr[k], sq, acc[a][k]);
+            for (int k = 0; k < KP; ++k) cf[k] = cr[k];
+            xj = X[(int64_t)tc * n_pad + j];
+        };
+        auto accumulate = [&](const double (&xi)[SW], const double (&cf)[KP], const double xj) {
+#pragma unroll
+            for (int a = 0; a < SW; ++a) {
+                const double d = xi[a] - xj;
+                const double sq = d * d;
+#pragma unroll
+                for (int k = 0; k < KP; ++k) acc[a][k] = __builtin_fma(cf[k], sq, acc[a][k]);
+            }
+        };
+        request(tA, xiA, cfA, xjA);
+        int t = tA;
+        for (; t + 1 < tB; t += 2) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): set A is in
+            request(t + 1, xiB, cfB, xjB);
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate(xiA, cfA, xjA);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // set B is in
+            request(t + 2, xiA, cfA, xjA);
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate(xiB, cfB, xjB);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (t < tB) accumulate(xiA, cfA, xjA);
     }
+    if ((exp_ & 8) && lane == 0) {  // tuning aid: per-wave (start, end) in 10 ns ticks
+        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+        const int64_t w = (int64_t)blockIdx.x * 4 + wave;
+        dbg[4 * w + 0] = (double)rt0;
+        dbg[4 * w + 1] = (double)r1;
+        dbg[4 * w + 2] = (double)__builtin_amdgcn_s_getreg(63492);          // HW_REG_HW_ID
+        dbg[4 * w + 3] = (double)(__builtin_amdgcn_s_getreg(63508) & 15u);  // XCC_ID
+    }
+    // ((wave 0 + wave 1) + wave 2) + wave 3, one row of the strip at a time (12 KB of LDS)
 #pragma unroll
     for (int a = 0; a < SW; ++a) {
-        double *dst = GS + (((int64_t)ts * n_pad + (i0 + a)) * n_pad + j) * KP;
+        if (wave > 0) {
 #pragma unroll
-        for (int k = 0; k < KP; k += 2) *reinterpret_cast<double2 *>(dst + k) = double2{acc[a][k], acc[a][k + 1]};
+            for (int k = 0; k < KP; k += 2) s_red[wave - 1][k / 2][lane] = double2{acc[a][k], acc[a][k + 1]};
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int v = 0; v < 3; ++v)
+#pragma unroll
+                for (int k = 0; k < KP; k += 2) {
+                    const double2 p = s_red[v][k / 2][lane];
+                    acc[a][k] += p.x;
+                    acc[a][k + 1] += p.y;
+                }
+            double *dst = GS + (((int64_t)ts * n_pad + (i0 + a)) * n_pad + j) * KP;
+#pragma unroll
+            for (int k = 0; k < KP; k += 2) *reinterpret_cast<double2 *>(dst + k) = double2{acc[a][k], acc[a][k + 1]};
+        }
+        __syncthreads();
     }
 }
 
@@ -167,42 +267,51 @@ __global__ void k_gd_logc_reset(GdDev P) {
         }
 }
 
+// sum of the strip-group partials of k_gd_grad_c, fixed order: 4 interleaved partial sums per
+// element (threadIdx.y), then ((p0 + p1) + p2) + p3
+__global__ __launch_bounds__(256) void k_gd_sc_reduce(GdDev P) {
+    __shared__ double s_p[4][64];
+    const int64_t q = (int64_t)blockIdx.x * 64 + threadIdx.x;  // (k, t)
+    const int gy = threadIdx.y;
+    double v = 0.0;
+    if (q < (int64_t)P.KP * P.Tp) {
+#pragma unroll 8
+        for (int g = gy; g < P.NG; g += 4) v += P.SC[(int64_t)g * P.KP * P.Tp + q];
+    }
+    s_p[gy][threadIdx.x] = v;
+    __syncthreads();
+    if (gy == 0 && q < (int64_t)P.KP * P.Tp)
+        P.SCR[q] = ((s_p[0][threadIdx.x] + s_p[1][threadIdx.x]) + s_p[2][threadIdx.x]) + s_p[3][threadIdx.x];
+}
+
 // ------------------------------------------------------------------------------------------
 // coefficient update (base_model.py:373-401), one wave per window
-__global__ __launch_bounds__(64) void k_gd_coef_update(GdDev P, int use_sc) {
+template <int KP>
+__global__ __launch_bounds__(64) void k_gd_coef_update(GdDev P) {
     const int lane = threadIdx.x, tw = blockIdx.x;
-    const int K = P.K;
     // adjoint term  W @ (S' dual')  ==  <S W_k, dual_tw>   (log_model.py:33-34)
-    double dt[GD_MAXK];
-    for (int k = 0; k < K; ++k) dt[k] = 0.0;
+    double dt[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) dt[k] = 0.0;
     for (int i = lane; i < P.n; i += 64) {
         const double dv = P.dual[(int64_t)tw * P.n + i];
-        for (int k = 0; k < K; ++k) dt[k] += P.deg[(int64_t)k * P.n_pad + i] * dv;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) dt[k] += P.deg[(int64_t)k * P.n_pad + i] * dv;  // rows k >= K are zero
     }
-    for (int k = 0; k < K; ++k) dt[k] = gd_wave_sum(dt[k]);
-    // smoothness term: partial sums over the strip groups, mean over the window's samples (:375-379)
-    double sm[GD_MAXK];
-    for (int k = 0; k < K; ++k) {
-        double tot = 0.0;
-        for (int q = 0; q < P.W; ++q) {
-            const int64_t t = (int64_t)tw * P.W + q;
-            double v = 0.0;
-            for (int g = lane; g < P.NG; g += 64) v += P.SC[((int64_t)g * P.KP + k) * P.Tp + t];
-            tot += gd_wave_sum(v);
-        }
-        sm[k] = P.W > 1 ? tot / (double)P.W : tot;
-    }
-    (void)use_sc;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) dt[k] = gd_wave_sum(dt[k]);
+    // lane k finishes atom k
+    double dterm = 0.0;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) dterm = lane == k ? dt[k] : dterm;
     double cmax = 0.0;
-    if (lane < K) {
+    if (lane < P.K) {
         const int k = lane;
+        // smoothness term: mean over the window's samples (:375-379) of the summed strip-group partials
+        double tot = 0.0;
+        for (int q = 0; q < P.W; ++q) tot += P.SCR[(int64_t)k * P.Tp + (int64_t)tw * P.W + q];
+        double grad = P.W > 1 ? tot / (double)P.W : tot;
         const double *c = P.C + (int64_t)k * P.T;  // the window view is c[m * W]
-        double grad = 0.0, dterm = 0.0;
-        for (int q = 0; q < K; ++q)  // select without dynamic register indexing
-            if (q == k) {
-                grad = sm[q];
-                dterm = dt[q];
-            }
         grad += P.l1_c * (double)P.T;
         if (P.l1_diff_c > 0) {  // :389-394, diff(sign(diff(c)), prepend=0, append=0)[tw]
             auto sgn = [](double v) { return v > 0 ? 1.0 : (v < 0 ? -1.0 : 0.0); };
@@ -220,9 +329,9 @@ __global__ __launch_bounds__(64) void k_gd_coef_update(GdDev P, int use_sc) {
     if (lane == 0) P.cpart[tw] = cmax;
 }
 
-// all-zero guard (:406-408) and the relative change of the coefficients (:516); one workgroup
+// all-zero guard (:406-408); one workgroup
 __global__ __launch_bounds__(256) void k_gd_coef_finish(GdDev P) {
-    __shared__ double s_a[256], s_b[256], s_c[256];
+    __shared__ double s_a[256];
     const int tid = threadIdx.x;
     double mx = 0.0;
     for (int tw = tid; tw < P.Tw; tw += 256) mx = fmax(mx, P.cpart[tw]);
@@ -232,35 +341,10 @@ __global__ __launch_bounds__(256) void k_gd_coef_finish(GdDev P) {
         if (tid < o) s_a[tid] = fmax(s_a[tid], s_a[tid + o]);
         __syncthreads();
     }
-    const bool all_zero = s_a[0] <= 1e-8;  // np.allclose(c, 0)
-    __syncthreads();
-    if (all_zero) {
-        for (int64_t q = tid; q < (int64_t)P.K * P.Tw; q += 256) P.Cw[(q / P.Tw) * P.Tw + q % P.Tw] = P.log_c;
+    if (s_a[0] <= 1e-8) {  // np.allclose(c, 0)
+        for (int64_t q = tid; q < (int64_t)P.K * P.Tw; q += 256) P.Cw[q] = P.log_c;
         if (tid == 0) P.stat[2] = 1.0;
     }
-    __syncthreads();
-    // relative_error(coefficients_.ravel(), new.ravel()): ||new - old|| / ||old||, plain norm if old ~ 0
-    double num = 0, den = 0, omax = 0;
-    for (int64_t q = tid; q < (int64_t)P.K * P.T; q += 256) {
-        const int64_t k = q / P.T, t = q % P.T;
-        const double o = P.C[q], nw = P.Cw[k * P.Tw + t / P.W];
-        num += (nw - o) * (nw - o);
-        den += o * o;
-        omax = fmax(omax, fabs(o));
-    }
-    s_a[tid] = num;
-    s_b[tid] = den;
-    s_c[tid] = omax;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) {
-            s_a[tid] += s_a[tid + o];
-            s_b[tid] += s_b[tid + o];
-            s_c[tid] = fmax(s_c[tid], s_c[tid + o]);
-        }
-        __syncthreads();
-    }
-    if (tid == 0) P.stat[0] = s_c[0] <= 1e-8 ? sqrt(s_a[0]) : sqrt(s_a[0]) / sqrt(s_b[0]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -277,40 +361,67 @@ __global__ __launch_bounds__(64) void k_gd_m(GdDev P, int tchunk) {
         }
     for (int k = 0; k < P.K; ++k) P.MSL[((int64_t)ms * P.KP + k) * P.n_pad + i] = i < P.n ? acc[k] : 0.0;
 }
-__global__ void k_gd_m_reduce(GdDev P) {
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= (int64_t)P.KP * P.n_pad) return;
+__global__ __launch_bounds__(256) void k_gd_m_reduce(GdDev P) {
+    __shared__ double s_p[4][64];
+    const int64_t q = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int gy = threadIdx.y;
     double v = 0.0;
-    for (int ms = 0; ms < P.MS; ++ms) v += P.MSL[(int64_t)ms * P.KP * P.n_pad + q];
-    P.M[q] = v;
+    if (q < (int64_t)P.KP * P.n_pad) {
+#pragma unroll 8
+        for (int ms = gy; ms < P.MS; ms += 4) v += P.MSL[(int64_t)ms * P.KP * P.n_pad + q];
+    }
+    s_p[gy][threadIdx.x] = v;
+    __syncthreads();
+    if (gy == 0 && q < (int64_t)P.KP * P.n_pad)
+        P.M[q] = ((s_p[0][threadIdx.x] + s_p[1][threadIdx.x]) + s_p[2][threadIdx.x]) + s_p[3][threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------
 // weight update (base_model.py:444-461): one wave per (row i, column block); in place
+template <int KP>
 __global__ __launch_bounds__(64) void k_gd_weight_update(GdDev P) {
     const int lane = threadIdx.x, jb = blockIdx.x, i = blockIdx.y;
     const int nbj = gridDim.x;
     const int j = jb * 64 + lane;
     double num = 0, den = 0, wmax = 0;
     if (jb * 64 + 63 > i && j > i && j < P.n) {
-        double *w = P.WS + ((int64_t)i * P.n_pad + j) * P.KP;
-        double wsum = 0.0;
-        for (int k = 0; k < P.K; ++k) wsum += w[k];
-        const double Tn = (double)P.T;
-        for (int k = 0; k < P.K; ++k) {
-            double g = 0.0;
-            for (int ts = 0; ts < P.TS; ++ts) g += P.GS[(((int64_t)ts * P.n_pad + i) * P.n_pad + j) * P.KP + k];
-            g += P.l1_w * Tn;                                                   // :448
-            const double wo = w[k];
-            if (P.ortho_w > 0) g += P.ortho_w * Tn * (wsum - wo);               // :450-451
-            const double dterm = P.M[(int64_t)k * P.n_pad + i] + P.M[(int64_t)k * P.n_pad + j];
-            double wn = wo - P.step_w / Tn * (dterm + g);                       // :456
-            wn = wn < 0 ? 0.0 : wn;                                             // :459
-            w[k] = wn;
-            num += (wn - wo) * (wn - wo);
-            den += wo * wo;
-            wmax = fmax(wmax, fabs(wo));
+        double *w = P.WS + ((int64_t)i * P.n_pad + j) * KP;
+        double wo[KP], g[KP];
+#pragma unroll
+        for (int k = 0; k < KP; k += 2) {  // 16-byte accesses: a lane owns KP contiguous doubles
+            const double2 v = *reinterpret_cast<const double2 *>(w + k);
+            wo[k] = v.x, wo[k + 1] = v.y;
+            g[k] = g[k + 1] = 0.0;
         }
+        for (int ts = 0; ts < P.TS; ++ts) {
+            const double *gp = P.GS + (((int64_t)ts * P.n_pad + i) * P.n_pad + j) * KP;
+#pragma unroll
+            for (int k = 0; k < KP; k += 2) {
+                const double2 v = *reinterpret_cast<const double2 *>(gp + k);
+                g[k] += v.x, g[k + 1] += v.y;
+            }
+        }
+        double wsum = 0.0;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) wsum += k < P.K ? wo[k] : 0.0;
+        const double Tn = (double)P.T;
+        double wn[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            double gk = g[k] + P.l1_w * Tn;                                       // :448
+            if (P.ortho_w > 0) gk += P.ortho_w * Tn * (wsum - wo[k]);             // :450-451
+            const double dterm = P.M[(int64_t)k * P.n_pad + i] + P.M[(int64_t)k * P.n_pad + j];
+            double v = wo[k] - P.step_w / Tn * (dterm + gk);                      // :456
+            v = v < 0 ? 0.0 : v;                                                  // :459
+            wn[k] = k < P.K ? v : 0.0;
+            if (k < P.K) {
+                num += (v - wo[k]) * (v - wo[k]);
+                den += wo[k] * wo[k];
+                wmax = fmax(wmax, fabs(wo[k]));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KP; k += 2) *reinterpret_cast<double2 *>(w + k) = double2{wn[k], wn[k + 1]};
     }
     num = gd_wave_sum(num);
     den = gd_wave_sum(den);
@@ -323,11 +434,11 @@ __global__ __launch_bounds__(64) void k_gd_weight_update(GdDev P) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_gd_weight_finish(GdDev P, int64_t nparts) {
-    __shared__ double s_a[256], s_b[256], s_c[256];
+__global__ __launch_bounds__(1024) void k_gd_weight_finish(GdDev P, int64_t nparts) {
+    __shared__ double s_a[1024], s_b[1024], s_c[1024];
     const int tid = threadIdx.x;
     double num = 0, den = 0, mx = 0;
-    for (int64_t q = tid; q < nparts; q += 256) {
+    for (int64_t q = tid; q < nparts; q += 1024) {
         num += P.wpart[3 * q];
         den += P.wpart[3 * q + 1];
         mx = fmax(mx, P.wpart[3 * q + 2]);
@@ -336,7 +447,7 @@ __global__ __launch_bounds__(256) void k_gd_weight_finish(GdDev P, int64_t npart
     s_b[tid] = den;
     s_c[tid] = mx;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if (tid < o) {
             s_a[tid] += s_a[tid + o];
             s_b[tid] += s_b[tid + o];
@@ -367,41 +478,77 @@ __global__ __launch_bounds__(64) void k_gd_degree(GdDev P, double *__restrict__ 
 // ------------------------------------------------------------------------------------------
 // dual update (log_model.py:39-50) with the overshoot 2 new - old of weights and coefficients
 // (base_model.py:509-514).  fixed_weights: predict() passes the weights themselves (:665-669).
+template <int KP>
 __global__ void k_gd_dual_update(GdDev P, int fixed_weights) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, tw = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
-    double step = 0.0;
-    for (int k = 0; k < P.K; ++k) {
+    double dv[KP];  // overshoot degrees of node i, shared by the 8 windows of this thread
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
         const double dn = P.deg_new[(int64_t)k * P.n_pad + i], dold = P.deg[(int64_t)k * P.n_pad + i];
-        const double dv = fixed_weights ? dold : 2.0 * dn - dold;
-        const double cv = 2.0 * P.Cw[(int64_t)k * P.Tw + tw] - P.C[(int64_t)k * P.T + (int64_t)tw * P.W];
-        step += dv * cv;
+        dv[k] = fixed_weights ? dold : 2.0 * dn - dold;
     }
     const double sigma = P.step_dual;
-    double d = P.dual[(int64_t)tw * P.n + i] + sigma * step;
-    P.dual[(int64_t)tw * P.n + i] = (d - sqrt(d * d + 4.0 * sigma)) / 2.0;
+    for (int tw = blockIdx.y * 8; tw < min(P.Tw, (int)blockIdx.y * 8 + 8); ++tw) {
+        double step = 0.0;
+#pragma unroll
+        for (int k = 0; k < KP; ++k)
+            if (k < P.K) step += dv[k] * (2.0 * P.Cw[(int64_t)k * P.Tw + tw] - P.C[(int64_t)k * P.T + (int64_t)tw * P.W]);
+        const double d = P.dual[(int64_t)tw * P.n + i] + sigma * step;
+        P.dual[(int64_t)tw * P.n + i] = (d - sqrt(d * d + 4.0 * sigma)) / 2.0;
+    }
 }
 
-// coefficients_ <- repeat(new window coefficients) (base_model.py:495-501,519); predict's stopping
-// norm ||new - old|| (:671) goes to stat[3]
+// coefficients_ <- repeat(new window coefficients) (base_model.py:495-501,519) and the partial sums
+// of relative_error(coefficients_.ravel(), new.ravel()) (:516); grid of <= 256 workgroups
 __global__ __launch_bounds__(256) void k_gd_coef_commit(GdDev P) {
-    __shared__ double s_a[256];
+    __shared__ double s_a[256], s_b[256], s_c[256];
     const int tid = threadIdx.x;
-    double num = 0.0;
+    double num = 0.0, den = 0.0, omax = 0.0;
     for (int64_t q = (int64_t)blockIdx.x * 256 + tid; q < (int64_t)P.K * P.T; q += (int64_t)gridDim.x * 256) {
         const int64_t k = q / P.T, t = q % P.T;
         const double nw = P.Cw[k * P.Tw + t / P.W], o = P.C[q];
         num += (nw - o) * (nw - o);
+        den += o * o;
+        omax = fmax(omax, fabs(o));
         P.C[q] = nw;
         P.CT[t * P.KP + k] = nw;
     }
     s_a[tid] = num;
+    s_b[tid] = den;
+    s_c[tid] = omax;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) s_a[tid] += s_a[tid + o];
+        if (tid < o) {
+            s_a[tid] += s_a[tid + o];
+            s_b[tid] += s_b[tid + o];
+            s_c[tid] = fmax(s_c[tid], s_c[tid + o]);
+        }
         __syncthreads();
     }
-    if (tid == 0) P.stat[3] = sqrt(s_a[0]);  // single workgroup launch
+    if (tid == 0) {
+        P.cnorm[3 * blockIdx.x] = s_a[0];
+        P.cnorm[3 * blockIdx.x + 1] = s_b[0];
+        P.cnorm[3 * blockIdx.x + 2] = s_c[0];
+    }
+}
+// stat[0] = relative change of the coefficients (plain norm if the old ones were ~ 0, evaluation.py:21-23),
+// stat[3] = ||new - old|| (predict's stopping norm, base_model.py:671)
+__global__ __launch_bounds__(64) void k_gd_coef_stat(GdDev P, int nblocks) {
+    const int lane = threadIdx.x;
+    double num = 0, den = 0, omax = 0;
+    for (int b = lane; b < nblocks; b += 64) {
+        num += P.cnorm[3 * b];
+        den += P.cnorm[3 * b + 1];
+        omax = fmax(omax, P.cnorm[3 * b + 2]);
+    }
+    num = gd_wave_sum(num);
+    den = gd_wave_sum(den);
+    omax = gd_wave_max(omax);
+    if (lane == 0) {
+        P.stat[0] = omax <= 1e-8 ? sqrt(num) : sqrt(num) / sqrt(den);
+        P.stat[3] = sqrt(num);
+    }
 }
 
 // ---- layout kernels --------------------------------------------------------------------------
@@ -446,6 +593,7 @@ struct gl_graphdict {
     double *stage = nullptr;  // device staging for host <-> device transfers of W (K x E) / x (T x n)
     size_t stage_elems = 0;
     bool have_x = false, have_state = false;
+    double *dbgbuf = nullptr;  // tuning aid (GD_EXP & 8): 4 doubles per wave of k_gd_grad_w
     std::vector<void *> allocs;
 };
 
@@ -470,25 +618,43 @@ int gd_launch_grad_c(gl_graphdict *s) {
     dim3 grid((unsigned)(P.Tp / GD_SB), (unsigned)P.NG);
     hipStream_t st = s->ctx->stream;
     switch (P.KP) {
-        case 4: k_gd_grad_c<4><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG); break;
-        case 8: k_gd_grad_c<8><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG); break;
-        default: k_gd_grad_c<16><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG); break;
+        case 4: k_gd_grad_c<4, 2><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG); break;
+        case 8: k_gd_grad_c<8, 2><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG); break;
+        default: k_gd_grad_c<16, 1><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG); break;
     }
     GL_HIP(s->ctx, hipGetLastError());
     return GL_OK;
 }
 
 int gd_strip_w(int KP) { return KP <= 8 ? 8 : 4; }
+void gd_launch_dual_update(const GdDev &P, hipStream_t st, int fixed) {
+    const dim3 grid((unsigned)((P.n + 255) / 256), (unsigned)((P.Tw + 7) / 8));
+    switch (P.KP) {
+        case 4: k_gd_dual_update<4><<<grid, 256, 0, st>>>(P, fixed); break;
+        case 8: k_gd_dual_update<8><<<grid, 256, 0, st>>>(P, fixed); break;
+        default: k_gd_dual_update<16><<<grid, 256, 0, st>>>(P, fixed); break;
+    }
+}
+void gd_launch_coef_update(const GdDev &P, hipStream_t st) {
+    switch (P.KP) {
+        case 4: k_gd_coef_update<4><<<dim3((unsigned)P.Tw), 64, 0, st>>>(P); break;
+        case 8: k_gd_coef_update<8><<<dim3((unsigned)P.Tw), 64, 0, st>>>(P); break;
+        default: k_gd_coef_update<16><<<dim3((unsigned)P.Tw), 64, 0, st>>>(P); break;
+    }
+}
+int gd_commit_blocks(const GdDev &P) { return (int)std::max<int64_t>(1, std::min<int64_t>(256, ((int64_t)P.K * P.T + 1023) / 1024)); }
 
 int gd_launch_grad_w(gl_graphdict *s) {
     const GdDev &P = s->dev;
     const int tchunk = (P.Tp + P.TS - 1) / P.TS;
     hipStream_t st = s->ctx->stream;
-    dim3 grid((unsigned)(P.n_pad / 64), (unsigned)(P.n_pad / gd_strip_w(P.KP)), (unsigned)P.TS);
+    int ex = getenv("GD_EXP") ? atoi(getenv("GD_EXP")) : 0;
+    if (!s->dbgbuf) ex &= ~8;
+    dim3 grid((unsigned)(P.nwtasks * P.TS));
     switch (P.KP) {
-        case 4: k_gd_grad_w<4, 8><<<grid, 64, 0, st>>>(P.X, P.CT, P.GS, P.n_pad, P.Tp, tchunk); break;
-        case 8: k_gd_grad_w<8, 8><<<grid, 64, 0, st>>>(P.X, P.CT, P.GS, P.n_pad, P.Tp, tchunk); break;
-        default: k_gd_grad_w<16, 4><<<grid, 64, 0, st>>>(P.X, P.CT, P.GS, P.n_pad, P.Tp, tchunk); break;
+        case 4: k_gd_grad_w<4, 8><<<grid, 256, 0, st>>>(P.X, P.CT, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, ex, s->dbgbuf); break;
+        case 8: k_gd_grad_w<8, 8><<<grid, 256, 0, st>>>(P.X, P.CT, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, ex, s->dbgbuf); break;
+        default: k_gd_grad_w<16, 4><<<grid, 256, 0, st>>>(P.X, P.CT, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, ex, s->dbgbuf); break;
     }
     GL_HIP(s->ctx, hipGetLastError());
     return GL_OK;
@@ -508,17 +674,24 @@ int gd_step(gl_graphdict *s) {
     if (P.log_c > 0) k_gd_logc_reset<<<dim3((unsigned)((P.Tw + 255) / 256)), 256, 0, st>>>(P);
     GL_TRY(gd_launch_grad_c(s));
     GL_TRY(gd_launch_grad_w(s));
-    k_gd_coef_update<<<dim3((unsigned)P.Tw), 64, 0, st>>>(P, 1);
+    k_gd_sc_reduce<<<dim3((unsigned)(((int64_t)P.KP * P.Tp + 63) / 64)), dim3(64, 4), 0, st>>>(P);
+    gd_launch_coef_update(P, st);
     k_gd_coef_finish<<<1, 256, 0, st>>>(P);
     const int mchunk = (P.T + P.MS - 1) / P.MS;
     k_gd_m<<<dim3((unsigned)(P.n_pad / 64), (unsigned)P.MS), 64, 0, st>>>(P, mchunk);
-    k_gd_m_reduce<<<dim3((unsigned)(((int64_t)P.KP * P.n_pad + 255) / 256)), 256, 0, st>>>(P);
+    k_gd_m_reduce<<<dim3((unsigned)(((int64_t)P.KP * P.n_pad + 63) / 64)), dim3(64, 4), 0, st>>>(P);
     const int nbj = P.n_pad / 64;
-    k_gd_weight_update<<<dim3((unsigned)nbj, (unsigned)P.n), 64, 0, st>>>(P);
-    k_gd_weight_finish<<<1, 256, 0, st>>>(P, (int64_t)P.n * nbj);
+    switch (P.KP) {
+        case 4: k_gd_weight_update<4><<<dim3((unsigned)nbj, (unsigned)P.n), 64, 0, st>>>(P); break;
+        case 8: k_gd_weight_update<8><<<dim3((unsigned)nbj, (unsigned)P.n), 64, 0, st>>>(P); break;
+        default: k_gd_weight_update<16><<<dim3((unsigned)nbj, (unsigned)P.n), 64, 0, st>>>(P); break;
+    }
+    k_gd_weight_finish<<<1, 1024, 0, st>>>(P, (int64_t)P.n * nbj);
     GL_TRY(gd_degrees(s, P.deg_new));
-    k_gd_dual_update<<<dim3((unsigned)((P.n + 255) / 256), (unsigned)P.Tw), 256, 0, st>>>(P, 0);
-    k_gd_coef_commit<<<1, 256, 0, st>>>(P);
+    gd_launch_dual_update(P, st, 0);
+    const int cb = gd_commit_blocks(P);
+    k_gd_coef_commit<<<dim3((unsigned)cb), 256, 0, st>>>(P);
+    k_gd_coef_stat<<<1, 64, 0, st>>>(P, cb);
     GL_HIP(ctx, hipGetLastError());
     std::swap(P.deg, P.deg_new);
     return GL_OK;
@@ -551,12 +724,22 @@ GL_API int gl_graphdict_create(gl_ctx *ctx, int64_t n_nodes, int64_t n_samples, 
     P.K = n_atoms;
     P.KP = n_atoms <= 4 ? 4 : (n_atoms <= 8 ? 8 : 16);
     // enough waves to fill 256 CUs x 4 SIMDs a few times over, slabs kept small
-    const int nstrips = (P.n + 3) / 4;
+    const int nstrips = (P.n + gd_rows_c(P.KP) - 1) / gd_rows_c(P.KP);
     const int sblocks = P.Tp / GD_SB;
-    P.NG = std::max(1, std::min(nstrips, std::min(128, (4096 + sblocks - 1) / sblocks)));
-    const int64_t wtasks = (int64_t)(P.n_pad / 64) * (P.n_pad / gd_strip_w(P.KP)) / 2 + 1;
-    P.TS = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, (P.Tp + 255) / 256), (4096 + wtasks - 1) / wtasks));
-    P.MS = std::max(1, std::min(32, P.T / 64));
+    P.NG = std::max(1, std::min(nstrips, std::min(512, (8192 + sblocks - 1) / sblocks)));
+    std::vector<int2> tasks;
+    {
+        const int sw = gd_strip_w(P.KP);
+        for (int st = 0; st < P.n_pad / sw; ++st)
+            for (int jb = 0; jb < P.n_pad / 64; ++jb)
+                if (jb * 64 + 63 > st * sw && st * sw < P.n) tasks.push_back(int2{st, jb});
+    }
+    P.nwtasks = (int)tasks.size();
+    const int64_t wtasks = P.nwtasks;
+    P.TS = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, (P.Tp + 511) / 512), (3072 + wtasks - 1) / wtasks));
+    if (const char *e = getenv("GRAPHLEARN_AMD_GD_TS")) P.TS = std::max(1, std::min(64, atoi(e)));  // tuning aid
+    if (const char *e = getenv("GRAPHLEARN_AMD_GD_NG")) P.NG = std::max(1, std::min(nstrips, atoi(e)));
+    P.MS = std::max(1, std::min(128, P.T / 32));
     int rc = GL_OK;
     const size_t np2 = (size_t)P.n_pad * P.n_pad;
     if ((rc = gd_alloc(s, &P.X, (size_t)P.Tp * P.n_pad)) || (rc = gd_alloc(s, &P.XT, (size_t)P.n_pad * P.Tp)) ||
@@ -564,6 +747,7 @@ GL_API int gl_graphdict_create(gl_ctx *ctx, int64_t n_nodes, int64_t n_samples, 
         (rc = gd_alloc(s, &P.CT, (size_t)P.Tp * P.KP)) || (rc = gd_alloc(s, &P.Cw, (size_t)P.KP * P.Tw)) ||
         (rc = gd_alloc(s, &P.dual, (size_t)P.Tw * P.n)) || (rc = gd_alloc(s, &P.deg, (size_t)P.KP * P.n_pad)) ||
         (rc = gd_alloc(s, &P.deg_new, (size_t)P.KP * P.n_pad)) || (rc = gd_alloc(s, &P.SC, (size_t)P.NG * P.KP * P.Tp)) ||
+        (rc = gd_alloc(s, &P.SCR, (size_t)P.KP * P.Tp)) || (rc = gd_alloc(s, &P.wtasks, tasks.size())) || (rc = gd_alloc(s, &P.cnorm, 256 * 3)) ||
         (rc = gd_alloc(s, &P.GS, (size_t)P.TS * np2 * P.KP)) || (rc = gd_alloc(s, &P.MSL, (size_t)P.MS * P.KP * P.n_pad)) ||
         (rc = gd_alloc(s, &P.M, (size_t)P.KP * P.n_pad)) || (rc = gd_alloc(s, &P.cpart, (size_t)P.Tw)) ||
         (rc = gd_alloc(s, &P.wpart, (size_t)P.n * (P.n_pad / 64) * 3)) || (rc = gd_alloc(s, &P.stat, GD_NORM_SLOTS))) {
@@ -577,6 +761,9 @@ GL_API int gl_graphdict_create(gl_ctx *ctx, int64_t n_nodes, int64_t n_samples, 
         delete s;
         return rc;
     }
+    GL_HIP(ctx, hipMemcpyAsync(P.wtasks, tasks.data(), tasks.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    if (getenv("GD_EXP") && (atoi(getenv("GD_EXP")) & 8))
+        (void)gd_alloc(s, &s->dbgbuf, (size_t)16 * P.nwtasks * P.TS);
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out = s;
     return GL_OK;
@@ -730,15 +917,18 @@ GL_API int gl_graphdict_predict(gl_graphdict *s, int64_t max_iter, double tol, d
     double *st = (double *)ctx->pinned;
     GL_HIP(ctx, hipMemsetAsync(P.dual, 0, (size_t)P.Tw * P.n * 8, st_));
     GL_TRY(gd_launch_grad_c(s));  // the weights never change: one pass over the pairs
+    k_gd_sc_reduce<<<dim3((unsigned)(((int64_t)P.KP * P.Tp + 63) / 64)), dim3(64, 4), 0, st_>>>(P);
     int flags = 0;
     int64_t i = 0;
     for (i = 0; i < max_iter; ++i) {
         GL_HIP(ctx, hipMemsetAsync(P.stat + 2, 0, 8, st_));
         if (P.log_c > 0) k_gd_logc_reset<<<dim3((unsigned)((P.Tw + 255) / 256)), 256, 0, st_>>>(P);
-        k_gd_coef_update<<<dim3((unsigned)P.Tw), 64, 0, st_>>>(P, 1);
+        gd_launch_coef_update(P, st_);
         k_gd_coef_finish<<<1, 256, 0, st_>>>(P);
-        k_gd_dual_update<<<dim3((unsigned)((P.n + 255) / 256), (unsigned)P.Tw), 256, 0, st_>>>(P, 1);
-        k_gd_coef_commit<<<1, 256, 0, st_>>>(P);
+        gd_launch_dual_update(P, st_, 1);
+        const int cb = gd_commit_blocks(P);
+        k_gd_coef_commit<<<dim3((unsigned)cb), 256, 0, st_>>>(P);
+        k_gd_coef_stat<<<1, 64, 0, st_>>>(P, cb);
         GL_HIP(ctx, hipGetLastError());
         GL_HIP(ctx, hipMemcpyAsync(st, P.stat, 4 * 8, hipMemcpyDeviceToHost, st_));
         GL_HIP(ctx, hipStreamSynchronize(st_));
@@ -772,6 +962,43 @@ GL_API int gl_graphdict_time_gradients(gl_graphdict *s, int reps, double *grad_c
         GL_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         double *o = which ? grad_w_us_out : grad_c_us_out;
         if (o) *o = (double)ms * 1e3 / reps;
+        if (which && s->dbgbuf) {
+            const GdDev &P = s->dev;
+            const size_t nw = (size_t)P.nwtasks * P.TS * 4;
+            std::vector<double> d(4 * nw);
+            (void)hipMemcpy(d.data(), s->dbgbuf, d.size() * 8, hipMemcpyDeviceToHost);
+            double t0 = 1e300, t1 = 0, dur = 0;
+            size_t cnt = 0;
+            for (size_t w = 0; w < nw; ++w)
+                if (d[4 * w + 1] > 0) t0 = std::min(t0, d[4 * w]), t1 = std::max(t1, d[4 * w + 1]), dur += d[4 * w + 1] - d[4 * w], ++cnt;
+            int nb8 = 0, nbc8 = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb8, k_gd_grad_w<8, 8>, 256, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbc8, k_gd_grad_c<8, 2>, 64, 0);
+            fprintf(stderr, "[grad_w probe] runtime occupancy: grad_w<8,8> %d workgroups/CU, grad_c<8> %d\n", nb8, nbc8);
+            fprintf(stderr, "[grad_w probe] %zu waves, span %.1f us, mean wave %.1f us\n", cnt, (t1 - t0) / 100, dur / cnt / 100);
+            // concurrency over time (20 buckets) and waves per (xcc, cu, simd) slot
+            int hist[20] = {0};
+            for (size_t w = 0; w < nw; ++w)
+                if (d[4 * w + 1] > 0)
+                    for (int b = 0; b < 20; ++b) {
+                        const double tb = t0 + (t1 - t0) * (b + 0.5) / 20;
+                        if (d[4 * w] <= tb && tb < d[4 * w + 1]) ++hist[b];
+                    }
+            fprintf(stderr, "[grad_w probe] resident waves over time:");
+            for (int b = 0; b < 20; ++b) fprintf(stderr, " %d", hist[b]);
+            fprintf(stderr, "\n");
+            std::vector<int> per(8 * 4096, 0);
+            for (size_t w = 0; w < nw; ++w)
+                if (d[4 * w + 1] > 0) {
+                    const unsigned hw = (unsigned)d[4 * w + 2];
+                    const unsigned simd = (hw >> 4) & 3, cu = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
+                    per[(size_t)d[4 * w + 3] * 4096 + ((se * 2 + sh) * 16 + cu) * 4 + simd]++;
+                }
+            int used = 0, mx = 0, mn = 1 << 30;
+            for (int v : per)
+                if (v) ++used, mx = std::max(mx, v), mn = std::min(mn, v);
+            fprintf(stderr, "[grad_w probe] distinct (xcc, se, sh, cu, simd) slots used %d, waves per slot min %d max %d\n", used, mn, mx);
+        }
     }
     return GL_OK;
 }
