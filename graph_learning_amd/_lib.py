@@ -72,6 +72,7 @@ SIGNATURES = {
     "gl_laplacian_adjoint": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     "gl_squared_pdiffs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "gl_theta_from_distances": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, _c_double_p]),
+    "gl_theta_from_matrix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _c_double_p]),
     "gl_relative_error": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, _c_double_p]),
     "gl_nonneg_qp_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int,
                                      C.c_void_p, _c_int_p]),

@@ -63,6 +63,8 @@ int gl_gram_distances(gl_ctx *ctx, const double *x_dev, int64_t d, int64_t n, do
 // gl_theta.hip
 int gl_theta_from_square(gl_ctx *ctx, const double *zsq_dev, int64_t n, int k, double *terms_dev,
                          double *theta_out);
+int gl_theta_from_rows(gl_ctx *ctx, const double *zsq_dev, int64_t rows, int64_t cols, int k, double *terms_dev,
+                       double *theta_out);
 // gl_resident.hip
 int gl_resident_prepare(gl_logdeg *s);
 void gl_resident_free(gl_logdeg *s);

@@ -141,3 +141,16 @@ GL_API int gl_theta_from_distances(gl_ctx *ctx, const double *zsq, int64_t n, in
     GL_HIP(ctx, hipMemcpyAsync(dz.p, zsq, (size_t)n * n * 8, hipMemcpyHostToDevice, ctx->stream));
     return gl_theta_from_square(ctx, dz.p, n, avg_degree, dt.p, theta_out);
 }
+
+GL_API int gl_theta_from_matrix(gl_ctx *ctx, const double *zsq, int64_t rows, int64_t cols, int avg_degree,
+                                double *theta_out) {
+    if (!ctx) return GL_E_INVALID;
+    if (!zsq || !theta_out) return gl_set_error(ctx, GL_E_INVALID, "NULL buffer");
+    if (rows < 1 || cols < 2) return gl_set_error(ctx, GL_E_INVALID, "need rows >= 1 and cols >= 2");
+    GL_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf dz, dt;
+    GL_HIP(ctx, hipMalloc((void **)&dz.p, (size_t)rows * cols * 8));
+    GL_HIP(ctx, hipMalloc((void **)&dt.p, (size_t)2 * rows * 8));
+    GL_HIP(ctx, hipMemcpyAsync(dz.p, zsq, (size_t)rows * cols * 8, hipMemcpyHostToDevice, ctx->stream));
+    return gl_theta_from_rows(ctx, dz.p, rows, cols, avg_degree, dt.p, theta_out);
+}

@@ -24,8 +24,9 @@ __device__ __forceinline__ double value_of(unsigned long long key) {
     return __longlong_as_double((long long)u);
 }
 
+// one workgroup per row; rows of length n; terms[row] and terms[rows + row]
 __global__ __launch_bounds__(256) void k_theta_rows(const double *__restrict__ zsq, int64_t n, int k,
-                                                    double *__restrict__ terms) {
+                                                    double *__restrict__ terms, int64_t rows) {
     __shared__ unsigned s_hist[256];
     __shared__ unsigned long long s_prefix;
     __shared__ unsigned s_rank;
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void k_theta_rows(const double *__restrict__ z
         const double vkm1 = (below >= (unsigned)k) ? s_max[0] : vk;
         const double kk = (double)k;
         terms[blockIdx.x] = pow(kk * (vk * vk) - head * vk, -0.5);
-        terms[n + blockIdx.x] = pow(kk * (vkm1 * vkm1) - head * vkm1, -0.5);
+        terms[rows + blockIdx.x] = pow(kk * (vkm1 * vkm1) - head * vkm1, -0.5);
     }
 }
 
@@ -108,16 +109,23 @@ double pairwise_sum(const double *a, int64_t n) {
 
 }  // namespace
 
-int gl_theta_from_square(gl_ctx *ctx, const double *zsq_dev, int64_t n, int k, double *terms_dev,
-                         double *theta_out) {
-    if (k < 1 || k >= n) return gl_set_error(ctx, GL_E_INVALID, "avg_degree must be in [1, n-1], got %d", k);
-    k_theta_rows<<<dim3((unsigned)n), dim3(256), 0, ctx->stream>>>(zsq_dev, n, k, terms_dev);
+// rows x cols matrix (the square n x n case of LogModel, or a block of it: get_theta's blocks branch,
+// smooth_learning.py:220-235, calls the plain branch on rectangular sub-matrices)
+int gl_theta_from_rows(gl_ctx *ctx, const double *zsq_dev, int64_t rows, int64_t cols, int k, double *terms_dev,
+                       double *theta_out) {
+    if (k < 1 || k >= cols) return gl_set_error(ctx, GL_E_INVALID, "avg_degree must be in [1, %lld], got %d", (long long)cols - 1, k);
+    k_theta_rows<<<dim3((unsigned)rows), dim3(256), 0, ctx->stream>>>(zsq_dev, cols, k, terms_dev, rows);
     GL_HIP(ctx, hipGetLastError());
-    std::vector<double> host((size_t)2 * n);
-    GL_HIP(ctx, hipMemcpyAsync(host.data(), terms_dev, (size_t)2 * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<double> host((size_t)2 * rows);
+    GL_HIP(ctx, hipMemcpyAsync(host.data(), terms_dev, (size_t)2 * rows * 8, hipMemcpyDeviceToHost, ctx->stream));
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const double lo = pairwise_sum(host.data(), n) / (double)n;
-    const double hi = pairwise_sum(host.data() + n, n) / (double)n;
+    const double lo = pairwise_sum(host.data(), rows) / (double)rows;
+    const double hi = pairwise_sum(host.data() + rows, rows) / (double)rows;
     *theta_out = sqrt(lo * hi);
     return GL_OK;
+}
+
+int gl_theta_from_square(gl_ctx *ctx, const double *zsq_dev, int64_t n, int k, double *terms_dev,
+                         double *theta_out) {
+    return gl_theta_from_rows(ctx, zsq_dev, n, n, k, terms_dev, theta_out);
 }

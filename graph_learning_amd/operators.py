@@ -102,9 +102,13 @@ def squared_pdiffs(x, *, ctx=None) -> np.ndarray:
 
 
 def theta_from_square(sq_pdists, avg_degree: int, *, ctx=None) -> float:
+    """get_theta, plain branch, on a (rows, cols) matrix of squared distances (square for LogModel,
+    rectangular for the block pairs of the blocks branch)."""
     sq = _lib.as_f64(sq_pdists)
+    if sq.ndim != 2:
+        raise ValueError(f"sq_pdists must be a matrix, got shape {sq.shape}")
     theta = C.c_double(0.0)
     c = _ctx(ctx)
-    c.check(c._lib.gl_theta_from_distances(c.handle, _lib.ptr(sq), sq.shape[0], int(avg_degree), C.byref(theta)),
-            "get_theta")
+    c.check(c._lib.gl_theta_from_matrix(c.handle, _lib.ptr(sq), sq.shape[0], sq.shape[1], int(avg_degree),
+                                        C.byref(theta)), "get_theta")
     return theta.value

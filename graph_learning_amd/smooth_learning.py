@@ -88,22 +88,36 @@ def gsp_learn_graph_log_degrees(
     return out
 
 
-def get_theta(sq_pdists: np.ndarray, avg_degree: int, blocks=None, *, ctx: Optional[_lib.Context] = None) -> float:
+def get_theta(sq_pdists: np.ndarray, avg_degree, blocks=None, *, ctx: Optional[_lib.Context] = None):
     """theta that gives the desired average degree (Kalofolias & Perraudin 2019).
 
-    ``sq_pdists`` is the SQUARE (n, n) matrix of squared distances; rows are
-    ranked with the zero diagonal included, as the reference does (:202-203).
-    The ``blocks`` branch of the reference (:220-235, used by GLMM only) is out
-    of this library's scope.
+    ``sq_pdists`` is the SQUARE (n, n) matrix of squared distances; rows are ranked with the zero
+    diagonal included, as the reference does (smooth_learning.py:202-203).  With ``blocks`` (node ->
+    block labels; reference :220-235, used by the clustering M-step) the plain rule is applied to
+    every block pair ``sq_pdists[block_a, block_b]`` -- ``avg_degree`` may then be a dict
+    ``{(a, b): degree}`` -- and the result is the condensed (E,) vector of per-edge thetas.
     """
-    if blocks is not None:
-        raise NotImplementedError("get_theta(blocks=...) is outside the accelerated hot path")
-    sq = _lib.as_f64(sq_pdists)
-    if sq.ndim != 2 or sq.shape[0] != sq.shape[1]:
-        raise ValueError(f"sq_pdists must be a square matrix, got {sq.shape}")
     from . import operators
 
-    return operators.theta_from_square(sq, int(avg_degree), ctx=ctx)
+    sq = _lib.as_f64(sq_pdists)
+    if blocks is None:
+        if sq.ndim != 2 or sq.shape[0] != sq.shape[1]:
+            raise ValueError(f"sq_pdists must be a square matrix, got {sq.shape}")
+        return operators.theta_from_square(sq, int(avg_degree), ctx=ctx)
+    blocks = np.asarray(blocks)
+    n = len(blocks)
+    thetas = np.zeros((n, n))
+    labels = np.unique(blocks).tolist()
+    for a_pos, a in enumerate(labels):
+        for b in labels[a_pos:]:  # combinations_with_replacement(labels, 2)
+            rows = np.where(blocks == a)[0]
+            cols = np.where(blocks == b)[0]
+            degree = avg_degree[(a, b)] if isinstance(avg_degree, dict) else avg_degree
+            theta = operators.theta_from_square(sq[np.ix_(rows, cols)], int(degree), ctx=ctx)
+            thetas[np.ix_(rows, cols)] = theta
+            thetas[np.ix_(cols, rows)] = theta
+    iu = np.triu_indices(n, k=1)
+    return thetas[iu]  # squareform(thetas, checks=False)
 
 
 class LogModel(BaseEstimator):

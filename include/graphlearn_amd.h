@@ -156,6 +156,10 @@ int gl_squared_pdiffs(gl_ctx *ctx, const double *x, int64_t T, int64_t n_nodes, 
 /* get_theta, blocks=None (graph_learn/smooth_learning.py:201-219) on a host
  * (n,n) matrix of squared distances (zero diagonal included in the ranking). */
 int gl_theta_from_distances(gl_ctx *ctx, const double *zsq, int64_t n_nodes, int avg_degree, double *theta_out);
+/* The same on a rows x cols matrix: the blocks branch of get_theta (:220-235) applies the plain
+ * branch to rectangular sub-matrices sq_pdists[block_a, block_b]; needs 1 <= avg_degree < cols. */
+int gl_theta_from_matrix(gl_ctx *ctx, const double *zsq, int64_t rows, int64_t cols, int avg_degree,
+                         double *theta_out);
 
 /* ---- batch of graphs across GPUs (BASELINE config 4) ----------------------
  * One independent problem per GPU/rank; RCCL over xGMI is used only as a barrier,

@@ -311,6 +311,41 @@ def gen_graphdict():
     save("graphdict", **arrays)
 
 
+def gen_clustering():
+    """Clustering M-step (clustering/glmm.py:18-85) and get_theta's blocks branch (:220-235)."""
+    from graph_learn.clustering.glmm import _estimate_gauss_laplacian_parameters as mstep
+
+    arrays = {}
+    rng = default_rng(31)
+    n, t, k = 12, 80, 3
+    laps = [sample_er_laplacian(n, 0.4, 0.3, 2.0, seed=rng) for _ in range(k)]
+    x = np.concatenate([sample_lgmrf(lap, t // k + 1, seed=rng) for lap in laps])[:t]
+    logits = rng.standard_normal((t, k)) * 2
+    resp = np.exp(logits) / np.exp(logits).sum(1, keepdims=True)
+    blocks = np.array([0] * 5 + [1] * 7)
+    degs = {(0, 0): 2, (0, 1): 3, (1, 1): 2}
+    arrays.update(x=x, resp=resp, blocks=blocks, delta=np.float64(2.0))
+    cases = {
+        "deg3": dict(avg_degree=3),
+        "theta05": dict(theta=0.5),
+        "blocks_int": dict(avg_degree=2, blocks=blocks),
+        "blocks_dict": dict(avg_degree=degs, blocks=blocks),
+    }
+    for tag, kw in cases.items():
+        w, m, lap = mstep(x, resp, 2.0, **kw)
+        arrays[f"{tag}_weights"], arrays[f"{tag}_means"], arrays[f"{tag}_laplacians"] = w, m, lap
+    # warm start from previous Laplacians
+    _, _, lap0 = mstep(x, resp, 2.0, avg_degree=3)
+    w, m, lap = mstep(x, resp * 0.9 + 0.1 / k, 2.0, avg_degree=3, laplacians=lap0)
+    arrays["warm_weights"], arrays["warm_means"], arrays["warm_laplacians"] = w, m, lap
+    # get_theta blocks branch on a plain distance matrix
+    z = squareform(pdist(rng.standard_normal((n, 6))) ** 2)
+    arrays["theta_z"] = z
+    arrays["theta_blocks_int"] = ref_sl.get_theta(z, 2, blocks=blocks)
+    arrays["theta_blocks_dict"] = ref_sl.get_theta(z, degs, blocks=blocks)
+    save("clustering", **arrays)
+
+
 if __name__ == "__main__":
     gen_sum_squareform()
     gen_theta()
@@ -319,3 +354,4 @@ if __name__ == "__main__":
     gen_lgmrf()
     gen_operators()
     gen_graphdict()
+    gen_clustering()
