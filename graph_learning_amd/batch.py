@@ -271,3 +271,10 @@ class LogModelBatch:
                         elif src == comm.rank:
                             self.theta_[j], self.n_iter_[j] = theta, n_it
         return self
+
+    def records(self):
+        """The gathered graphs as self-describing records (``graph_learning_amd.wire``), one per problem."""
+        from . import wire
+
+        return [wire.pack(self.weights_[j], problem_id=j, n_iter=int(self.n_iter_[j]), theta=float(self.theta_[j]),
+                          edge_tol=self.edge_tol) for j in range(len(self.weights_))]
