@@ -31,7 +31,10 @@
 #include "gl_logdeg.h"
 
 #ifndef GL_RES_MIN_BULK_TILES
-#define GL_RES_MIN_BULK_TILES 1400
+#define GL_RES_MIN_BULK_TILES 700
+#endif
+#ifndef GL_RES_STOP_AT_END
+#define GL_RES_STOP_AT_END 1
 #endif
 #ifndef GL_RES_FAST_FRINGE
 #define GL_RES_FAST_FRINGE 0
@@ -127,23 +130,31 @@ struct NodeVals {
 };
 
 __device__ __forceinline__ NodeVals load_node_vals(const ResDev &P, int I, int J, int lane) {
-    const int c0 = 2 * (lane & 31);
+    int oj = J * TB + 2 * (lane & 31), oi = I * TB + lane;
+    asm volatile("" : "+v"(oj), "+v"(oi));  // recompute the six addresses each iteration rather than spill them
     NodeVals v;
-    v.dj0 = ld_sc1(P.dvar + (int64_t)J * TB + c0);
-    v.dj1 = ld_sc1(P.dvar + (int64_t)J * TB + c0 + 1);
-    v.pj0 = ld_sc1(P.pbar + (int64_t)J * TB + c0);
-    v.pj1 = ld_sc1(P.pbar + (int64_t)J * TB + c0 + 1);
-    v.dvec = ld_sc1(P.dvar + (int64_t)I * TB + lane);
-    v.pvec = ld_sc1(P.pbar + (int64_t)I * TB + lane);
+    v.dj0 = ld_sc1(P.dvar + oj);
+    v.dj1 = ld_sc1(P.dvar + oj + 1);
+    v.pj0 = ld_sc1(P.pbar + oj);
+    v.pj1 = ld_sc1(P.pbar + oj + 1);
+    v.dvec = ld_sc1(P.dvar + oi);
+    v.pvec = ld_sc1(P.pbar + oi);
     return v;
 }
 
+__device__ __forceinline__ double2 ld_z(const double *base, unsigned byte_off) {
+    return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
 __device__ __forceinline__ void bulk_tile_pass(const ResDev &P, double2 (&wreg)[RS], double2 *wl, double2 (&zr)[8],
-                                               const NodeVals &nv, const int I, const int J, const int64_t tb,
+                                               const NodeVals &nv, const int I, const int J, const unsigned zb_in,
                                                const int entry, const int lane, double &nqy, double &nw) {
     const int half = lane >> 5, c0 = 2 * (lane & 31);
     const double c = P.c, g = P.gamma, g2 = P.g2;
     const double dj0 = nv.dj0, dj1 = nv.dj1, pj0 = nv.pj0, pj1 = nv.pj1, dvec = nv.dvec, pvec = nv.pvec;
+    unsigned zb = zb_in;
+    int rbase = J * (int)P.n_pad + I * TB + 2 * ((lane >> 2) & 7) + half;  // this lane's row-slab entry of group 0
+    asm volatile("" : "+v"(zb), "+v"(rbase));  // not loop-invariant for the compiler: addresses are recomputed, not spilled
     double colp0 = 0, colp1 = 0, colw0 = 0, colw1 = 0;
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
@@ -182,13 +193,16 @@ __device__ __forceinline__ void bulk_tile_pass(const ResDev &P, double2 (&wreg)[
             else
                 wl[(s - RS) * 64] = double2{wn[0], wn[1]};
             // refill the ring: slot s + 8 of this tile (wraps into the next iteration)
-            zr[k] = *reinterpret_cast<const double2 *>(P.z + tb + ((s + 8) & (SLOTS - 1)) * (2 * TB));
+            // uniform base + 32-bit lane offset: one address register per wave.  With 64-bit per-slot
+            // pointers the compiler hoists 28 of them out of the iteration loop, spills them, and every
+            // reload drains the prefetch ring (scratch loads share vmcnt with the z loads).
+            zr[k] = ld_z(P.z, zb + (unsigned)(((s + 8) & (SLOTS - 1)) * (2 * TB) * 8));
             asm volatile("" : "+v"(nqy), "+v"(nw), "+v"(colp0), "+v"(colp1), "+v"(colw0), "+v"(colw1));
         }
         const double rw = halfwave_rows8(roww, lane);
         const double rp = halfwave_rows8(rowp, lane);
         if ((lane & 3) == 0) {
-            const int64_t idx = (int64_t)J * P.n_pad + (int64_t)I * TB + 2 * (8 * gq + ((lane >> 2) & 7)) + half;
+            const int64_t idx = (int64_t)rbase + 16 * gq;
             st_sc1(P.rowslab_p + idx, rp);
             st_sc1(P.rowslab_w + idx, rw);
         }
@@ -289,6 +303,7 @@ __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
     const bool has_bulk = slot < P.F;
     int I = 0, J = 0;
     int64_t tb = 0;
+    unsigned zb = 0;  // byte offset of this lane's first z entry (the z array of a resident problem is < 4 GB)
     double2 wreg[RS], zr[8];
     double2 *wl = &s_w[wave][0][lane];
 #pragma unroll
@@ -301,6 +316,7 @@ __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
         I = __builtin_amdgcn_readfirstlane(I);
         J = __builtin_amdgcn_readfirstlane(J);
         tb = t * GL_TILE_ELEMS + lofs;
+        zb = (unsigned)(tb * 8);
 #pragma unroll
         for (int s = 0; s < RS; ++s) wreg[s] = *reinterpret_cast<const double2 *>(P.w + tb + s * (2 * TB));
 #pragma unroll
@@ -367,7 +383,7 @@ __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
         }
         NodeVals nv{};
         if (has_bulk) nv = load_node_vals(P, I, J, lane);
-        if (iter > 0) {  // stopping rule of iteration iter-1 (:156-161,166): same data, same order everywhere
+        if (!GL_RES_STOP_AT_END && iter > 0) {  // stopping rule of iteration iter-1 (:156-161,166): same data, same order everywhere
             if (wave == 0) {
                 const double *bn = P.bnorm + ((P.it0 + iter - 1) & 1) * 4 * P.nb;
                 double b0 = 0, b1 = 0, b2 = 0, b3 = 0;
@@ -464,7 +480,7 @@ __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
             }
         }
         // ================= edge phase: my resident bulk tile =================
-        if (has_bulk) bulk_tile_pass(P, wreg, wl, zr, nv, I, J, tb, bulk_row, lane, nqy, nw);
+        if (has_bulk) bulk_tile_pass(P, wreg, wl, zr, nv, I, J, zb, bulk_row, lane, nqy, nw);
         // ================= edge phase: fringe pairs, generic loop (slots with more than two) =================
         if (fr0 < fr1 && !fr_fast) {
             int seg = 0;
@@ -667,16 +683,46 @@ __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
         if (!(ok = grid_barrier(P, bs, &s_ok))) break;
         if (stamp) ts[4] = __builtin_amdgcn_s_memrealtime();
 
+        done_iters = iter + 1;
+        if (GL_RES_STOP_AT_END) {  // stopping rule of this iteration, after its update (:156-167)
+            if (wave == 0) {
+                const double *bn = P.bnorm + ((P.it0 + iter) & 1) * 4 * P.nb;
+                double b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+                for (int64_t bb = lane; bb < P.nb; bb += 64) {
+                    b0 += ld_sc1(bn + 4 * bb + 0);
+                    b1 += ld_sc1(bn + 4 * bb + 1);
+                    b2 += ld_sc1(bn + 4 * bb + 2);
+                    b3 += ld_sc1(bn + 4 * bb + 3);
+                }
+                b0 = wave_sum(b0);
+                b1 = wave_sum(b1);
+                b2 = wave_sum(b2);
+                b3 = wave_sum(b3);
+                if (lane == 0) {
+                    s_rel[0] = sqrt(b0) / sqrt(b1);
+                    s_rel[1] = sqrt(b2) / sqrt(b3);
+                }
+            }
+            __syncthreads();
+            const double rp = s_rel[0], rd = s_rel[1];
+            const long long itp = P.it0 + iter;
+            if (wg == 0 && tid == 0 && itp >= 1) {
+                P.dstat[0] = rp;
+                P.dstat[1] = rd;
+            }
+            if (itp >= 1 && rp < P.tol && rd < P.tol) stopped = 1;  // never at iteration 0
+            __syncthreads();  // s_rel is rewritten next iteration
+        }
         if (stamp && tid == 0) {
             ts[5] = __builtin_amdgcn_s_memrealtime();
             unsigned long long *o = P.dbg + ((size_t)wg * 16 + (iter - 8)) * 6;
             for (int q = 0; q < 6; ++q) o[q] = ts[q];
         }
-        done_iters = iter + 1;
+        if (stopped) break;
     }
 
     // relative changes of the last completed iteration (and its stopping rule) when the loop ran out
-    if (ok && !stopped && done_iters > 0) {
+    if (!GL_RES_STOP_AT_END && ok && !stopped && done_iters > 0) {
         if (wave == 0) {
             const double *bn = P.bnorm + ((P.it0 + done_iters - 1) & 1) * 4 * P.nb;
             double b0 = 0, b1 = 0, b2 = 0, b3 = 0;
@@ -764,9 +810,9 @@ int gl_resident_prepare(gl_logdeg *s) {
         }
     const int F = (int)bulk.size(), NF = (int)fringe.size();
     if (F > ncu * RW) return GL_OK;  // does not fit: the streaming engine handles it
-    // One iteration of this engine costs ~30 us almost independently of n (two grid barriers and a
-    // single wave per tile), the streaming engine ~2.5 us per 100 tiles: it pays off from ~1400
-    // bulk tiles (n >~ 3400) on.  GRAPHLEARN_AMD_ENGINE=resident forces it wherever it fits.
+    // One iteration of this engine costs ~23-25 us almost independently of n (two grid barriers and a
+    // single wave per tile), the streaming engine ~2.5 us per 100 tiles: it pays off from ~700
+    // bulk tiles (n >~ 2400) on.  GRAPHLEARN_AMD_ENGINE=resident forces it wherever it fits.
     if (!forced && F < GL_RES_MIN_BULK_TILES) return GL_OK;
     int NWG = std::max(1, (F + RW - 1) / RW);
     NWG = std::max<int>(NWG, (int)std::min<int64_t>(D.nb, ncu));  // enough workgroups for the node phase / fringe

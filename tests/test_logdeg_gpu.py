@@ -29,7 +29,7 @@ CASES = ["logmodel_n7_d23", "logmodel_n16_d40", "logmodel_n64_d256"]
 def engine(request, monkeypatch):
     """Every test of this file runs on both iteration engines: the streaming one (one edge-pass +
     one node-pass launch per iteration) and the resident one (iterate held in registers / LDS,
-    grid barriers; by default only chosen for n >~ 3400, forced here)."""
+    grid barriers; by default only chosen for n >~ 2400, forced here)."""
     monkeypatch.setenv("GRAPHLEARN_AMD_ENGINE", request.param)
     return request.param
 

@@ -91,5 +91,5 @@ def test_shape_errors():
         ops.laplacian_squareform_vec(np.zeros((2, 7)))
     with pytest.raises(ValueError):
         get_theta(np.zeros((3, 4)), 1)
-    with pytest.raises(NotImplementedError):
-        get_theta(np.zeros((4, 4)), 1, blocks=np.zeros(4, dtype=int))
+    with pytest.raises(ValueError):  # a block with fewer than avg_degree + 1 columns
+        get_theta(np.ones((4, 4)), 3, blocks=np.array([0, 0, 1, 1]))

@@ -23,8 +23,8 @@ algo = 12 * n * (n - 1)
 
 
 def one(pattern):
-    files = glob.glob(pattern, recursive=True)
-    return files[0] if files else None
+    files = sorted(glob.glob(pattern, recursive=True), key=lambda f: int(os.path.basename(f).split("_")[0]))
+    return files[-1] if files else None  # the latest run id when gpurun_out/ still holds older passes
 
 
 def short(name):
