@@ -33,12 +33,6 @@
 #ifndef GL_RES_MIN_BULK_TILES
 #define GL_RES_MIN_BULK_TILES 700
 #endif
-#ifndef GL_RES_STOP_AT_END
-#define GL_RES_STOP_AT_END 1
-#endif
-#ifndef GL_RES_FAST_FRINGE
-#define GL_RES_FAST_FRINGE 0
-#endif
 
 namespace {
 
@@ -327,28 +321,6 @@ __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
     // ---- my share of the fringe (row pairs of diagonal / ragged tiles)
     const int64_t fr0 = (int64_t)slot * P.R / P.S, fr1 = (int64_t)(slot + 1) * P.R / P.S;
 
-    // up to two fringe pairs per slot take the fast path (their loads are issued with the
-    // iteration's first loads); slots with more (small problems) use the generic loop below
-    const int nfr = (int)(fr1 - fr0);
-    const bool fr_fast = GL_RES_FAST_FRINGE && nfr >= 1 && nfr <= 2;
-    int64_t foff[2] = {0, 0};
-    int fIv[2] = {0, 0}, fJv[2] = {0, 0}, fav[2] = {0, 0};
-    if (fr_fast) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-            if (q < nfr) {
-                const int64_t fp = fr0 + q;
-                const int64_t t = P.fr_tile[fp >> 5];
-                int a_, b_;
-                gl_tile_decode(t, P.nb, a_, b_);
-                fIv[q] = __builtin_amdgcn_readfirstlane(a_);
-                fJv[q] = __builtin_amdgcn_readfirstlane(b_);
-                fav[q] = (int)(fp & (SLOTS - 1));
-                foff[q] = t * GL_TILE_ELEMS + (int64_t)fav[q] * (2 * TB) + lofs;
-            }
-    }
-    const bool fr_two_tiles = fr_fast && nfr == 2 && (fIv[0] != fIv[1] || fJv[0] != fJv[1]);
-
     BarState bs{};
     if (tid == 0) s_ok = barrier_setup(P, bs) ? 1 : 0;
     __syncthreads();
@@ -361,128 +333,10 @@ __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
         unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
         const bool stamp = P.dbg != nullptr && iter >= 8 && iter < 24;
         if (stamp) ts[0] = __builtin_amdgcn_s_memrealtime();
-        // ================= first loads of the iteration, all in one round trip =================
-        // fringe pairs (w, z plain; node entries write-through), the bulk tile's node entries, and
-        // -- wave 0 -- the norm partials of the PREVIOUS iteration for its stopping rule
-        double2 fw[2] = {double2{0.0, 0.0}, double2{0.0, 0.0}}, fz[2] = {double2{0.0, 0.0}, double2{0.0, 0.0}};
-        double fdi[2] = {0, 0}, fpi[2] = {0, 0}, fdj[2][2] = {{0, 0}, {0, 0}}, fpj[2][2] = {{0, 0}, {0, 0}};
-        if (fr_fast) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                if (q < nfr) {
-                    fw[q] = *reinterpret_cast<const double2 *>(P.w + foff[q]);
-                    fz[q] = *reinterpret_cast<const double2 *>(P.z + foff[q]);
-                    const int i = fIv[q] * TB + 2 * fav[q] + half;
-                    fdi[q] = ld_sc1(P.dvar + i);
-                    fpi[q] = ld_sc1(P.pbar + i);
-                    fdj[q][0] = ld_sc1(P.dvar + (int64_t)fJv[q] * TB + c0);
-                    fdj[q][1] = ld_sc1(P.dvar + (int64_t)fJv[q] * TB + c0 + 1);
-                    fpj[q][0] = ld_sc1(P.pbar + (int64_t)fJv[q] * TB + c0);
-                    fpj[q][1] = ld_sc1(P.pbar + (int64_t)fJv[q] * TB + c0 + 1);
-                }
-        }
-        NodeVals nv{};
-        if (has_bulk) nv = load_node_vals(P, I, J, lane);
-        if (!GL_RES_STOP_AT_END && iter > 0) {  // stopping rule of iteration iter-1 (:156-161,166): same data, same order everywhere
-            if (wave == 0) {
-                const double *bn = P.bnorm + ((P.it0 + iter - 1) & 1) * 4 * P.nb;
-                double b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-                for (int64_t bb = lane; bb < P.nb; bb += 64) {
-                    b0 += ld_sc1(bn + 4 * bb + 0);
-                    b1 += ld_sc1(bn + 4 * bb + 1);
-                    b2 += ld_sc1(bn + 4 * bb + 2);
-                    b3 += ld_sc1(bn + 4 * bb + 3);
-                }
-                b0 = wave_sum(b0);
-                b1 = wave_sum(b1);
-                b2 = wave_sum(b2);
-                b3 = wave_sum(b3);
-                if (lane == 0) {
-                    s_rel[0] = sqrt(b0) / sqrt(b1);
-                    s_rel[1] = sqrt(b2) / sqrt(b3);
-                }
-            }
-            __syncthreads();
-            const double rp = s_rel[0], rd = s_rel[1];
-            const long long itp = P.it0 + iter - 1;  // index of the iteration just completed
-            if (wg == 0 && tid == 0 && itp >= 1) {
-                P.dstat[0] = rp;
-                P.dstat[1] = rd;
-            }
-            if (itp >= 1 && rp < P.tol && rd < P.tol) {  // never at iteration 0 (:156-161)
-                stopped = 1;
-                break;  // nothing of this iteration has been applied yet
-            }
-        }
-        // ================= edge phase: fringe pairs, fast path (masked entries) =================
-        if (fr_fast) {
-            double colp0 = 0, colp1 = 0, colw0 = 0, colw1 = 0;
-            int seg = 0;
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                if (q < nfr) {
-                    if (q == 1 && fr_two_tiles) {  // the second pair opens another tile: flush the first
-                        colp0 += shfl_xor_d(colp0, 32);
-                        colp1 += shfl_xor_d(colp1, 32);
-                        colw0 += shfl_xor_d(colw0, 32);
-                        colw1 += shfl_xor_d(colw1, 32);
-                        if (half == 0) {
-                            double *dst = P.colslab + (int64_t)P.col_ent[P.F + slot * P.KF + seg] * (2 * TB) + c0;
-                            st_sc1(dst, colp0);
-                            st_sc1(dst + 1, colp1);
-                            st_sc1(dst + TB, colw0);
-                            st_sc1(dst + TB + 1, colw1);
-                        }
-                        colp0 = colp1 = colw0 = colw1 = 0.0;
-                        ++seg;
-                    }
-                    const int i = fIv[q] * TB + 2 * fav[q] + half;
-                    double wn[2], pp[2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int j = fJv[q] * TB + c0 + e;
-                        const bool valid = i < j && j < P.n;
-                        const double w = e ? fw[q].y : fw[q].x, z = e ? fz[q].y : fz[q].x;
-                        const double y = c * w - g * (fdi[q] + fdj[q][e]);
-                        const double tt = y - g2 * z;
-                        const double pr = tt > 0 ? tt : 0.0;
-                        const double qq = c * pr - g * (fpi[q] + fpj[q][e]);
-                        const double wnew = (w - y) + qq;
-                        const double dq = qq - y;
-                        pp[e] = valid ? pr : 0.0;
-                        wn[e] = valid ? wnew : 0.0;
-                        nqy += valid ? dq * dq : 0.0;
-                        nw += valid ? w * w : 0.0;
-                    }
-                    colp0 += pp[0];
-                    colp1 += pp[1];
-                    colw0 += wn[0];
-                    colw1 += wn[1];
-                    *reinterpret_cast<double2 *>(P.w + foff[q]) = double2{wn[0], wn[1]};  // in place: this pair is mine
-                    const double rp_ = half_sum(pp[0] + pp[1]);
-                    const double rw_ = half_sum(wn[0] + wn[1]);
-                    if ((lane & 31) == 0) {
-                        const int64_t idx = (int64_t)fJv[q] * P.n_pad + i;
-                        st_sc1(P.rowslab_p + idx, rp_);
-                        st_sc1(P.rowslab_w + idx, rw_);
-                    }
-                }
-            colp0 += shfl_xor_d(colp0, 32);
-            colp1 += shfl_xor_d(colp1, 32);
-            colw0 += shfl_xor_d(colw0, 32);
-            colw1 += shfl_xor_d(colw1, 32);
-            if (half == 0) {
-                double *dst = P.colslab + (int64_t)P.col_ent[P.F + slot * P.KF + seg] * (2 * TB) + c0;
-                st_sc1(dst, colp0);
-                st_sc1(dst + 1, colp1);
-                st_sc1(dst + TB, colw0);
-                st_sc1(dst + TB + 1, colw1);
-            }
-        }
         // ================= edge phase: my resident bulk tile =================
-        if (has_bulk) bulk_tile_pass(P, wreg, wl, zr, nv, I, J, zb, bulk_row, lane, nqy, nw);
-        // ================= edge phase: fringe pairs, generic loop (slots with more than two) =================
-        if (fr0 < fr1 && !fr_fast) {
+        if (has_bulk) bulk_tile_pass(P, wreg, wl, zr, load_node_vals(P, I, J, lane), I, J, zb, bulk_row, lane, nqy, nw);
+        // ================= edge phase: my fringe row pairs (streamed, masked, in place) =================
+        if (fr0 < fr1) {
             int seg = 0;
             int64_t tcur = -1;
             int fI = 0, fJ = 0;
@@ -684,7 +538,7 @@ __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
         if (stamp) ts[4] = __builtin_amdgcn_s_memrealtime();
 
         done_iters = iter + 1;
-        if (GL_RES_STOP_AT_END) {  // stopping rule of this iteration, after its update (:156-167)
+        {  // stopping rule of this iteration, after its update (:156-167): same data, same order everywhere
             if (wave == 0) {
                 const double *bn = P.bnorm + ((P.it0 + iter) & 1) * 4 * P.nb;
                 double b0 = 0, b1 = 0, b2 = 0, b3 = 0;
@@ -719,37 +573,6 @@ __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
             for (int q = 0; q < 6; ++q) o[q] = ts[q];
         }
         if (stopped) break;
-    }
-
-    // relative changes of the last completed iteration (and its stopping rule) when the loop ran out
-    if (!GL_RES_STOP_AT_END && ok && !stopped && done_iters > 0) {
-        if (wave == 0) {
-            const double *bn = P.bnorm + ((P.it0 + done_iters - 1) & 1) * 4 * P.nb;
-            double b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-            for (int64_t bb = lane; bb < P.nb; bb += 64) {
-                b0 += ld_sc1(bn + 4 * bb + 0);
-                b1 += ld_sc1(bn + 4 * bb + 1);
-                b2 += ld_sc1(bn + 4 * bb + 2);
-                b3 += ld_sc1(bn + 4 * bb + 3);
-            }
-            b0 = wave_sum(b0);
-            b1 = wave_sum(b1);
-            b2 = wave_sum(b2);
-            b3 = wave_sum(b3);
-            if (lane == 0) {
-                s_rel[0] = sqrt(b0) / sqrt(b1);
-                s_rel[1] = sqrt(b2) / sqrt(b3);
-            }
-        }
-        __syncthreads();
-        const long long itp = P.it0 + done_iters - 1;
-        if (itp >= 1) {
-            if (wg == 0 && tid == 0) {
-                P.dstat[0] = s_rel[0];
-                P.dstat[1] = s_rel[1];
-            }
-            if (s_rel[0] < P.tol && s_rel[1] < P.tol) stopped = 1;
-        }
     }
 
     // ---- registers back to the iterate buffer, bookkeeping for the host / the streaming engine
