@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "gl_common.h"
+#include "gl_gridbar.h"
 
 namespace {
 
@@ -316,8 +317,206 @@ __global__ __launch_bounds__(256) void k_lg_admm(LgDev D, int it) {
     if (blockIdx.x == 0 && tid == 0) D.scal[1] = (double)(it + 1);
 }
 
+// ------------------------------------------------------------------------------------------
+// The same ADMM, all steps in ONE persistent launch ("resident" form): workgroup b keeps its R rows
+// of the explicit inverse W in LDS for the whole QP (n = 2048: 8 rows = 128 KiB per CU, the 33.5 MB
+// matrix is read from memory once per QP instead of once per step), the right-hand side v (n
+// doubles) is exchanged through memory with write-through stores / sc1 loads, and the grid-wide
+// dependency between steps is the XCD-hierarchical grid barrier of gl_gridbar.h instead of a
+// kernel boundary.  Same update formulas, same deferred stopping rule (every workgroup evaluates
+// it from the same partials in the same order).  Needs all workgroups co-resident (grid <= #CU,
+// one workgroup per CU); the start-up rendezvous fails cleanly otherwise (error word in scal[8]).
+constexpr int ADMM_RES_MAXR = 8;
+
+__device__ __forceinline__ double lg_ld_sc1(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void lg_st_sc1(double *p, double v) {
+    __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void k_lg_admm_res(LgDev D, GlGridBar gb, int R, int max_iter) {
+    extern __shared__ double s_W[];  // R rows of W, row-major (R * n doubles)
+    __shared__ double s_acc[4][ADMM_RES_MAXR];
+    __shared__ double s_x[ADMM_RES_MAXR];
+    __shared__ int s_ok, s_stop;
+    const int64_t n = D.n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * R;
+    const int nrows = (int)max((int64_t)0, min((int64_t)R, n - r0));
+
+    for (int64_t q = tid; q < (int64_t)nrows * n; q += 256) s_W[q] = D.W[r0 * n + q];
+    GlBarState bs{};
+    if (tid == 0) s_ok = gl_barrier_setup(gb, bs) ? 1 : 0;
+    __syncthreads();
+    if (!s_ok) {
+        if (blockIdx.x == 0 && tid == 0) D.scal[8] = 1.0;
+        return;
+    }
+    // thread r < nrows owns row r0 + r: its ADMM state stays in registers for the whole QP
+    double xo = 0, zo = 0, uo = 0, pi = 0, on = 0;
+    if (tid < nrows) {
+        const int64_t i = r0 + tid;
+        xo = D.x[i];
+        zo = D.z[i];
+        uo = D.uu[i];
+        pi = D.p[i];
+        on = D.act[i];
+    }
+    int steps = 0;
+    bool stopped = false;
+    for (int it = 0; it < max_iter; ++it) {
+        const double *vin = (it & 1) ? D.y : D.v;
+        double *vout = (it & 1) ? D.v : D.y;
+        const bool chk = it >= 2;  // rule of step it-1 (never for step 0: `it > 0`)
+        // (1) partials of step it-1 for the deferred stopping rule (wave 0), requested first
+        double a0 = 0, a1 = 0, a3 = 0, a4 = 0, m2 = 0, m5 = 0;
+        if (chk && wave == 0) {
+            const double *pp = D.part + (size_t)((it - 1) & 1) * nblk * 6;
+            for (int b = lane; b < nblk; b += 64) {
+                a0 += lg_ld_sc1(pp + 6 * b + 0);
+                a1 += lg_ld_sc1(pp + 6 * b + 1);
+                m2 = fmax(m2, lg_ld_sc1(pp + 6 * b + 2));
+                a3 += lg_ld_sc1(pp + 6 * b + 3);
+                a4 += lg_ld_sc1(pp + 6 * b + 4);
+                m5 = fmax(m5, lg_ld_sc1(pp + 6 * b + 5));
+            }
+        }
+        // (2) my rows times v: thread t takes columns t, t + 256, ...
+        double acc[ADMM_RES_MAXR];
+#pragma unroll
+        for (int r = 0; r < ADMM_RES_MAXR; ++r) acc[r] = 0.0;
+#pragma unroll 8
+        for (int64_t j = tid; j < n; j += 256) {
+            const double vj = lg_ld_sc1(vin + j);
+#pragma unroll
+            for (int r = 0; r < ADMM_RES_MAXR; ++r)
+                if (r < nrows) acc[r] += s_W[(int64_t)r * n + j] * vj;
+        }
+#pragma unroll
+        for (int r = 0; r < ADMM_RES_MAXR; ++r) acc[r] = wsum(acc[r]);
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < ADMM_RES_MAXR; ++r) s_acc[wave][r] = acc[r];
+        }
+        if (tid == 0) s_stop = 0;
+        __syncthreads();
+        if (tid < ADMM_RES_MAXR) s_x[tid] = ((s_acc[0][tid] + s_acc[1][tid]) + s_acc[2][tid]) + s_acc[3][tid];
+        if (chk && wave == 0) {
+            a0 = wsum(a0);
+            a1 = wsum(a1);
+            a3 = wsum(a3);
+            a4 = wsum(a4);
+            m2 = wmax(m2);
+            m5 = wmax(m5);
+            // relative_error(prev, new): plain norm when prev is allclose to 0 (atol 1e-8)
+            const double rx = (m2 <= 1e-8) ? sqrt(a0) : sqrt(a0) / sqrt(a1);
+            const double rz = (m5 <= 1e-8) ? sqrt(a3) : sqrt(a3) / sqrt(a4);
+            if (lane == 0 && rx < D.qp_tol && rz < D.qp_tol) s_stop = 1;
+        }
+        __syncthreads();
+        if (s_stop) {  // step it-1 met the rule: its z is the result, nothing of step `it` is applied
+            stopped = true;
+            break;
+        }
+        // (3) row-local updates (lgmrf.py:57-69) and the partial norms of this step
+        double dx2 = 0, x2 = 0, xm = 0, dz2 = 0, z2 = 0, zm = 0;
+        if (tid < nrows) {
+            const bool active = on != 0.0;
+            const double xn = active ? s_x[tid] : 0.0;
+            double zn = xn + uo;
+            zn = zn < 0 ? 0.0 : zn;
+            const double un = uo + (xn - zn);
+            if (active) {
+                dx2 = (xn - xo) * (xn - xo);
+                x2 = xo * xo;
+                xm = fabs(xo);
+                dz2 = (zn - zo) * (zn - zo);
+                z2 = zo * zo;
+                zm = fabs(zo);
+            }
+            xo = xn;
+            zo = active ? zn : 0.0;
+            uo = active ? un : 0.0;
+            lg_st_sc1(vout + r0 + tid, active ? (zn - un) + D.rho * pi : 0.0);
+        }
+        if (wave == 0) {  // rows live in lanes 0..R-1 of wave 0: fixed-order sums over those lanes
+            dx2 = wsum(dx2);
+            x2 = wsum(x2);
+            xm = wmax(xm);
+            dz2 = wsum(dz2);
+            z2 = wsum(z2);
+            zm = wmax(zm);
+            if (lane == 0) {
+                double *o = D.part + ((size_t)(it & 1) * nblk + blockIdx.x) * 6;
+                lg_st_sc1(o + 0, dx2);
+                lg_st_sc1(o + 1, x2);
+                lg_st_sc1(o + 2, xm);
+                lg_st_sc1(o + 3, dz2);
+                lg_st_sc1(o + 4, z2);
+                lg_st_sc1(o + 5, zm);
+            }
+        }
+        steps = it + 1;
+        if (!gl_grid_barrier(gb, bs, &s_ok)) {
+            if (blockIdx.x == 0 && tid == 0) D.scal[8] = 2.0;  // barrier lost in mid-run
+            break;
+        }
+    }
+    if (tid < nrows) {
+        const int64_t i = r0 + tid;
+        D.x[i] = xo;
+        D.z[i] = zo;
+        D.uu[i] = uo;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        D.scal[1] = (double)steps;
+        D.scal[0] = stopped ? 1.0 : 0.0;
+    }
+}
+
 // The QP's ADMM loop: launches in chunks and polls the device-side stop flag in between, so a
 // QP that stops after ~30 steps does not pay for 100 launches.
+// Persistent form: rows per workgroup R = ceil(n / #CU) <= 8 and R * n * 8 bytes of LDS.
+struct AdmmRes {
+    bool on = false;
+    int R = 0, nwg = 0;
+    size_t lds = 0;
+    unsigned *bar = nullptr;
+};
+
+int admm_res_plan(gl_ctx *ctx, int64_t n, AdmmRes &A) {
+    A.on = false;
+    if (const char *e = getenv("GRAPHLEARN_AMD_LGMRF_ADMM"))
+        if (!strcmp(e, "launch")) return GL_OK;
+    const int ncu = ctx->prop.multiProcessorCount;
+    const int R = (int)((n + ncu - 1) / ncu);
+    const size_t lds = (size_t)R * n * 8;
+    if (R > ADMM_RES_MAXR || lds > 150 * 1024) return GL_OK;
+    // A persistent step costs ~6-7 us whatever n is (barrier + one exchange of v through memory); a
+    // launch-per-step costs ~5 us + the stream of W: measured break-even near n = 1000
+    // (n = 256: 0.76 vs 0.70 ms per node-update, 1024: 0.92 vs 0.97, 2048: 1.24 vs 1.63).
+    const char *force = getenv("GRAPHLEARN_AMD_LGMRF_ADMM");
+    if (n < 1024 && !(force && !strcmp(force, "resident"))) return GL_OK;
+    A.R = R;
+    A.nwg = (int)((n + R - 1) / R);
+    A.lds = lds;
+    GL_HIP(ctx, hipFuncSetAttribute((const void *)k_lg_admm_res, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    A.on = true;
+    return GL_OK;
+}
+
+int run_admm_res(gl_ctx *ctx, const LgDev &D, const AdmmRes &A, int max_iter) {
+    GL_HIP(ctx, hipMemsetAsync(A.bar, 0, GL_BAR_WORDS * 4, ctx->stream));
+    const GlGridBar gb{A.bar, A.nwg};
+    k_lg_admm_res<<<dim3((unsigned)A.nwg), 256, A.lds, ctx->stream>>>(D, gb, A.R, max_iter);
+    GL_HIP(ctx, hipGetLastError());
+    return GL_OK;
+}
+
 int run_admm(gl_ctx *ctx, const LgDev &D, int max_iter) {
     const unsigned nblk = (unsigned)((D.n + ADMM_ROWS - 1) / ADMM_ROWS);
     double *flag = (double *)ctx->pinned + 32;
@@ -551,9 +750,13 @@ GL_API int gl_nonneg_qp_solve(gl_ctx *ctx, const double *mat, const double *vec,
     if (!ctx) return GL_E_INVALID;
     if (!mat || !vec || !z_out || m < 1 || max_iter < 0) return gl_set_error(ctx, GL_E_INVALID, "bad argument");
     GL_HIP(ctx, hipSetDevice(ctx->device));
-    Buf W, vecs, scal, part;
+    Buf W, vecs, scal, part, bar;
     GL_HIP(ctx, hipMalloc(&W.p, (size_t)m * m * 8));
-    GL_HIP(ctx, hipMalloc(&part.p, (size_t)2 * ((m + ADMM_ROWS - 1) / ADMM_ROWS) * 6 * 8));
+    GL_HIP(ctx, hipMalloc(&part.p, (size_t)2 * m * 6 * 8));  // one entry per workgroup, either ADMM form
+    GL_HIP(ctx, hipMalloc(&bar.p, GL_BAR_WORDS * 4));
+    AdmmRes ares;
+    GL_TRY(admm_res_plan(ctx, m, ares));
+    ares.bar = (unsigned *)bar.p;
     GL_HIP(ctx, hipMalloc(&vecs.p, (size_t)16 * m * 8));
     GL_HIP(ctx, hipMalloc(&scal.p, 16 * 8));
     double *V = (double *)vecs.p;
@@ -586,11 +789,12 @@ GL_API int gl_nonneg_qp_solve(gl_ctx *ctx, const double *mat, const double *vec,
     GL_HIP(ctx, hipMemcpyAsync(V, hv.data(), hv.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     GL_HIP(ctx, hipMemsetAsync(D.scal, 0, 16 * 8, ctx->stream));
     GL_TRY(invert_spd_inplace(ctx, D.W, m, pivrow));
-    GL_TRY(run_admm(ctx, D, max_iter));
-    double sc[2];
+    GL_TRY(ares.on ? run_admm_res(ctx, D, ares, max_iter) : run_admm(ctx, D, max_iter));
+    double sc[9];
     GL_HIP(ctx, hipMemcpyAsync(z_out, D.z, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GL_HIP(ctx, hipMemcpyAsync(sc, D.scal, 16, hipMemcpyDeviceToHost, ctx->stream));
+    GL_HIP(ctx, hipMemcpyAsync(sc, D.scal, 9 * 8, hipMemcpyDeviceToHost, ctx->stream));
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (sc[8] != 0.0) return gl_set_error(ctx, GL_E_HIP, "ADMM: grid barrier timed out (workgroups not co-resident; GRAPHLEARN_AMD_LGMRF_ADMM=launch avoids it)");
     if (iters_out) *iters_out = (int)sc[1];
     return GL_OK;
 }
@@ -629,8 +833,12 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
     GL_HIP(ctx, hipMalloc(&bVec.p, (size_t)16 * n * 8));
     GL_HIP(ctx, hipMalloc(&bScal.p, 16 * 8));
     GL_HIP(ctx, hipMalloc(&bPart.p, 3 * 256 * 8));
-    Buf bAdmm;
-    GL_HIP(ctx, hipMalloc(&bAdmm.p, (size_t)2 * ((n + ADMM_ROWS - 1) / ADMM_ROWS) * 6 * 8));
+    Buf bAdmm, bBar;
+    GL_HIP(ctx, hipMalloc(&bAdmm.p, (size_t)2 * n * 6 * 8));  // one entry per workgroup, either ADMM form
+    GL_HIP(ctx, hipMalloc(&bBar.p, GL_BAR_WORDS * 4));
+    AdmmRes ares;
+    GL_TRY(admm_res_plan(ctx, n, ares));
+    ares.bar = (unsigned *)bBar.p;
     GL_HIP(ctx, hipMemsetAsync(bVec.p, 0, (size_t)16 * n * 8, ctx->stream));
     GL_HIP(ctx, hipMemsetAsync(bScal.p, 0, 16 * 8, ctx->stream));
 
@@ -687,7 +895,7 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
                 k_lg_build_w<<<g2, 256, 0, ctx->stream>>>(D, u);
                 GL_TRY(invert_spd_inplace(ctx, D.W, n, pivrow));
             }
-            GL_TRY(run_admm(ctx, D, max_qp_iter));
+            GL_TRY(ares.on ? run_admm_res(ctx, D, ares, max_qp_iter) : run_admm(ctx, D, max_qp_iter));
             k_lg_beta<<<1, VT, 0, ctx->stream>>>(D, u);
             k_matvec<<<mvb, 256, 0, ctx->stream>>>(D.C, D.beta, D.t, n, D.scal, 0);
             k_lg_snap_col<<<1, VT, 0, ctx->stream>>>(D, u);
@@ -701,6 +909,14 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
             GL_HIP(ctx, hipGetLastError());
         }
         cycles = cycle + 1;
+        if (ares.on) {  // error word of the persistent ADMM launches of this cycle
+            double flag = 0;
+            GL_HIP(ctx, hipMemcpyAsync(&flag, D.scal + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
+            GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (flag != 0.0)
+                return gl_set_error(ctx, GL_E_HIP, "LGMRF: grid barrier of the ADMM kernel timed out (workgroups not "
+                                                    "co-resident; GRAPHLEARN_AMD_LGMRF_ADMM=launch avoids it)");
+        }
         if (cycle > 4) {  // :221
             double rel = 0;
             GL_TRY(relative_error_dev(ctx, D.ThPrev, D.Th, n * n, (double *)bPart.p, &rel));

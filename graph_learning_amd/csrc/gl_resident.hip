@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <vector>
 
+#include "gl_gridbar.h"
 #include "gl_logdeg.h"
 
 #ifndef GL_RES_MIN_BULK_TILES
@@ -214,70 +215,7 @@ __device__ __forceinline__ void bulk_tile_pass(const ResDev &P, double2 (&wreg)[
     }
 }
 
-// Grid barrier among the NWG resident workgroups (one per CU), XCD-hierarchical: arrivals are
-// counted per XCD (the chip has 8, each with its own L2), the last arriver of an XCD reports to a
-// top counter, the last of those releases every XCD through its own generation word, and each
-// workgroup polls only its XCD's word -- ~32 pollers per line instead of 252 on one.  All words are
-// monotonic within a launch (zeroed by a memset node before it); payload visibility comes from the
-// write-through protocol described at the top of this file, so no fences are needed here.
-// bar layout (unsigned, 32 words = 128 B apart): [0] flat counter (setup), [32] error word,
-// [64 + 32 x] xnum[x], [320 + 32 x] xcnt[x], [576] top, [608 + 32 x] gen[x].
-struct BarState {
-    unsigned xcc;    // my XCD (group label only: any value is correct, placement changes speed only)
-    unsigned n_my;   // workgroups in my group
-    unsigned nx;     // groups in use
-    unsigned epoch;  // barriers passed
-};
-
-__device__ __forceinline__ unsigned ld_u32(const unsigned *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// spin until *p >= target; false on error word / timeout
-__device__ bool spin_until(const ResDev &P, const unsigned *p, unsigned target) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
-    while (ld_u32(p) < target) {
-        __builtin_amdgcn_s_sleep(1);
-        if (ld_u32(P.bar + 32) != 0u) return false;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull) {  // 1 s: a workgroup is not resident
-            __hip_atomic_store(P.bar + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-        }
-    }
-    return true;
-}
-
-// called by thread 0 only, once at kernel start: learn the group sizes (flat barrier underneath)
-__device__ bool barrier_setup(const ResDev &P, BarState &B) {
-    B.xcc = __builtin_amdgcn_s_getreg(63508) & 7u;  // hwreg(HW_REG_XCC_ID, 0, 32)
-    B.epoch = 0;
-    __hip_atomic_fetch_add(P.bar + 64 + 32 * B.xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(P.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!spin_until(P, P.bar, (unsigned)P.rendezvous)) return false;
-    B.n_my = ld_u32(P.bar + 64 + 32 * B.xcc);
-    B.nx = 0;
-    for (int x = 0; x < 8; ++x) B.nx += ld_u32(P.bar + 64 + 32 * x) != 0u;
-    return true;
-}
-
-__device__ bool grid_barrier(const ResDev &P, BarState &B, int *s_ok) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its write-through stores have left
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned e = ++B.epoch;
-        const unsigned a = __hip_atomic_fetch_add(P.bar + 320 + 32 * B.xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-        if (a == B.n_my * e) {  // last of my XCD
-            const unsigned t = __hip_atomic_fetch_add(P.bar + 576, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-            if (t == B.nx * e)  // last XCD: release everybody
-                for (int x = 0; x < 8; ++x)
-                    __hip_atomic_store(P.bar + 608 + 32 * x, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        *s_ok = spin_until(P, P.bar + 608 + 32 * B.xcc, e) ? 1 : 0;
-    }
-    __syncthreads();
-    return *s_ok != 0;
-}
-
+// The grid barrier (XCD-hierarchical, bounded spins) is in gl_gridbar.h.
 __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
     __shared__ double2 s_w[RW][SLOTS - RS][64];  // 128 KiB: the LDS half of every wave's tile
     __shared__ double s_sum[2][RW][TB];
@@ -321,8 +259,9 @@ __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
     // ---- my share of the fringe (row pairs of diagonal / ragged tiles)
     const int64_t fr0 = (int64_t)slot * P.R / P.S, fr1 = (int64_t)(slot + 1) * P.R / P.S;
 
-    BarState bs{};
-    if (tid == 0) s_ok = barrier_setup(P, bs) ? 1 : 0;
+    const GlGridBar gb{P.bar, P.rendezvous};
+    GlBarState bs{};
+    if (tid == 0) s_ok = gl_barrier_setup(gb, bs) ? 1 : 0;
     __syncthreads();
     bool ok = s_ok != 0;
     int done_iters = 0;
@@ -424,7 +363,7 @@ __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
 
         // ================= all degree partials are out =================
         if (stamp) ts[1] = __builtin_amdgcn_s_memrealtime();
-        if (!(ok = grid_barrier(P, bs, &s_ok))) break;
+        if (!(ok = gl_grid_barrier(gb, bs, &s_ok))) break;
         if (stamp) ts[2] = __builtin_amdgcn_s_memrealtime();
 
         // ================= node phase: workgroup wg updates node blocks wg, wg + NWG, ... =================
@@ -534,7 +473,7 @@ __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
 
         // ================= the new dual state is out =================
         if (stamp) ts[3] = __builtin_amdgcn_s_memrealtime();
-        if (!(ok = grid_barrier(P, bs, &s_ok))) break;
+        if (!(ok = gl_grid_barrier(gb, bs, &s_ok))) break;
         if (stamp) ts[4] = __builtin_amdgcn_s_memrealtime();
 
         done_iters = iter + 1;
@@ -693,7 +632,7 @@ int gl_resident_prepare(gl_logdeg *s) {
     const size_t ncol = (size_t)F + (size_t)S * KF;
     if (hipMalloc((void **)&r->colslab, ncol * 2 * GL_TB * 8) != hipSuccess ||
         hipMalloc((void **)&r->tnorm, (size_t)S * 2 * 8) != hipSuccess ||
-        hipMalloc((void **)&r->bar, 1024 * 4) != hipSuccess) {
+        hipMalloc((void **)&r->bar, GL_BAR_WORDS * 4) != hipSuccess) {
         gl_resident_free(s);
         return gl_set_error(ctx, GL_E_NOMEM, "resident engine: hipMalloc failed");
     }
@@ -752,7 +691,7 @@ int gl_resident_launch(gl_logdeg *s, int64_t iters, double tol) {
     P.it0 = s->it;
     P.maxit = (int)std::min<int64_t>(iters, 1 << 30);
     P.rendezvous = P.NWG + (getenv("GRAPHLEARN_AMD_RES_TEST_NOT_RESIDENT") ? 1 : 0);
-    GL_HIP(ctx, hipMemsetAsync(r->bar, 0, 1024 * 4, ctx->stream));
+    GL_HIP(ctx, hipMemsetAsync(r->bar, 0, GL_BAR_WORDS * 4, ctx->stream));
     k_resident<<<dim3((unsigned)P.NWG), dim3(RT), 0, ctx->stream>>>(P);
     GL_HIP(ctx, hipGetLastError());
     return GL_OK;

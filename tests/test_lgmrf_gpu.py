@@ -16,6 +16,14 @@ from oracle import lgmrf as olg
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["launch", "resident"])
+def admm_form(request, monkeypatch):
+    """Every test runs with both forms of the QP's ADMM loop: one launch per step (default below
+    n = 1024) and the persistent kernel with the matrix resident in LDS and grid barriers."""
+    monkeypatch.setenv("GRAPHLEARN_AMD_LGMRF_ADMM", request.param)
+    return request.param
+
+
 def close(a, b, rel=1e-6):
     return np.abs(a - b).max() <= rel * max(np.abs(b).max(), 1e-300)
 
