@@ -61,6 +61,8 @@ SIGNATURES = {
     "gl_logdeg_time_edge_pass": (C.c_int, [C.c_void_p, C.c_int, _c_double_p]),
     "gl_logdeg_engine": (C.c_int, [C.c_void_p]),
     "gl_logdeg_batch_gram": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
+    "gl_logdeg_batch_iterate": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_double, _c_int64_p, _c_int_p,
+                                          _c_double_p]),
     "gl_log_degrees_fit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p,
                                      C.c_int64, C.c_double, C.c_double, C.c_double, C.c_void_p, _c_int64_p,
                                      _c_double_p]),

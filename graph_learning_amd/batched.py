@@ -5,10 +5,11 @@ shape (B, E) every array in the loop is (E, B) / (n, B), ``np.linalg.norm(M, ord
 SPECTRAL norm of the matrix, and all B graphs stop at the same iteration.  Used by
 ``WindowLogModel`` (temporal/smooth.py) and by the clustering M-steps.
 
-Here each graph is a device-resident solver session advancing in lockstep; after every iteration
-the four B x B Gram matrices of the updates are reduced on the GPU (``gl_logdeg_batch_gram``) and
-the spectral norms are ``sqrt(lambda_max)`` of them.  The per-iteration host round trip makes this
-path latency-bound; it is meant for the many-small-graphs regime the reference uses it in.
+Here each graph is a device-resident solver session; the lockstep loop runs inside the library
+(``gl_logdeg_batch_iterate``): per iteration 2 B launches, then only the B diagonal Gram entries come
+back -- lambda_max of a Gram matrix lies between its largest diagonal entry and its trace, which
+decides most iterations -- and the full B x B Gram matrices / eigenvalues are computed only when
+those bounds straddle ``tol`` and for the values reported at the end.
 """
 
 from __future__ import annotations
@@ -49,21 +50,10 @@ def learn_log_degrees_batch(distances, alpha, beta, edge_init=None, maxit=1000, 
             s.set_distances(distances[b])
             s.init(alpha, beta, step_size, None if edge_init is None else np.ascontiguousarray(edge_init[:, b]))
         handles = (C.c_void_p * n_batch)(*[s._h for s in sessions])
-        gram = np.empty((4, n_batch, n_batch))
-        rel_p = rel_d = np.inf
-        n_iter, converged = 0, False
-        for i in range(int(maxit)):
-            for s in sessions:
-                s.iterate_async(1)
-            n_iter = i + 1
-            if i > 0:  # :156-161
-                ctx.check(lib.gl_logdeg_batch_gram(handles, n_batch, _lib.ptr(gram)), "batch_gram")
-                with np.errstate(divide="ignore", invalid="ignore"):
-                    rel_p = np.float64(_spectral(gram[0])) / np.float64(_spectral(gram[1]))
-                    rel_d = np.float64(_spectral(gram[2])) / np.float64(_spectral(gram[3]))
-            if rel_p < tol and rel_d < tol:  # :166-167 (after the update, like the reference)
-                converged = True
-                break
+        n_it, conv, rel = C.c_int64(0), C.c_int(0), (C.c_double * 2)(np.inf, np.inf)
+        ctx.check(lib.gl_logdeg_batch_iterate(handles, n_batch, int(maxit), float(tol), C.byref(n_it), C.byref(conv), rel),
+                  "batch_iterate")
+        n_iter, converged, rel_p, rel_d = n_it.value, bool(conv.value), rel[0], rel[1]
         out = np.stack([s.weights_condensed(edge_tol) for s in sessions])  # (B, E) == edge_w.T (:174)
     finally:
         for s in sessions:

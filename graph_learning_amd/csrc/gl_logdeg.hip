@@ -697,6 +697,53 @@ __global__ __launch_bounds__(256) void k_pair_dots(const double *__restrict__ wa
             ((sh[threadIdx.x][0] + sh[threadIdx.x][1]) + sh[threadIdx.x][2]) + sh[threadIdx.x][3];
 }
 
+// The same four inner products for MANY pairs in one launch: blockIdx.y = pair index into `pairs`
+// (session indices a, b), operands through a table of per-session pointers.
+struct BatchPtrs {
+    const double *w_new, *w_old, *d_new, *d_old;
+};
+__global__ __launch_bounds__(256) void k_batch_dots(const BatchPtrs *__restrict__ ptrs, const int2 *__restrict__ pairs,
+                                                    int64_t n_tiled, int64_t n_nodes, double *__restrict__ part) {
+    __shared__ double sh[4][4];
+    const int2 pr = pairs[blockIdx.y];
+    const BatchPtrs A = ptrs[pr.x], Bq = ptrs[pr.y];
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_tiled; i += (int64_t)gridDim.x * 256) {
+        const double ao = A.w_old[i], bo = Bq.w_old[i];
+        s0 += (A.w_new[i] - ao) * (Bq.w_new[i] - bo);
+        s1 += ao * bo;
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = threadIdx.x; i < n_nodes; i += 256) {
+            s2 += (A.d_new[i] - A.d_old[i]) * (Bq.d_new[i] - Bq.d_old[i]);
+            s3 += A.d_old[i] * Bq.d_old[i];
+        }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    s3 = wave_sum(s3);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        sh[0][wave] = s0;
+        sh[1][wave] = s1;
+        sh[2][wave] = s2;
+        sh[3][wave] = s3;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + threadIdx.x] =
+            ((sh[threadIdx.x][0] + sh[threadIdx.x][1]) + sh[threadIdx.x][2]) + sh[threadIdx.x][3];
+}
+// out[pair][q] = sum over the blocks of part[pair][block][q], fixed order
+__global__ void k_batch_dots_reduce(const double *__restrict__ part, int npairs, int blocks, double *__restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npairs * 4) return;
+    const int pr = t >> 2, q = t & 3;
+    double acc = 0;
+    for (int k = 0; k < blocks; ++k) acc += part[((size_t)pr * blocks + k) * 4 + q];
+    out[t] = acc;
+}
+
 int check(gl_logdeg *s) { return (s && s->ctx) ? GL_OK : GL_E_INVALID; }
 
 // Where the column partials go.  The partition of the flat row-pair list over the
@@ -1220,6 +1267,200 @@ GL_API int gl_logdeg_batch_gram(gl_logdeg **sessions, int B, double *out) {
                 out[((size_t)q * B + a) * B + b] = acc;
                 out[((size_t)q * B + b) * B + a] = acc;
             }
+    return GL_OK;
+}
+
+namespace {
+// largest eigenvalue of a symmetric B x B matrix (cyclic Jacobi, in place); the matrices here are
+// Gram matrices, and np.linalg.norm(M, 2)^2 of the reference (:158-159) is exactly this value
+double sym_lambda_max(std::vector<double> &a, int B) {
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0, diag = 0;
+        for (int p = 0; p < B; ++p)
+            for (int q = 0; q < B; ++q) (p == q ? diag : off) += a[(size_t)p * B + q] * a[(size_t)p * B + q];
+        if (off <= 1e-32 * diag || off == 0.0) break;
+        for (int p = 0; p < B - 1; ++p)
+            for (int q = p + 1; q < B; ++q) {
+                const double apq = a[(size_t)p * B + q];
+                if (apq == 0.0) continue;
+                const double theta = (a[(size_t)q * B + q] - a[(size_t)p * B + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < B; ++k) {  // columns p, q
+                    const double akp = a[(size_t)k * B + p], akq = a[(size_t)k * B + q];
+                    a[(size_t)k * B + p] = c * akp - sn * akq;
+                    a[(size_t)k * B + q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < B; ++k) {  // rows p, q
+                    const double apk = a[(size_t)p * B + k], aqk = a[(size_t)q * B + k];
+                    a[(size_t)p * B + k] = c * apk - sn * aqk;
+                    a[(size_t)q * B + k] = sn * apk + c * aqk;
+                }
+            }
+    }
+    double m = a[0];
+    for (int p = 1; p < B; ++p) m = std::max(m, a[(size_t)p * B + p]);
+    return m;
+}
+}  // namespace
+
+// The 2-D (batched) branch of gsp_learn_graph_log_degrees (smooth_learning.py:128-129,146-167): B
+// graphs advance in lockstep and ALL stop at the iteration where both spectral-norm ratios
+//   ||Q - Y||_2 / ||W_old||_2  and  ||Qbar - Ybar||_2 / ||D_old||_2      ((E x B) and (n x B) matrices)
+// fall below tol.  The whole loop runs here.  One iteration of all graphs + the B diagonal Gram
+// entries + their copy to pinned memory are captured once per parity of the iteration count and
+// replayed (one graph launch and one sync per iteration).  lambda_max of a Gram matrix lies in
+// [max diagonal, trace], which decides most iterations without the off-diagonal inner products --
+// those (one launch for all pairs) and the B x B eigenproblems (Jacobi, host) are computed only when
+// the bounds straddle tol and for the values reported at the end.  (A fork / join graph with one
+// branch per session was measured 6x SLOWER than the serial chain on this runtime.)  Sessions must
+// share the context and n, be initialised and have run the same number of iterations.
+GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, double tol, int64_t *n_iter_out,
+                                   int *converged_out, double *rel_out) {
+    if (!sessions || B < 1) return GL_E_INVALID;
+    for (int a = 0; a < B; ++a) GL_TRY(check(sessions[a]));
+    gl_ctx *ctx = sessions[0]->ctx;
+    if (maxit < 0) return gl_set_error(ctx, GL_E_INVALID, "maxit < 0");
+    for (int a = 0; a < B; ++a) {
+        gl_logdeg *s = sessions[a];
+        if (s->ctx != ctx || s->n != sessions[0]->n)
+            return gl_set_error(ctx, GL_E_INVALID, "batched sessions must share the context and n_nodes");
+        if (!s->inited || s->it != sessions[0]->it)
+            return gl_set_error(ctx, GL_E_STATE, "batched sessions must be initialised and at the same iteration");
+    }
+    GL_HIP(ctx, hipSetDevice(ctx->device));
+    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int a = 0; a < B; ++a) {
+        GL_TRY(resident_check(sessions[a]));
+        GL_TRY(set_tol(sessions[a], 0.0));  // the per-graph rule never fires; the coupled rule is evaluated here
+        GL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // one pinned slot: let the copy land before the next
+    }
+    const LogdegDev &D0 = sessions[0]->dev;
+    const int64_t n_tiled = D0.ntiles * GL_TILE_ELEMS;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(64, (n_tiled + 2047) / 2048));
+    const int npairs = B * (B + 1) / 2;
+    // pair table: the B diagonal pairs first, then the strict upper triangle
+    std::vector<int2> pairs;
+    for (int a = 0; a < B; ++a) pairs.push_back(int2{a, a});
+    for (int a = 0; a < B; ++a)
+        for (int b = a + 1; b < B; ++b) pairs.push_back(int2{a, b});
+    std::vector<BatchPtrs> ptrs((size_t)2 * B);  // [parity of the iteration count after the step][session]
+    for (int par = 0; par < 2; ++par)
+        for (int a = 0; a < B; ++a) {
+            const LogdegDev &D = sessions[a]->dev;
+            ptrs[(size_t)par * B + a] = BatchPtrs{D.w[par], D.w[par ^ 1], D.dvar, D.dprev};
+        }
+    struct Scratch {
+        void *pairs = nullptr, *ptrs = nullptr, *part = nullptr, *out = nullptr;
+        ~Scratch() {
+            for (void *p : {pairs, ptrs, part, out})
+                if (p) (void)hipFree(p);
+        }
+    } sc;
+    GL_HIP(ctx, hipMalloc(&sc.pairs, pairs.size() * sizeof(int2)));
+    GL_HIP(ctx, hipMalloc(&sc.ptrs, ptrs.size() * sizeof(BatchPtrs)));
+    GL_HIP(ctx, hipMalloc(&sc.part, (size_t)npairs * blocks * 4 * 8));
+    GL_HIP(ctx, hipMalloc(&sc.out, (size_t)npairs * 4 * 8));
+    GL_HIP(ctx, hipMemcpyAsync(sc.pairs, pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    GL_HIP(ctx, hipMemcpyAsync(sc.ptrs, ptrs.data(), ptrs.size() * sizeof(BatchPtrs), hipMemcpyHostToDevice, ctx->stream));
+    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<double> host((size_t)npairs * 4);
+
+    auto exact = [&](double &rp, double &rd) -> int {  // spectral-norm ratios from the full Gram matrices
+        const int64_t it = sessions[0]->it;
+        k_batch_dots<<<dim3((unsigned)blocks, (unsigned)npairs), 256, 0, ctx->stream>>>(
+            (const BatchPtrs *)sc.ptrs + (size_t)(it & 1) * B, (const int2 *)sc.pairs, n_tiled, sessions[0]->n,
+            (double *)sc.part);
+        k_batch_dots_reduce<<<dim3((unsigned)((npairs * 4 + 255) / 256)), 256, 0, ctx->stream>>>((const double *)sc.part,
+                                                                                           npairs, blocks, (double *)sc.out);
+        GL_HIP(ctx, hipGetLastError());
+        GL_HIP(ctx, hipMemcpyAsync(host.data(), sc.out, (size_t)npairs * 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        double lam[4];
+        std::vector<double> g((size_t)B * B);
+        for (int q = 0; q < 4; ++q) {
+            for (int k = 0; k < npairs; ++k) {
+                const int2 pr = pairs[(size_t)k];
+                g[(size_t)pr.x * B + pr.y] = g[(size_t)pr.y * B + pr.x] = host[(size_t)k * 4 + q];
+            }
+            lam[q] = std::max(sym_lambda_max(g, B), 0.0);
+        }
+        rp = sqrt(lam[0]) / sqrt(lam[1]);  // inf / nan when the previous iterate is zero, like NumPy
+        rd = sqrt(lam[2]) / sqrt(lam[3]);
+        return GL_OK;
+    };
+
+    double *diag = (double *)ctx->pinned + 1024;
+    const bool use_graph = maxit >= 8 && !getenv("GRAPHLEARN_AMD_NO_GRAPH") &&
+                           (size_t)(1024 + 4 * B) * 8 <= ctx->pinned_bytes;
+    if ((size_t)(1024 + 4 * B) * 8 > ctx->pinned_bytes) return gl_set_error(ctx, GL_E_INVALID, "batch too large (B = %d)", B);
+    struct Graphs {
+        hipGraphExec_t g[2] = {nullptr, nullptr};
+        ~Graphs() {
+            for (hipGraphExec_t e : g)
+                if (e) (void)hipGraphExecDestroy(e);
+        }
+    } graphs;
+    auto step_and_diag = [&](int par_after) {
+        for (int a = 0; a < B; ++a) enqueue_iteration(sessions[a]);
+        k_batch_dots<<<dim3((unsigned)blocks, (unsigned)B), 256, 0, ctx->stream>>>(
+            (const BatchPtrs *)sc.ptrs + (size_t)par_after * B, (const int2 *)sc.pairs, n_tiled, sessions[0]->n,
+            (double *)sc.part);
+        k_batch_dots_reduce<<<dim3((unsigned)((B * 4 + 255) / 256)), 256, 0, ctx->stream>>>((const double *)sc.part, B, blocks,
+                                                                                      (double *)sc.out);
+        (void)hipMemcpyAsync(diag, sc.out, (size_t)B * 4 * 8, hipMemcpyDeviceToHost, ctx->stream);
+    };
+    if (use_graph)
+        for (int par = 0; par < 2; ++par) {
+            hipGraph_t graph = nullptr;
+            GL_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            step_and_diag(par);
+            hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+            if (e == hipSuccess) e = hipGraphInstantiate(&graphs.g[par], graph, nullptr, nullptr, 0);
+            if (graph) (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) return gl_set_error(ctx, GL_E_HIP, "batch graph capture failed: %s", hipGetErrorString(e));
+        }
+
+    double rp = std::numeric_limits<double>::infinity(), rd = rp;
+    bool have_exact = false, converged = false;
+    int64_t n_iter = 0;
+    for (int64_t i = 0; i < maxit; ++i) {
+        const int par_after = (int)((sessions[0]->it + 1) & 1);
+        if (use_graph)
+            GL_HIP(ctx, hipGraphLaunch(graphs.g[par_after], ctx->stream));
+        else
+            step_and_diag(par_after);
+        for (int a = 0; a < B; ++a) sessions[a]->it += 1;
+        GL_HIP(ctx, hipGetLastError());
+        GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        n_iter = i + 1;
+        have_exact = false;
+        if (i == 0) continue;  // :156 `if i > 0`
+        double mx[4] = {0, 0, 0, 0}, tr[4] = {0, 0, 0, 0};
+        for (int a = 0; a < B; ++a)
+            for (int q = 0; q < 4; ++q) {
+                mx[q] = std::max(mx[q], diag[(size_t)a * 4 + q]);
+                tr[q] += diag[(size_t)a * 4 + q];
+            }
+        const bool degenerate = !(mx[1] > 0) || !(mx[3] > 0);
+        // rel_p^2 in [mx0 / tr1, tr0 / mx1], rel_d^2 in [mx2 / tr3, tr2 / mx3]; a margin for rounding
+        const double t2 = tol * tol;
+        const bool surely_not = !degenerate && (mx[0] / tr[1] > t2 * (1 + 1e-9) || mx[2] / tr[3] > t2 * (1 + 1e-9));
+        if (surely_not) continue;
+        GL_TRY(exact(rp, rd));
+        have_exact = true;
+        if (rp < tol && rd < tol) {  // :166-167, after the update
+            converged = true;
+            break;
+        }
+    }
+    if (!have_exact && n_iter > 1) GL_TRY(exact(rp, rd));  // the values the caller sees
+    if (n_iter_out) *n_iter_out = n_iter;
+    if (converged_out) *converged_out = converged ? 1 : 0;
+    if (rel_out) {
+        rel_out[0] = rp;
+        rel_out[1] = rd;
+    }
     return GL_OK;
 }
 

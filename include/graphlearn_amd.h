@@ -125,6 +125,11 @@ int gl_logdeg_engine(gl_logdeg *s);
  * [<dw_a,dw_b>, <w_old_a,w_old_b>, <dd_a,dd_b>, <d_old_a,d_old_b>]); the caller takes
  * sqrt(lambda_max) of each for the stopping rule. */
 int gl_logdeg_batch_gram(gl_logdeg **sessions, int B, double *out);
+/* The whole coupled loop of the 2-D branch (smooth_learning.py:146-167 with :158-159 spectral norms):
+ * B initialised sessions (same context, same n, same iteration count) advance up to maxit iterations in
+ * lockstep and stop together; rel_out[2] = the two spectral-norm ratios of the last iteration. */
+int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, double tol, int64_t *n_iter_out,
+                            int *converged_out, double *rel_out);
 
 /* One-shot forms (what the reference-side binding calls). */
 /* gsp_learn_graph_log_degrees(distances, alpha, beta, edge_init, maxit, tol,
