@@ -144,15 +144,14 @@ __device__ __forceinline__ EdgeStep edge_step_at(int64_t p, int64_t pend) {
 // them would sit in the in-order vector-memory queue behind the prefetch just issued by the
 // previous slot, and waiting for them would cost a full memory round trip per slot.
 template <bool INIT, int ABL = 0>
-__global__ __launch_bounds__(64, GL_EDGE_WAVES_PER_SIMD) void k_edge(LogdegDev P, const double *__restrict__ dvar,
-                                                                     const double *__restrict__ pbar) {
+__device__ __forceinline__ void edge_body(const LogdegDev &P, const double *__restrict__ dvar,
+                                          const double *__restrict__ pbar, const int b) {
     if (!INIT && P.ctr[0] != 0) return;  // converged earlier: leave everything as is
     const long long it = INIT ? 0 : P.ctr[2];
 
     const int lane = threadIdx.x;
     const int half = lane >> 5;
     const int c0 = 2 * (lane & 31);
-    const int b = blockIdx.x;
     if (!INIT && b == 0 && lane == 0) P.ctr[3] = it;  // hand the index to the node pass
 
     const double *__restrict__ wsrc = P.w[it & 1];
@@ -379,6 +378,18 @@ __global__ __launch_bounds__(64, GL_EDGE_WAVES_PER_SIMD) void k_edge(LogdegDev P
     }
 }
 
+template <bool INIT, int ABL = 0>
+__global__ __launch_bounds__(64, GL_EDGE_WAVES_PER_SIMD) void k_edge(LogdegDev P, const double *__restrict__ dvar,
+                                                                     const double *__restrict__ pbar) {
+    edge_body<INIT, ABL>(P, dvar, pbar, (int)blockIdx.x);
+}
+// the same pass for a batch of problems of one size in ONE launch (blockIdx.y = problem): small
+// graphs then run side by side instead of one latency-bound launch after the other
+__global__ __launch_bounds__(64, GL_EDGE_WAVES_PER_SIMD) void k_edge_batch(const LogdegDev *__restrict__ devs) {
+    const LogdegDev P = devs[blockIdx.y];
+    edge_body<false, 0>(P, P.dvar, P.pbar, (int)blockIdx.x);
+}
+
 // ---------------------------------------------------------------------------
 // Node pass.  One workgroup (16 waves) per block of 64 nodes: lanes are nodes,
 // wave v sums every 16th slab entry, so all slab loads of a lane are in flight
@@ -389,13 +400,12 @@ __global__ __launch_bounds__(64, GL_EDGE_WAVES_PER_SIMD) void k_edge(LogdegDev P
 constexpr int NODE_WAVES = 16;
 
 template <bool INIT>
-__global__ __launch_bounds__(NODE_WAVES * 64) void k_node(LogdegDev P) {
+__device__ __forceinline__ void node_body(const LogdegDev &P, const int64_t B) {
     __shared__ double s_sum[2][NODE_WAVES][TB];
     __shared__ double s_red[2][NODE_WAVES];
     __shared__ int s_stop;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t B = blockIdx.x;
     long long it = 0;
     if (!INIT) {
         if (P.ctr[0] != 0) return;
@@ -523,6 +533,15 @@ __global__ __launch_bounds__(NODE_WAVES * 64) void k_node(LogdegDev P) {
             }
         }
     }
+}
+
+template <bool INIT>
+__global__ __launch_bounds__(NODE_WAVES * 64) void k_node(LogdegDev P) {
+    node_body<INIT>(P, (int64_t)blockIdx.x);
+}
+__global__ __launch_bounds__(NODE_WAVES * 64) void k_node_batch(const LogdegDev *__restrict__ devs) {
+    const LogdegDev P = devs[blockIdx.y];
+    node_body<false>(P, (int64_t)blockIdx.x);
 }
 
 // After a batch of launches: rel. changes of the last completed iteration, and
@@ -1307,13 +1326,15 @@ double sym_lambda_max(std::vector<double> &a, int B) {
 // The 2-D (batched) branch of gsp_learn_graph_log_degrees (smooth_learning.py:128-129,146-167): B
 // graphs advance in lockstep and ALL stop at the iteration where both spectral-norm ratios
 //   ||Q - Y||_2 / ||W_old||_2  and  ||Qbar - Ybar||_2 / ||D_old||_2      ((E x B) and (n x B) matrices)
-// fall below tol.  The whole loop runs here.  One iteration of all graphs + the B diagonal Gram
+// fall below tol.  The whole loop runs here.  One iteration of all graphs (two batched launches,
+// blockIdx.y = graph) + the B diagonal Gram
 // entries + their copy to pinned memory are captured once per parity of the iteration count and
 // replayed (one graph launch and one sync per iteration).  lambda_max of a Gram matrix lies in
 // [max diagonal, trace], which decides most iterations without the off-diagonal inner products --
 // those (one launch for all pairs) and the B x B eigenproblems (Jacobi, host) are computed only when
-// the bounds straddle tol and for the values reported at the end.  (A fork / join graph with one
-// branch per session was measured 6x SLOWER than the serial chain on this runtime.)  Sessions must
+// the bounds straddle tol and for the values reported at the end.  (Per-session launches cost
+// ~12 us per graph and iteration; a fork / join hipGraph with one branch per session was 6x
+// slower still on this runtime.)  Sessions must
 // share the context and n, be initialised and have run the same number of iterations.
 GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, double tol, int64_t *n_iter_out,
                                    int *converged_out, double *rel_out) {
@@ -1351,9 +1372,9 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
             ptrs[(size_t)par * B + a] = BatchPtrs{D.w[par], D.w[par ^ 1], D.dvar, D.dprev};
         }
     struct Scratch {
-        void *pairs = nullptr, *ptrs = nullptr, *part = nullptr, *out = nullptr;
+        void *pairs = nullptr, *ptrs = nullptr, *part = nullptr, *out = nullptr, *devs = nullptr;
         ~Scratch() {
-            for (void *p : {pairs, ptrs, part, out})
+            for (void *p : {pairs, ptrs, part, out, devs})
                 if (p) (void)hipFree(p);
         }
     } sc;
@@ -1363,6 +1384,10 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
     GL_HIP(ctx, hipMalloc(&sc.out, (size_t)npairs * 4 * 8));
     GL_HIP(ctx, hipMemcpyAsync(sc.pairs, pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
     GL_HIP(ctx, hipMemcpyAsync(sc.ptrs, ptrs.data(), ptrs.size() * sizeof(BatchPtrs), hipMemcpyHostToDevice, ctx->stream));
+    std::vector<LogdegDev> devs((size_t)B);  // the problems' device descriptors, for the batched launches
+    for (int a = 0; a < B; ++a) devs[(size_t)a] = sessions[a]->dev;
+    GL_HIP(ctx, hipMalloc(&sc.devs, devs.size() * sizeof(LogdegDev)));
+    GL_HIP(ctx, hipMemcpyAsync(sc.devs, devs.data(), devs.size() * sizeof(LogdegDev), hipMemcpyHostToDevice, ctx->stream));
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<double> host((size_t)npairs * 4);
 
@@ -1402,7 +1427,8 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
         }
     } graphs;
     auto step_and_diag = [&](int par_after) {
-        for (int a = 0; a < B; ++a) enqueue_iteration(sessions[a]);
+        k_edge_batch<<<dim3((unsigned)D0.G, (unsigned)B), dim3(64), 0, ctx->stream>>>((const LogdegDev *)sc.devs);
+        k_node_batch<<<dim3((unsigned)D0.nb, (unsigned)B), dim3(NODE_WAVES * 64), 0, ctx->stream>>>((const LogdegDev *)sc.devs);
         k_batch_dots<<<dim3((unsigned)blocks, (unsigned)B), 256, 0, ctx->stream>>>(
             (const BatchPtrs *)sc.ptrs + (size_t)par_after * B, (const int2 *)sc.pairs, n_tiled, sessions[0]->n,
             (double *)sc.part);
