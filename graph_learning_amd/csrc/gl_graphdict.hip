@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64) void k_gd_grad_c(const double *__restrict__ XT,
 template <int KP, int SW>
 __global__ __launch_bounds__(256, 3) void k_gd_grad_w(const double *__restrict__ X, const double *__restrict__ CT,
                                                    double *__restrict__ GS, const int2 *__restrict__ tasks, int ntasks,
-                                                   int n_pad, int Tp, int tchunk, int exp_, double *dbg) {
+                                                   int n_pad, int Tp, int tchunk, double *dbg) {
     // the four waves of a workgroup take a quarter of the split's samples each and add their
     // partial sums through LDS: finer tasks (even load per SIMD) without more slabs in HBM
     __shared__ double2 s_red[3][KP / 2][64];
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, 3) void k_gd_grad_w(const double *__restrict__
     const int tA0 = ts * tchunk, tB0 = min(Tp, tA0 + tchunk);
     const int sub = (max(tB0 - tA0, 0) + 3) / 4;
     const int tA = tA0 + wave * sub, tB = min(tB0, tA + sub);
-    const unsigned long long rt0 = (exp_ & 8) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long rt0 = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // Software pipeline over the samples: the wave-uniform operands of sample t + 1 (SW node values,
     // KP coefficients: scalar loads, which return out of order and can only be waited for all
     // together) are requested right after the wait for those of sample t and land while t computes.
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, 3) void k_gd_grad_w(const double *__restrict__
         }
         if (t < tB) accumulate(xiA, cfA, xjA);
     }
-    if ((exp_ & 8) && lane == 0) {  // tuning aid: per-wave (start, end) in 10 ns ticks
+    if (dbg && lane == 0) {  // tuning aid (GRAPHLEARN_AMD_GD_PROBE=1): per-wave (start, end) in 10 ns ticks
         const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
         const int64_t w = (int64_t)blockIdx.x * 4 + wave;
         dbg[4 * w + 0] = (double)rt0;
@@ -648,13 +648,11 @@ int gd_launch_grad_w(gl_graphdict *s) {
     const GdDev &P = s->dev;
     const int tchunk = (P.Tp + P.TS - 1) / P.TS;
     hipStream_t st = s->ctx->stream;
-    int ex = getenv("GD_EXP") ? atoi(getenv("GD_EXP")) : 0;
-    if (!s->dbgbuf) ex &= ~8;
     dim3 grid((unsigned)(P.nwtasks * P.TS));
     switch (P.KP) {
-        case 4: k_gd_grad_w<4, 8><<<grid, 256, 0, st>>>(P.X, P.CT, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, ex, s->dbgbuf); break;
-        case 8: k_gd_grad_w<8, 8><<<grid, 256, 0, st>>>(P.X, P.CT, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, ex, s->dbgbuf); break;
-        default: k_gd_grad_w<16, 4><<<grid, 256, 0, st>>>(P.X, P.CT, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, ex, s->dbgbuf); break;
+        case 4: k_gd_grad_w<4, 8><<<grid, 256, 0, st>>>(P.X, P.CT, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, s->dbgbuf); break;
+        case 8: k_gd_grad_w<8, 8><<<grid, 256, 0, st>>>(P.X, P.CT, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, s->dbgbuf); break;
+        default: k_gd_grad_w<16, 4><<<grid, 256, 0, st>>>(P.X, P.CT, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, s->dbgbuf); break;
     }
     GL_HIP(s->ctx, hipGetLastError());
     return GL_OK;
@@ -762,7 +760,7 @@ GL_API int gl_graphdict_create(gl_ctx *ctx, int64_t n_nodes, int64_t n_samples, 
         return rc;
     }
     GL_HIP(ctx, hipMemcpyAsync(P.wtasks, tasks.data(), tasks.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
-    if (getenv("GD_EXP") && (atoi(getenv("GD_EXP")) & 8))
+    if (getenv("GRAPHLEARN_AMD_GD_PROBE"))
         (void)gd_alloc(s, &s->dbgbuf, (size_t)16 * P.nwtasks * P.TS);
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out = s;

@@ -158,3 +158,39 @@ def test_sklearn_surface():
     m = GraphDictLog(n_atoms=2, l1_w=0.1, window_size=2)
     p = m.get_params()
     assert p["n_atoms"] == 2 and p["l1_w"] == 0.1 and p["window_size"] == 2
+
+
+def test_baseline_config5_size_first_step_closed_form():
+    """BASELINE config 5 (K = 8 atoms, n = 1024 nodes, T = 4096 samples): the reference cannot allocate this
+    case (17 GB of squared differences), so the check is a size-independent property.  With dual = 0 the
+    first step has a closed form per entry (base_model.py:375-400,447-459):
+        c1[k,t] = clip(c0 - step_c/T (sum_e W0[k,e] (x_ti - x_tj)^2 + l1_c T), 0, 1)
+        w1[k,e] = max(0, w0 - step_w/T (sum_t C0[k,t] (x_ti - x_tj)^2 + l1_w T))
+    evaluated here in NumPy for sampled samples t / edges e, plus range invariants of the state."""
+    n, t, k = 1024, 4096, 8
+    e = n * (n - 1) // 2
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((t, n)) * 0.3
+    rs = np.random.RandomState(0)
+    c0, w0 = rs.uniform(size=(k, t)), rs.uniform(size=(k, e)) * 0.01
+    par = dict(l1_w=0.02, l1_c=0.01, step_c=0.5, step_w=0.25, step_dual=0.5)
+    with _lib.GraphDictSession(n, t, k) as s:
+        s.set_signals(x)
+        s.set_params(**par)
+        s.set_state(c0, w0)
+        hist, ran, conv, flags = s.fit(1, 0.0)
+        c1, w1, d1 = s.get_state()
+    assert ran == 1 and np.isfinite(hist[0]).all()
+    iu = np.triu_indices(n, k=1)
+    for ts in rng.integers(0, t, size=6):
+        sq = (x[ts, iu[0]] - x[ts, iu[1]]) ** 2
+        want = np.clip(c0[:, ts] - par["step_c"] / t * (w0 @ sq + par["l1_c"] * t), 0, 1)
+        np.testing.assert_allclose(c1[:, ts], want, rtol=1e-10, atol=1e-12)
+    for es in rng.integers(0, e, size=64):
+        sq = (x[:, iu[0][es]] - x[:, iu[1][es]]) ** 2
+        want = np.maximum(w0[:, es] - par["step_w"] / t * (c0 @ sq + par["l1_w"] * t), 0)
+        np.testing.assert_allclose(w1[:, es], want, rtol=1e-10, atol=1e-13)
+    assert (w1 >= 0).all() and (c1 >= 0).all() and (c1 <= 1).all() and (d1 < 0).all()  # log-barrier prox: dual < 0
+    # relative changes reported by the step = the reference's relative_error(old, new)
+    assert hist[0, 0] == pytest.approx(np.linalg.norm(c1 - c0) / np.linalg.norm(c0), rel=1e-10)
+    assert hist[0, 1] == pytest.approx(np.linalg.norm(w1 - w0) / np.linalg.norm(w0), rel=1e-10)
