@@ -17,6 +17,7 @@
 // wave-wide 16-B load); a persistent grid of G = 8 x #CU single-wave workgroups
 // takes equal contiguous ranges of it, so every CU streams the same number of
 // bytes and the launch has no tail.
+#include "gl_lanes.h"
 #include "gl_logdeg.h"
 
 #include <algorithm>
@@ -38,58 +39,6 @@ constexpr int PAIRS_PER_TILE = TB / 2;
 constexpr int LAYOUT_ROWS = 8;        // layout kernels: lane = 2 columns x 8 rows (256 threads per tile)
 constexpr int ITER_BATCH = 64;       // iterations per captured graph / per convergence poll
 
-__device__ __forceinline__ double shfl_xor_d(double v, int mask) { return __shfl_xor(v, mask, 64); }
-
-// Sum v[0..7] (row partials of 8 different rows) across the 32 lanes of each
-// half-wave with a halving butterfly: 4+2+1+1+1 exchanges instead of 8*5.
-// On return every lane holds the complete sum of row k = (lane >> 2) & 7.
-__device__ __forceinline__ double halfwave_rows8(const double (&v)[8], int lane) {
-    const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
-    double a[4], b[2], c;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        double keep = b4 ? v[m + 4] : v[m];
-        double send = b4 ? v[m] : v[m + 4];
-        a[m] = keep + shfl_xor_d(send, 16);
-    }
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        double keep = b3 ? a[m + 2] : a[m];
-        double send = b3 ? a[m] : a[m + 2];
-        b[m] = keep + shfl_xor_d(send, 8);
-    }
-    {
-        double keep = b2 ? b[1] : b[0];
-        double send = b2 ? b[0] : b[1];
-        c = keep + shfl_xor_d(send, 4);
-    }
-    c += shfl_xor_d(c, 2);
-    c += shfl_xor_d(c, 1);
-    return c;
-}
-
-// Same for 4 rows per half-wave: 2+1 halving exchanges, then 3 full ones.
-// On return every lane holds the complete sum of row k = (lane >> 3) & 3.
-__device__ __forceinline__ double halfwave_rows4(const double (&v)[4], int lane) {
-    const bool b4 = lane & 16, b3 = lane & 8;
-    double a[2], c;
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        double keep = b4 ? v[m + 2] : v[m];
-        double send = b4 ? v[m] : v[m + 2];
-        a[m] = keep + shfl_xor_d(send, 16);
-    }
-    {
-        double keep = b3 ? a[1] : a[0];
-        double send = b3 ? a[0] : a[1];
-        c = keep + shfl_xor_d(send, 8);
-    }
-    c += shfl_xor_d(c, 4);
-    c += shfl_xor_d(c, 2);
-    c += shfl_xor_d(c, 1);
-    return c;
-}
-
 template <int R>
 struct RowReduce;
 template <>
@@ -105,11 +54,6 @@ struct RowReduce<4> {
     static __device__ __forceinline__ bool writer(int lane) { return (lane & 7) == 0; }
 };
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_d(v, m);
-    return v;
-}
 
 // ---------------------------------------------------------------------------
 // Edge pass.  Every WAVE is an autonomous worker (workgroup = one wave, no LDS, no
@@ -333,8 +277,8 @@ __device__ __forceinline__ void edge_body(const LogdegDev &P, const double *__re
             } else {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    colp[e] += shfl_xor_d(colp[e], 32);
-                    colw[e] += shfl_xor_d(colw[e], 32);
+                    colp[e] = add_xor32(colp[e]);
+                    colw[e] = add_xor32(colw[e]);
                 }
                 if (half == 0) {
                     const int64_t ent = P.seg_dest[(int64_t)b * P.kmax + seg];

@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "gl_gridbar.h"
+#include "gl_lanes.h"
 #include "gl_logdeg.h"
 
 #ifndef GL_RES_MIN_BULK_TILES
@@ -50,78 +51,6 @@ __device__ __forceinline__ double ld_sc1(const double *p) {
 }
 __device__ __forceinline__ void st_sc1(double *p, double v) {
     __hip_atomic_store((u64 *)p, (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double shfl_xor_d(double v, int mask) { return __shfl_xor(v, mask, 64); }
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_d(v, m);
-    return v;
-}
-// sum over the 32 lanes of each half-wave (result in every lane of the half)
-__device__ __forceinline__ double half_sum(double v) {
-#pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) v += shfl_xor_d(v, m);
-    return v;
-}
-// 8 row partials -> complete row sums across each half-wave (see gl_logdeg.hip)
-// ---- cross-lane exchanges on the VALU (DPP / gfx950 permlane swaps): a few cycles of latency, where
-//      ds_bpermute (what __shfl_xor compiles to) costs an LDS round trip per exchange and leaves the
-//      reduction butterflies latency-bound at 2 waves per SIMD.  Lane maps verified on hardware.
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(double v) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-constexpr int DPP_ROW_ROR8 = 0x128;     // lane i <- lane i ^ 8 (rows of 16 lanes)
-constexpr int DPP_HALF_MIRROR = 0x141;  // lane i <- lane 7 - i (groups of 8 lanes)
-constexpr int DPP_QUAD_XOR2 = 0x4E;     // quad_perm [2,3,0,1]
-constexpr int DPP_QUAD_XOR1 = 0xB1;     // quad_perm [1,0,3,2]
-
-// v_permlane16_swap(X, Y): X's odd 16-lane rows <-> Y's even rows.  The sum of its two results is
-//   even-row lane l:  x[l] + x[l + 16]        odd-row lane l:  y[l - 16] + y[l]
-// i.e. one halving step of the butterfly (even rows keep x, odd rows keep y) with no select at all.
-__device__ __forceinline__ double swap16_halve(double x, double y) {
-    const long long xb = __double_as_longlong(x), yb = __double_as_longlong(y);
-    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)xb, (unsigned)yb, false, false);
-    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(xb >> 32), (unsigned)(yb >> 32), false, false);
-    const double r0 = __longlong_as_double(((long long)hi[0] << 32) | lo[0]);
-    const double r1 = __longlong_as_double(((long long)hi[1] << 32) | lo[1]);
-    return r0 + r1;
-}
-// v + (v of lane ^ 32) in every lane, through v_permlane32_swap (lower / upper half exchange)
-__device__ __forceinline__ double add_xor32(double v) {
-    const long long b = __double_as_longlong(v);
-    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
-    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
-    const double r0 = __longlong_as_double(((long long)hi[0] << 32) | lo[0]);
-    const double r1 = __longlong_as_double(((long long)hi[1] << 32) | lo[1]);
-    return r0 + r1;
-}
-
-// Sums of 8 per-lane values over the 32 lanes of a half-wave, "halving" butterfly: every step
-// exchanges half of what is left, so 4 + 2 + 1 + 1 + 1 = 9 exchanges instead of 8 x 5.  Afterwards
-// lane l holds the total of value ((l >> 2) & 7) of its half-wave.
-__device__ __forceinline__ double halfwave_rows8(const double (&v)[8], int lane) {
-    const bool b3 = lane & 8, b2 = lane & 4;
-    double a[4], b[2], c;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) a[m] = swap16_halve(v[m], v[m + 4]);  // even rows keep m, odd rows m + 4
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const double keep = b3 ? a[m + 2] : a[m];
-        const double send = b3 ? a[m] : a[m + 2];
-        b[m] = keep + dpp_mov<DPP_ROW_ROR8>(send);
-    }
-    {
-        const double keep = b2 ? b[1] : b[0];
-        const double send = b2 ? b[0] : b[1];
-        c = keep + dpp_mov<DPP_HALF_MIRROR>(send);  // partner 7 - i instead of i ^ 4: also across bit 2
-    }
-    c += dpp_mov<DPP_QUAD_XOR2>(c);
-    c += dpp_mov<DPP_QUAD_XOR1>(c);
-    return c;
 }
 
 struct ResDev {
@@ -379,10 +308,10 @@ __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
                     st_sc1(P.rowslab_w + idx, rw);
                 }
             }
-            colp0 += shfl_xor_d(colp0, 32);
-            colp1 += shfl_xor_d(colp1, 32);
-            colw0 += shfl_xor_d(colw0, 32);
-            colw1 += shfl_xor_d(colw1, 32);
+            colp0 = add_xor32(colp0);
+            colp1 = add_xor32(colp1);
+            colw0 = add_xor32(colw0);
+            colw1 = add_xor32(colw1);
             if (half == 0) {
                 double *dst = P.colslab + (int64_t)P.col_ent[P.F + slot * P.KF + seg] * (2 * TB) + c0;
                 st_sc1(dst, colp0);
