@@ -22,6 +22,7 @@
 // Weights live in WS: n_pad x n_pad x KP doubles, entry (i, j, k) for i < j < n, zero elsewhere
 // (the zero lower triangle doubles as the mask of the pair loops).  KP = K rounded up to 4/8/16.
 #include "gl_common.h"
+#include "gl_lanes.h"
 
 #include <algorithm>
 #include <limits>
@@ -65,11 +66,7 @@ struct GdDev {
     double l1_w, ortho_w, l1_c, log_c, l1_diff_c, step_c, step_w, step_dual;
 };
 
-__device__ __forceinline__ double gd_wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ double gd_wave_sum(double v) { return wave_sum(v); }  // gl_lanes.h
 __device__ __forceinline__ double gd_wave_max(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));

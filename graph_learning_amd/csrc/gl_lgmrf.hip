@@ -30,16 +30,13 @@
 
 #include "gl_common.h"
 #include "gl_gridbar.h"
+#include "gl_lanes.h"
 
 namespace {
 
 constexpr int VT = 1024;  // threads of the single-workgroup vector kernels
 
-__device__ __forceinline__ double wsum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
+__device__ __forceinline__ double wsum(double v) { return wave_sum(v); }  // gl_lanes.h: DPP / permlane swaps
 __device__ __forceinline__ double wmax(double v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
