@@ -225,6 +225,7 @@ __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
     // ---- my share of the fringe (row pairs of diagonal / ragged tiles)
     const int64_t fr0 = (int64_t)slot * P.R / P.S, fr1 = (int64_t)(slot + 1) * P.R / P.S;
 
+    const int my_e0 = wg < P.nb ? P.col_ptr[wg] : 0, my_e1 = wg < P.nb ? P.col_ptr[wg + 1] : 0;
     const GlGridBar gb{P.bar, P.rendezvous};
     GlBarState bs{};
     if (tid == 0) s_ok = gl_barrier_setup(gb, bs) ? 1 : 0;
@@ -344,7 +345,9 @@ __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
                 rp[u] = on ? ld_sc1(P.rowslab_p + Jb * P.n_pad + i) : 0.0;
                 rw[u] = on ? ld_sc1(P.rowslab_w + Jb * P.n_pad + i) : 0.0;
             }
-            const int e0 = P.col_ptr[B], e1 = P.col_ptr[B + 1];
+            // colslab range of the block: known before the loop for the workgroup's first block, so the
+            // slab loads below do not wait for an index load
+            const int e0 = B == wg ? my_e0 : P.col_ptr[B], e1 = B == wg ? my_e1 : P.col_ptr[B + 1];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {  // column partials of the tiles (Ib, B)
                 const int e = e0 + wave + u * RW;
