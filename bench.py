@@ -187,7 +187,10 @@ def main():
                          "kernel": kernel, "iterations_per_launch": its_per_launch,
                          "algorithmic_bytes_per_launch": launch_bytes, "avg_launch_us": launch_us,
                          "traffic_source": "profiles/r01_rocprof_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                           "FETCH x2 per MI355X_MICROARCH.md)" if traffic else None},
+                                           "FETCH x2 per MI355X_MICROARCH.md)" if traffic else None,
+                         # the resident engine does not stream the iterate: its real fabric traffic is below the
+                         # algorithmic 24 E bytes, so `frac` (algorithmic bytes / time / peak) can exceed 1
+                         "measured_traffic_rate": (traffic / (launch_us * 1e-6) / 1e9) if traffic else None},
         }
         if not args.no_cpu_baseline:
             z = sess.get_distances() * theta
