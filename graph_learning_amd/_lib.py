@@ -294,8 +294,8 @@ class LogDegreeSession:
 
     @property
     def engine(self) -> str:
-        """"resident" or "stream": the engine long iterate calls of this session run on."""
-        return "resident" if self._lib.gl_logdeg_engine(self._h) == 1 else "stream"
+        """"resident", "small" or "stream": the engine long iterate calls of this session run on."""
+        return {1: "resident", 2: "small"}.get(self._lib.gl_logdeg_engine(self._h), "stream")
 
     def time_edge_pass(self, reps=200) -> float:
         """Average edge-pass duration in microseconds (HIP events; state unchanged)."""

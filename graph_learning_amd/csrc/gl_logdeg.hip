@@ -804,6 +804,19 @@ int launch_iterations(gl_logdeg *s, int64_t count) {
 
 }  // namespace
 
+int gl_logdeg_tiled_to_condensed(gl_logdeg *s, const double *src_tiled, double *dst_condensed) {
+    k_to_condensed<<<dim3((unsigned)s->dev.ntiles), dim3(256), 0, s->ctx->stream>>>(
+        src_tiled, dst_condensed, s->n, s->dev.nb, -std::numeric_limits<double>::infinity());
+    GL_HIP(s->ctx, hipGetLastError());
+    return GL_OK;
+}
+int gl_logdeg_condensed_to_tiled(gl_logdeg *s, const double *src_condensed, double *dst_tiled) {
+    k_to_tiled<0><<<dim3((unsigned)s->dev.ntiles), dim3(256), 0, s->ctx->stream>>>(src_condensed, dst_tiled, s->n, s->dev.nb,
+                                                                                  1.0);
+    GL_HIP(s->ctx, hipGetLastError());
+    return GL_OK;
+}
+
 // ===========================================================================
 GL_API int gl_logdeg_create(gl_ctx *ctx, int64_t n_nodes, gl_logdeg **out) {
     if (!ctx || !out) return GL_E_INVALID;
@@ -863,6 +876,7 @@ GL_API int gl_logdeg_destroy(gl_logdeg *s) {
         (void)hipStreamSynchronize(s->ctx->stream);
     }
     drop_graph(s);
+    gl_small_free(s);
     gl_resident_free(s);
     LogdegDev &D = s->dev;
     void *ptrs[] = {D.w[0], D.w[1], const_cast<double *>(D.z), D.dvar, D.dprev, D.ybar, D.pbar, D.rowslab_p, D.rowslab_w,
@@ -885,6 +899,7 @@ GL_API int gl_logdeg_set_distances(gl_logdeg *s, const double *z_condensed) {
     GL_HIP(ctx, hipGetLastError());
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     s->have_z = true;
+    gl_small_invalidate_z(s);
     s->have_zsq = false;
     s->theta = 1.0;
     s->inited = false;
@@ -922,6 +937,7 @@ GL_API int gl_logdeg_set_signals(gl_logdeg *s, const double *x, int64_t d, int64
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     s->theta = theta;
     s->have_z = true;
+    gl_small_invalidate_z(s);
     s->have_zsq = true;
     s->inited = false;
     if (theta_out) *theta_out = theta;
@@ -984,6 +1000,7 @@ GL_API int gl_logdeg_init(gl_logdeg *s, double alpha, double beta, double step_s
 
 // The resident engine (gl_resident.hip) takes over when it applies and the call is long enough
 // to amortise loading / storing the register-held iterate.  GRAPHLEARN_AMD_ENGINE=stream disables it.
+static bool use_small(const gl_logdeg *s, int64_t iters) { return iters >= 8 && gl_small_applicable(s); }
 static bool use_resident(const gl_logdeg *s, int64_t iters) { return s->res != nullptr && iters >= 16; }
 
 // error word of an earlier asynchronous resident launch (read at the next synchronising call)
@@ -1022,6 +1039,12 @@ GL_API int gl_logdeg_iterate_async(gl_logdeg *s, int64_t n_iter) {
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the pinned tol slot may still be in flight
     GL_TRY(resident_check(s));
     GL_TRY(set_tol(s, 0.0));
+    if (use_small(s, n_iter)) {  // tol = 0 never stops: the iteration count is known now
+        GL_TRY(gl_small_launch(s, n_iter, 0.0));
+        GL_HIP(ctx, hipMemsetAsync(s->dev.ctr, 0, 2 * 8, ctx->stream));
+        s->it += n_iter;
+        return GL_OK;
+    }
     if (use_resident(s, n_iter)) {
         // tol = 0 never stops: the iteration count and the parity of the final buffer are known now
         GL_TRY(gl_resident_launch(s, n_iter, 0.0));
@@ -1051,6 +1074,23 @@ GL_API int gl_logdeg_iterate(gl_logdeg *s, int64_t maxit, double tol, int64_t *n
     GL_TRY(resident_check(s));
     LogdegDev &D = s->dev;
     GL_TRY(set_tol(s, tol));
+    if (use_small(s, maxit)) {
+        double *st = (double *)ctx->pinned;
+        long long *ct = (long long *)(st + 8);
+        GL_TRY(gl_small_launch(s, maxit, tol));
+        GL_HIP(ctx, hipMemcpyAsync(st, D.dstat, 2 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        GL_HIP(ctx, hipMemcpyAsync(ct, D.ctr, 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        GL_HIP(ctx, hipMemsetAsync(D.ctr, 0, 2 * 8, ctx->stream));  // the done flag belongs to this call
+        GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (n_iter_out) *n_iter_out = (int64_t)ct[1] - s->it;
+        if (converged_out) *converged_out = ct[0] != 0 ? 1 : 0;
+        if (rel_out) {
+            rel_out[0] = st[0];
+            rel_out[1] = st[1];
+        }
+        s->it = (int64_t)ct[1];
+        return GL_OK;
+    }
     if (use_resident(s, maxit)) {
         double *st = (double *)ctx->pinned;
         int64_t ran = 0;
@@ -1438,7 +1478,11 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
 // events on the solver's stream over `reps` back-to-back launches.  The iteration counter is not
 // advanced, so every launch recomputes the same pass (reads w[it&1], writes w[(it+1)&1]) and the
 // session state is unchanged.
-GL_API int gl_logdeg_engine(gl_logdeg *s) { return s && s->res ? 1 : 0; }
+GL_API int gl_logdeg_engine(gl_logdeg *s) {
+    if (!s) return 0;
+    if (s->inited && gl_small_applicable(s)) return 2;
+    return s->res ? 1 : 0;
+}
 
 GL_API int gl_logdeg_time_edge_pass(gl_logdeg *s, int reps, double *avg_us_out) {
     GL_TRY(check(s));

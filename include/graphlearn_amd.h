@@ -114,8 +114,9 @@ int gl_logdeg_time_edge_pass(gl_logdeg *s, int reps, double *avg_us_out);
 /* Which iteration engine serves long gl_logdeg_iterate / _async calls of this session (after
  * gl_logdeg_init): 0 = streaming (one edge-pass + one node-pass launch per iteration, iterate in
  * HBM), 1 = resident (one persistent launch per call, iterate held in registers / LDS, grid
- * barriers; chosen when the lattice fits the register files and is large enough to pay off;
- * GRAPHLEARN_AMD_ENGINE=stream|resident overrides).  Same iterates up to summation order. */
+ * barriers; chosen when the lattice fits the register files and is large enough to pay off),
+ * 2 = small (n <= 128: one workgroup, the whole problem in LDS / registers, one launch per call).
+ * GRAPHLEARN_AMD_ENGINE=stream|resident|small overrides.  Same iterates up to summation order. */
 int gl_logdeg_engine(gl_logdeg *s);
 
 /* Batched (2-D) path of gsp_learn_graph_log_degrees (smooth_learning.py:128-129,158-159):

@@ -25,11 +25,12 @@ ATOL = 1e-10
 CASES = ["logmodel_n7_d23", "logmodel_n16_d40", "logmodel_n64_d256"]
 
 
-@pytest.fixture(autouse=True, params=["stream", "resident"])
+@pytest.fixture(autouse=True, params=["stream", "resident", "small"])
 def engine(request, monkeypatch):
-    """Every test of this file runs on both iteration engines: the streaming one (one edge-pass +
-    one node-pass launch per iteration) and the resident one (iterate held in registers / LDS,
-    grid barriers; by default only chosen for n >~ 2400, forced here)."""
+    """Every test of this file runs on the three iteration engines: streaming (one edge-pass + one
+    node-pass launch per iteration), resident (iterate held in registers / LDS, grid barriers; by default
+    only chosen for n >~ 2400, forced here) and small (n <= 128: one workgroup, one launch per call; where
+    it does not apply the automatic choice takes over)."""
     monkeypatch.setenv("GRAPHLEARN_AMD_ENGINE", request.param)
     return request.param
 
