@@ -1,6 +1,8 @@
 // Development probe: which part of the edge pass costs what?  Includes the product kernel source
 // and times ablated instantiations (results are WRONG by construction; timing only).
 //   ./edge_ablate [n=4096] [reps=300]
+// build (from graph_learning_amd/csrc): hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I../../include -I. \
+//   ../../tools/edge_ablate.hip gl_ctx.hip gl_gram.hip gl_theta.hip gl_resident.hip gl_small.hip -o ../../tools/edge_ablate -ldl
 #include "../graph_learning_amd/csrc/gl_logdeg.hip"
 #include <chrono>
 
