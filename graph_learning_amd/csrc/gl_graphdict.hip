@@ -590,11 +590,22 @@ struct gl_graphdict {
     double *stage = nullptr;  // device staging for host <-> device transfers of W (K x E) / x (T x n)
     size_t stage_elems = 0;
     bool have_x = false, have_state = false;
+    // one step (memset + 14 kernels + copy of the status words) captured per parity of the degree
+    // ping-pong and replayed: one graph launch per step instead of 16 enqueues (matters below ~1 ms/step)
+    hipGraphExec_t step_graph[2] = {nullptr, nullptr};
+    int step_parity = 0;  // which of (deg, deg_new) is current: flips with every step
     double *dbgbuf = nullptr;  // tuning aid (GD_EXP & 8): 4 doubles per wave of k_gd_grad_w
     std::vector<void *> allocs;
 };
 
 namespace {
+
+void gd_drop_graphs(gl_graphdict *s) {
+    for (hipGraphExec_t &g : s->step_graph) {
+        if (g) (void)hipGraphExecDestroy(g);
+        g = nullptr;
+    }
+}
 
 int gd_check(gl_graphdict *s) {
     if (!s || !s->ctx) return GL_E_INVALID;
@@ -689,6 +700,43 @@ int gd_step(gl_graphdict *s) {
     k_gd_coef_stat<<<1, 64, 0, st>>>(P, cb);
     GL_HIP(ctx, hipGetLastError());
     std::swap(P.deg, P.deg_new);
+    s->step_parity ^= 1;
+    return GL_OK;
+}
+
+// one step + the copy of the status words to pinned memory, through the captured graph of the current
+// parity (captured on first use; the kernels' arguments -- pointers, regularisers, step sizes -- are
+// frozen in it, so set_params and the plateau rule drop the graphs)
+int gd_step_replayed(gl_graphdict *s, double *pinned_stat) {
+    gl_ctx *ctx = s->ctx;
+    GdDev &P = s->dev;
+    if (getenv("GRAPHLEARN_AMD_NO_GRAPH")) {
+        GL_HIP(ctx, hipMemsetAsync(P.stat + 2, 0, 8, ctx->stream));
+        GL_TRY(gd_step(s));
+        GL_HIP(ctx, hipMemcpyAsync(pinned_stat, P.stat, 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        return GL_OK;
+    }
+    const int par = s->step_parity;
+    if (!s->step_graph[par]) {
+        hipGraph_t graph = nullptr;
+        GL_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        (void)hipMemsetAsync(P.stat + 2, 0, 8, ctx->stream);
+        const int rc = gd_step(s);  // flips the parity and the degree buffers: undone below, replay redoes it
+        (void)hipMemcpyAsync(pinned_stat, P.stat, 4 * 8, hipMemcpyDeviceToHost, ctx->stream);
+        hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+        std::swap(P.deg, P.deg_new);
+        s->step_parity ^= 1;
+        if (rc != GL_OK) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        if (e == hipSuccess) e = hipGraphInstantiate(&s->step_graph[par], graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) return gl_set_error(ctx, GL_E_HIP, "step graph capture failed: %s", hipGetErrorString(e));
+    }
+    GL_HIP(ctx, hipGraphLaunch(s->step_graph[par], ctx->stream));
+    std::swap(P.deg, P.deg_new);
+    s->step_parity ^= 1;
     return GL_OK;
 }
 
@@ -770,6 +818,7 @@ GL_API void gl_graphdict_destroy(gl_graphdict *s) {
         (void)hipSetDevice(s->ctx->device);
         (void)hipStreamSynchronize(s->ctx->stream);
     }
+    gd_drop_graphs(s);
     for (void *p : s->allocs) (void)hipFree(p);
     delete s;
 }
@@ -840,8 +889,11 @@ GL_API int gl_graphdict_set_params(gl_graphdict *s, double l1_w, double ortho_w,
     if (!(step_c > 0) || !(step_w > 0) || !(step_dual > 0))
         return gl_set_error(s->ctx, GL_E_INVALID, "step sizes must be positive");
     GdDev &P = s->dev;
+    const bool same = P.l1_w == l1_w && P.ortho_w == ortho_w && P.l1_c == l1_c && P.log_c == log_c &&
+                      P.l1_diff_c == l1_diff_c && P.step_c == step_c && P.step_w == step_w && P.step_dual == step_dual;
     P.l1_w = l1_w, P.ortho_w = ortho_w, P.l1_c = l1_c, P.log_c = log_c, P.l1_diff_c = l1_diff_c;
     P.step_c = step_c, P.step_w = step_w, P.step_dual = step_dual;
+    if (!same) gd_drop_graphs(s);  // the captured steps carry the old values in their kernel arguments
     return GL_OK;
 }
 
@@ -866,9 +918,7 @@ GL_API int gl_graphdict_fit(gl_graphdict *s, int64_t max_iter, double tol, int r
     int flags = 0;
     for (int64_t q = 0; q < 2 * max_iter; ++q) history_out[q] = -1.0;
     for (i = 0; i < max_iter; ++i) {
-        GL_HIP(ctx, hipMemsetAsync(P.stat + 2, 0, 8, ctx->stream));
-        GL_TRY(gd_step(s));
-        GL_HIP(ctx, hipMemcpyAsync(st, P.stat, 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        GL_TRY(gd_step_replayed(s, st));
         GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const double dc = st[0], dw = st[1];
         history_out[2 * i] = dc;
@@ -883,6 +933,7 @@ GL_API int gl_graphdict_fit(gl_graphdict *s, int64_t max_iter, double tol, int r
             }
             if (dc >= mc / 10 && dw >= mw / 10) {
                 P.step_c *= 0.7, P.step_w *= 0.7, P.step_dual *= 0.7;
+                gd_drop_graphs(s);  // the step sizes are frozen in the captured kernels' arguments
                 flags |= 2;  // "Divergence detected ..., reducing step size"
             }
         }
