@@ -475,10 +475,115 @@ __global__ __launch_bounds__(256) void k_lg_admm_res(LgDev D, GlGridBar gb, int 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same ADMM for small problems (n <= 64) in ONE launch of ONE workgroup: the whole explicit inverse
+// (<= 128 KiB) in LDS (transposed, so a wave's lanes read consecutive addresses), v double-buffered in
+// LDS, 8 threads per row, row sums combined by DPP, the
+// stopping rule evaluated in place after each step exactly as the reference does (lgmrf.py:66-69).
+// A step costs ~1 us instead of a ~5 us launch.
+constexpr int ADMM_ONE_MAXN = 64;  // measured: n = 32: 0.25 -> 0.21 ms per node-update, 64: 0.40 -> 0.35, 128: 0.61 -> 0.83 (slower)
+
+__global__ __launch_bounds__(1024) void k_lg_admm_one(LgDev D, int max_iter) {
+    extern __shared__ double s_W[];  // n * n, then v[2][n], then red[6][16]
+    const int n = (int)D.n;
+    double *s_v = s_W + (size_t)n * n;
+    double *red = s_v + 2 * n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = tid >> 3, part = tid & 7;
+    // transposed copy: s_W[j * n + r] = W[r][j], so that the 8 x 8 (row, part) lanes of a wave read
+    // consecutive addresses (no symmetry of W is assumed)
+    for (int q = tid; q < n * n; q += 1024) s_W[(size_t)(q % n) * n + q / n] = D.W[q];
+    if (tid < n) s_v[tid] = D.v[tid];
+    double xo = 0, zo = 0, uo = 0, pi = 0, on = 0;
+    if (part == 0 && row < n) {
+        xo = D.x[row];
+        zo = D.z[row];
+        uo = D.uu[row];
+        pi = D.p[row];
+        on = D.act[row];
+    }
+    __syncthreads();
+    int steps = 0;
+    bool stopped = false;
+    for (int it = 0; it < max_iter; ++it) {
+        const double *vin = s_v + (it & 1) * n;
+        double *vout = s_v + ((it + 1) & 1) * n;
+        double acc = 0.0;
+        if (row < n)
+            for (int j = part; j < n; j += 8) acc += s_W[(size_t)j * n + row] * vin[j];
+        acc += dpp_mov<DPP_QUAD_XOR1>(acc);
+        acc += dpp_mov<DPP_QUAD_XOR2>(acc);
+        acc += dpp_mov<DPP_HALF_MIRROR>(acc);
+        double dx2 = 0, x2 = 0, xm = 0, dz2 = 0, z2 = 0, zm = 0;
+        if (part == 0 && row < n) {
+            const bool active = on != 0.0;
+            const double xn = active ? acc : 0.0;
+            double zn = xn + uo;
+            zn = zn < 0 ? 0.0 : zn;
+            const double un = uo + (xn - zn);
+            if (active) {
+                dx2 = (xn - xo) * (xn - xo);
+                x2 = xo * xo;
+                xm = fabs(xo);
+                dz2 = (zn - zo) * (zn - zo);
+                z2 = zo * zo;
+                zm = fabs(zo);
+            }
+            xo = xn;
+            zo = active ? zn : 0.0;
+            uo = active ? un : 0.0;
+            vout[row] = active ? (zn - un) + D.rho * pi : 0.0;
+        }
+        dx2 = wsum(dx2);
+        x2 = wsum(x2);
+        xm = wmax(xm);
+        dz2 = wsum(dz2);
+        z2 = wsum(z2);
+        zm = wmax(zm);
+        if (lane == 0) {
+            red[0 * 16 + wave] = dx2;
+            red[1 * 16 + wave] = x2;
+            red[2 * 16 + wave] = xm;
+            red[3 * 16 + wave] = dz2;
+            red[4 * 16 + wave] = z2;
+            red[5 * 16 + wave] = zm;
+        }
+        __syncthreads();
+        double t[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            double a = (q == 2 || q == 5) ? 0.0 : 0.0;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) a = (q == 2 || q == 5) ? fmax(a, red[q * 16 + v]) : a + red[q * 16 + v];
+            t[q] = a;
+        }
+        steps = it + 1;
+        if (it > 0) {  // lgmrf.py:68 `if it > 0 and ...`; relative_error's plain-norm branch when prev ~ 0
+            const double rx = (t[2] <= 1e-8) ? sqrt(t[0]) : sqrt(t[0]) / sqrt(t[1]);
+            const double rz = (t[5] <= 1e-8) ? sqrt(t[3]) : sqrt(t[3]) / sqrt(t[4]);
+            if (rx < D.qp_tol && rz < D.qp_tol) {
+                stopped = true;
+                break;
+            }
+        }
+        __syncthreads();  // red and the v buffer about to be overwritten are free again
+    }
+    if (part == 0 && row < n) {
+        D.x[row] = xo;
+        D.z[row] = zo;
+        D.uu[row] = uo;
+    }
+    if (tid == 0) {
+        D.scal[1] = (double)steps;
+        D.scal[0] = stopped ? 1.0 : 0.0;
+    }
+}
+
 // The QP's ADMM loop: launches in chunks and polls the device-side stop flag in between, so a
 // QP that stops after ~30 steps does not pay for 100 launches.
 // Persistent form: rows per workgroup R = ceil(n / #CU) <= 8 and R * n * 8 bytes of LDS.
 struct AdmmRes {
+    bool one = false;  // n <= 128: single-workgroup form (k_lg_admm_one)
     bool on = false;
     int R = 0, nwg = 0;
     size_t lds = 0;
@@ -486,9 +591,18 @@ struct AdmmRes {
 };
 
 int admm_res_plan(gl_ctx *ctx, int64_t n, AdmmRes &A) {
-    A.on = false;
+    A.on = A.one = false;
     if (const char *e = getenv("GRAPHLEARN_AMD_LGMRF_ADMM"))
         if (!strcmp(e, "launch")) return GL_OK;
+    if (n <= ADMM_ONE_MAXN) {
+        const char *e = getenv("GRAPHLEARN_AMD_LGMRF_ADMM");
+        if (!(e && !strcmp(e, "resident"))) {  // "resident" asks for the multi-workgroup form (tests)
+            A.lds = ((size_t)n * n + 2 * n + 6 * 16) * 8;
+            GL_HIP(ctx, hipFuncSetAttribute((const void *)k_lg_admm_one, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A.lds));
+            A.one = true;
+            return GL_OK;
+        }
+    }
     const int ncu = ctx->prop.multiProcessorCount;
     const int R = (int)((n + ncu - 1) / ncu);
     const size_t lds = (size_t)R * n * 8;
@@ -503,6 +617,12 @@ int admm_res_plan(gl_ctx *ctx, int64_t n, AdmmRes &A) {
     A.lds = lds;
     GL_HIP(ctx, hipFuncSetAttribute((const void *)k_lg_admm_res, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     A.on = true;
+    return GL_OK;
+}
+
+int run_admm_one(gl_ctx *ctx, const LgDev &D, const AdmmRes &A, int max_iter) {
+    k_lg_admm_one<<<1, 1024, A.lds, ctx->stream>>>(D, max_iter);
+    GL_HIP(ctx, hipGetLastError());
     return GL_OK;
 }
 
@@ -786,7 +906,8 @@ GL_API int gl_nonneg_qp_solve(gl_ctx *ctx, const double *mat, const double *vec,
     GL_HIP(ctx, hipMemcpyAsync(V, hv.data(), hv.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     GL_HIP(ctx, hipMemsetAsync(D.scal, 0, 16 * 8, ctx->stream));
     GL_TRY(invert_spd_inplace(ctx, D.W, m, pivrow));
-    GL_TRY(ares.on ? run_admm_res(ctx, D, ares, max_iter) : run_admm(ctx, D, max_iter));
+    GL_TRY(ares.one ? run_admm_one(ctx, D, ares, max_iter)
+                    : (ares.on ? run_admm_res(ctx, D, ares, max_iter) : run_admm(ctx, D, max_iter)));
     double sc[9];
     GL_HIP(ctx, hipMemcpyAsync(z_out, D.z, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
     GL_HIP(ctx, hipMemcpyAsync(sc, D.scal, 9 * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -892,7 +1013,8 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
                 k_lg_build_w<<<g2, 256, 0, ctx->stream>>>(D, u);
                 GL_TRY(invert_spd_inplace(ctx, D.W, n, pivrow));
             }
-            GL_TRY(ares.on ? run_admm_res(ctx, D, ares, max_qp_iter) : run_admm(ctx, D, max_qp_iter));
+            GL_TRY(ares.one ? run_admm_one(ctx, D, ares, max_qp_iter)
+                            : (ares.on ? run_admm_res(ctx, D, ares, max_qp_iter) : run_admm(ctx, D, max_qp_iter)));
             k_lg_beta<<<1, VT, 0, ctx->stream>>>(D, u);
             k_matvec<<<mvb, 256, 0, ctx->stream>>>(D.C, D.beta, D.t, n, D.scal, 0);
             k_lg_snap_col<<<1, VT, 0, ctx->stream>>>(D, u);

@@ -16,11 +16,15 @@ from oracle import lgmrf as olg
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["launch", "resident"])
+@pytest.fixture(autouse=True, params=["launch", "resident", "auto"])
 def admm_form(request, monkeypatch):
-    """Every test runs with both forms of the QP's ADMM loop: one launch per step (default below
-    n = 1024) and the persistent kernel with the matrix resident in LDS and grid barriers."""
-    monkeypatch.setenv("GRAPHLEARN_AMD_LGMRF_ADMM", request.param)
+    """Every test runs with the three forms of the QP's ADMM loop: one launch per step, the persistent
+    multi-workgroup kernel (matrix rows resident in LDS, grid barriers; default from n = 1024) and the
+    automatic choice, which for n <= 64 is the single-workgroup kernel."""
+    if request.param == "auto":
+        monkeypatch.delenv("GRAPHLEARN_AMD_LGMRF_ADMM", raising=False)
+    else:
+        monkeypatch.setenv("GRAPHLEARN_AMD_LGMRF_ADMM", request.param)
     return request.param
 
 
