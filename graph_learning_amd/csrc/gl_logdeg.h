@@ -33,7 +33,6 @@ struct LogdegDev {
 };
 
 struct gl_resident;
-struct gl_small;
 
 struct gl_logdeg {
     gl_ctx *ctx = nullptr;
@@ -57,7 +56,6 @@ struct gl_logdeg {
     gl_resident *res = nullptr;   // resident engine (register-held iterate), null when not applicable
     bool res_unchecked = false;   // an asynchronous resident launch has not had its error word read yet
     int64_t res_pending = 0;      // ... and this many iterations were asked of it
-    gl_small *small = nullptr;    // small-graph engine (n <= 128, one workgroup), scratch allocated on first use
 };
 
 // gl_gram.hip
@@ -74,9 +72,10 @@ int gl_resident_launch(gl_logdeg *s, int64_t iters, double tol);
 int gl_resident_finish(gl_logdeg *s, int64_t *iters_done, bool *stopped, bool *not_resident);
 // gl_small.hip
 bool gl_small_applicable(const gl_logdeg *s);
-void gl_small_free(gl_logdeg *s);
-void gl_small_invalidate_z(gl_logdeg *s);
 int gl_small_launch(gl_logdeg *s, int64_t iters, double tol);
+size_t gl_small_batch_scratch_bytes(int B);
+int gl_small_batch_run(gl_logdeg **sessions, int B, int64_t iters, double tol, void *dev_scratch, int64_t *ran_out,
+                       bool *need_exact_out);
 // gl_logdeg.hip: layout conversions of an edge vector (tiled <-> condensed, device to device)
 int gl_logdeg_tiled_to_condensed(gl_logdeg *s, const double *src_tiled, double *dst_condensed);
 int gl_logdeg_condensed_to_tiled(gl_logdeg *s, const double *src_condensed, double *dst_tiled);

@@ -876,7 +876,6 @@ GL_API int gl_logdeg_destroy(gl_logdeg *s) {
         (void)hipStreamSynchronize(s->ctx->stream);
     }
     drop_graph(s);
-    gl_small_free(s);
     gl_resident_free(s);
     LogdegDev &D = s->dev;
     void *ptrs[] = {D.w[0], D.w[1], const_cast<double *>(D.z), D.dvar, D.dprev, D.ybar, D.pbar, D.rowslab_p, D.rowslab_w,
@@ -899,7 +898,6 @@ GL_API int gl_logdeg_set_distances(gl_logdeg *s, const double *z_condensed) {
     GL_HIP(ctx, hipGetLastError());
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     s->have_z = true;
-    gl_small_invalidate_z(s);
     s->have_zsq = false;
     s->theta = 1.0;
     s->inited = false;
@@ -937,7 +935,6 @@ GL_API int gl_logdeg_set_signals(gl_logdeg *s, const double *x, int64_t d, int64
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     s->theta = theta;
     s->have_z = true;
-    gl_small_invalidate_z(s);
     s->have_zsq = true;
     s->inited = false;
     if (theta_out) *theta_out = theta;
@@ -1398,6 +1395,42 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
         rd = sqrt(lam[2]) / sqrt(lam[3]);
         return GL_OK;
     };
+
+    // Small graphs (n <= 128): one persistent launch, one workgroup per graph, the norm bounds evaluated
+    // on the device (gl_small.hip); the host only steps in when the exact spectral norms are needed.
+    if (maxit >= 8 && gl_small_applicable(sessions[0]) && B <= ctx->prop.multiProcessorCount) {
+        void *small_scratch = nullptr;
+        GL_HIP(ctx, hipMalloc(&small_scratch, gl_small_batch_scratch_bytes(B)));
+        struct Free {
+            void *p;
+            ~Free() { (void)hipFree(p); }
+        } guard{small_scratch};
+        double rp = std::numeric_limits<double>::infinity(), rd = rp;
+        bool have_exact = false, converged = false;
+        int64_t n_iter = 0;
+        while (n_iter < maxit) {
+            int64_t ran = 0;
+            bool need_exact = false;
+            GL_TRY(gl_small_batch_run(sessions, B, maxit - n_iter, tol, small_scratch, &ran, &need_exact));
+            n_iter += ran;
+            if (ran > 0) have_exact = false;
+            if (!need_exact) break;  // maxit reached
+            GL_TRY(exact(rp, rd));
+            have_exact = true;
+            if (rp < tol && rd < tol) {  // :166-167, after the update
+                converged = true;
+                break;
+            }
+        }
+        if (!have_exact && n_iter > 1) GL_TRY(exact(rp, rd));
+        if (n_iter_out) *n_iter_out = n_iter;
+        if (converged_out) *converged_out = converged ? 1 : 0;
+        if (rel_out) {
+            rel_out[0] = rp;
+            rel_out[1] = rd;
+        }
+        return GL_OK;
+    }
 
     double *diag = (double *)ctx->pinned + 1024;
     const bool use_graph = maxit >= 8 && !getenv("GRAPHLEARN_AMD_NO_GRAPH") &&
