@@ -24,10 +24,22 @@ struct gl_ctx {
     hipDeviceProp_t prop;
     // small pinned host staging area for status words / reductions
     void *pinned = nullptr;
-    size_t pinned_bytes = 0;
+    void *pinned_dev = nullptr;  // the same memory as the device sees it (mapped)
+    size_t pinned_bytes = 0;  // status area only (the staging area follows it)
+    bool stage_busy = false;  // an asynchronous staged upload may still be reading the staging area
 };
 
 int gl_set_error(gl_ctx *ctx, int code, const char *fmt, ...);
+
+// Host <-> device copies of caller-owned (pageable) buffers on the context's stream.  Up to
+// GL_STAGE_BYTES they go through the context's pinned, device-mapped staging area and a copy kernel (a
+// hipMemcpyAsync of a few tens of KB costs ~0.4 ms on this platform); larger ones are left to the runtime.
+// gl_h2d is asynchronous (the staging area is fenced by a stream sync before its next use), gl_d2h
+// returns with the data in place.
+constexpr size_t GL_STATUS_BYTES = 1 << 16;  // pinned[0 .. 64 KiB): status words of the kernels
+constexpr size_t GL_STAGE_BYTES = 1 << 20;   // pinned[64 KiB ..): staging
+int gl_h2d(gl_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int gl_d2h(gl_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 
 #define GL_HIP(ctx, call)                                                                   \
     do {                                                                                    \

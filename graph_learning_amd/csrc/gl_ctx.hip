@@ -1,6 +1,8 @@
 // Context, error reporting and the stream timer of libgraphlearn_amd.
 #include <cstdarg>
 
+#include <algorithm>
+
 #include "gl_common.h"
 
 int gl_set_error(gl_ctx *ctx, int code, const char *fmt, ...) {
@@ -65,9 +67,10 @@ GL_API int gl_ctx_create(int device, gl_ctx **out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(GL_E_HIP);
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess)
         return fail(GL_E_HIP);
-    ctx->pinned_bytes = 1 << 16;
-    if (hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault) != hipSuccess)
+    ctx->pinned_bytes = GL_STATUS_BYTES;
+    if (hipHostMalloc(&ctx->pinned, GL_STATUS_BYTES + GL_STAGE_BYTES, hipHostMallocMapped) != hipSuccess)
         return fail(GL_E_NOMEM);
+    if (hipHostGetDevicePointer(&ctx->pinned_dev, ctx->pinned, 0) != hipSuccess) return fail(GL_E_HIP);
     *out = ctx;
     return GL_OK;
 }
@@ -115,5 +118,50 @@ GL_API int gl_ctx_timer_stop(gl_ctx *ctx, double *elapsed_ms) {
     float ms = 0.f;
     GL_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *elapsed_ms = (double)ms;
+    return GL_OK;
+}
+
+// Small staged copies are done by a copy KERNEL that reads / writes the pinned (device-mapped) staging area
+// directly: hipMemcpyAsync hands anything above ~16 KB to the SDMA engine, whose fixed latency on this
+// platform is ~0.4 ms per copy (measured: 40 KB upload 0.47 ms, the same bytes through this kernel 0.06).
+__global__ void k_copy_words(const unsigned long long *__restrict__ src, unsigned long long *__restrict__ dst, size_t nwords) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+static int stage_copy(gl_ctx *ctx, const void *src, void *dst, size_t bytes) {
+    const size_t nwords = (bytes + 7) / 8;  // every buffer involved is a multiple of 8 bytes long
+    const unsigned blocks = (unsigned)std::min<size_t>(64, (nwords + 255) / 256);
+    k_copy_words<<<blocks, 256, 0, ctx->stream>>>((const unsigned long long *)src, (unsigned long long *)dst, nwords);
+    GL_HIP(ctx, hipGetLastError());
+    return GL_OK;
+}
+
+int gl_h2d(gl_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+    if (bytes == 0) return GL_OK;
+    if (bytes > GL_STAGE_BYTES || (bytes & 7)) {
+        GL_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return GL_OK;
+    }
+    if (ctx->stage_busy) GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    char *stage = (char *)ctx->pinned + GL_STATUS_BYTES;
+    memcpy(stage, src_host, bytes);
+    GL_TRY(stage_copy(ctx, (char *)ctx->pinned_dev + GL_STATUS_BYTES, dst_dev, bytes));
+    ctx->stage_busy = true;
+    return GL_OK;
+}
+
+int gl_d2h(gl_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
+    if (bytes == 0) return GL_OK;
+    if (bytes > GL_STAGE_BYTES || (bytes & 7)) {
+        GL_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->stage_busy = false;
+        return GL_OK;
+    }
+    char *stage = (char *)ctx->pinned + GL_STATUS_BYTES;
+    GL_TRY(stage_copy(ctx, src_dev, (char *)ctx->pinned_dev + GL_STATUS_BYTES, bytes));
+    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // also fences any earlier staged upload (same stream)
+    ctx->stage_busy = false;
+    memcpy(dst_host, stage, bytes);
     return GL_OK;
 }

@@ -892,7 +892,7 @@ GL_API int gl_logdeg_set_distances(gl_logdeg *s, const double *z_condensed) {
     gl_ctx *ctx = s->ctx;
     if (!z_condensed) return gl_set_error(ctx, GL_E_INVALID, "z_condensed is NULL");
     GL_HIP(ctx, hipSetDevice(ctx->device));
-    GL_HIP(ctx, hipMemcpyAsync(s->stage, z_condensed, (size_t)s->n_edges * 8, hipMemcpyHostToDevice, ctx->stream));
+    GL_TRY(gl_h2d(ctx, s->stage, z_condensed, (size_t)s->n_edges * 8));
     k_to_tiled<0><<<dim3((unsigned)s->dev.ntiles), dim3(256), 0, ctx->stream>>>(
         s->stage, const_cast<double *>(s->dev.z), s->n, s->dev.nb, 1.0);
     GL_HIP(ctx, hipGetLastError());
@@ -925,7 +925,7 @@ GL_API int gl_logdeg_set_signals(gl_logdeg *s, const double *x, int64_t d, int64
     }
     if (!s->zsq) GL_HIP(ctx, hipMalloc((void **)&s->zsq, (size_t)s->n * s->n * 8));
     if (!s->theta_terms) GL_HIP(ctx, hipMalloc((void **)&s->theta_terms, (size_t)2 * s->n * 8));
-    GL_HIP(ctx, hipMemcpyAsync(s->xdev, x, (size_t)xe * 8, hipMemcpyHostToDevice, ctx->stream));
+    GL_TRY(gl_h2d(ctx, s->xdev, x, (size_t)xe * 8));
     GL_TRY(gl_gram_distances(ctx, s->xdev, d, s->n, s->zsq));
     double theta = 1.0;
     if (avg_degree > 0) GL_TRY(gl_theta_from_square(ctx, s->zsq, s->n, avg_degree, s->theta_terms, &theta));
@@ -950,7 +950,7 @@ GL_API int gl_logdeg_get_distances(gl_logdeg *s, double *z_condensed) {
     dim3 grid((unsigned)((s->n + 255) / 256), (unsigned)s->n);
     k_square_to_condensed<<<grid, dim3(256), 0, ctx->stream>>>(s->zsq, s->stage, s->n);
     GL_HIP(ctx, hipGetLastError());
-    GL_HIP(ctx, hipMemcpyAsync(z_condensed, s->stage, (size_t)s->n_edges * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GL_TRY(gl_d2h(ctx, z_condensed, s->stage, (size_t)s->n_edges * 8));
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GL_OK;
 }
@@ -969,7 +969,7 @@ GL_API int gl_logdeg_init(gl_logdeg *s, double alpha, double beta, double step_s
     D.a4g = 4 * alpha * D.gamma;
     const size_t tiled_bytes = (size_t)D.ntiles * GL_TILE_ELEMS * sizeof(double);
     if (edge_init) {
-        GL_HIP(ctx, hipMemcpyAsync(s->stage, edge_init, (size_t)s->n_edges * 8, hipMemcpyHostToDevice, ctx->stream));
+        GL_TRY(gl_h2d(ctx, s->stage, edge_init, (size_t)s->n_edges * 8));
         k_to_tiled<0><<<dim3((unsigned)D.ntiles), dim3(256), 0, ctx->stream>>>(s->stage, D.w[0], s->n, D.nb, 1.0);
         GL_HIP(ctx, hipGetLastError());
     } else {
@@ -1155,7 +1155,7 @@ GL_API int gl_logdeg_get_weights_condensed(gl_logdeg *s, double edge_tol, double
                                                                               s->dev.nb, edge_tol);
     GL_HIP(ctx, hipGetLastError());
     if (w_out)
-        GL_HIP(ctx, hipMemcpyAsync(w_out, s->stage, (size_t)s->n_edges * 8, hipMemcpyDeviceToHost, ctx->stream));
+        GL_TRY(gl_d2h(ctx, w_out, s->stage, (size_t)s->n_edges * 8));
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GL_OK;
 }
@@ -1173,11 +1173,11 @@ GL_API int gl_logdeg_get_weights_square(gl_logdeg *s, double edge_tol, double *w
     k_to_square<<<dim3((unsigned)s->dev.ntiles), dim3(256), 0, ctx->stream>>>(s->dev.w[s->it & 1], sq, s->n,
                                                                            s->dev.nb, edge_tol);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(w_out, sq, (size_t)s->n * s->n * 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    int rc = GL_OK;
+    if (e == hipSuccess) rc = gl_d2h(ctx, w_out, sq, (size_t)s->n * s->n * 8);  // returns with the data in place
     (void)hipFree(sq);
     if (e != hipSuccess) return gl_set_error(ctx, GL_E_HIP, "get_weights_square: %s", hipGetErrorString(e));
-    return GL_OK;
+    return rc;
 }
 
 GL_API int gl_logdeg_get_dual(gl_logdeg *s, double *d_out) {
@@ -1187,7 +1187,7 @@ GL_API int gl_logdeg_get_dual(gl_logdeg *s, double *d_out) {
     if (!s->inited) return gl_set_error(ctx, GL_E_STATE, "no iterate yet: call init first");
     GL_HIP(ctx, hipSetDevice(ctx->device));
     GL_TRY(resident_check(s));
-    GL_HIP(ctx, hipMemcpyAsync(d_out, s->dev.dvar, (size_t)s->n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GL_TRY(gl_d2h(ctx, d_out, s->dev.dvar, (size_t)s->n * 8));
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GL_OK;
 }
