@@ -804,7 +804,7 @@ GL_API int gl_graphdict_create(gl_ctx *ctx, int64_t n_nodes, int64_t n_samples, 
         delete s;
         return rc;
     }
-    GL_HIP(ctx, hipMemcpyAsync(P.wtasks, tasks.data(), tasks.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    GL_TRY(gl_h2d(ctx, P.wtasks, tasks.data(), tasks.size() * sizeof(int2)));
     if (getenv("GRAPHLEARN_AMD_GD_PROBE"))
         (void)gd_alloc(s, &s->dbgbuf, (size_t)16 * P.nwtasks * P.TS);
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -832,7 +832,7 @@ GL_API int gl_graphdict_set_signals(gl_graphdict *s, const double *x) {
     const size_t cnt = (size_t)P.T * P.n;
     for (size_t q = 0; q < cnt; ++q)
         if (!std::isfinite(x[q])) return gl_set_error(ctx, GL_E_NONFINITE, "x contains NaN or Inf");
-    GL_HIP(ctx, hipMemcpyAsync(s->stage, x, cnt * 8, hipMemcpyHostToDevice, ctx->stream));
+    GL_TRY(gl_h2d(ctx, s->stage, x, cnt * 8));
     k_gd_pack_x<<<dim3((unsigned)((cnt + 255) / 256)), 256, 0, ctx->stream>>>(s->stage, P);
     GL_HIP(ctx, hipGetLastError());
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -847,14 +847,14 @@ GL_API int gl_graphdict_set_state(gl_graphdict *s, const double *coefficients, c
     if (!coefficients || !weights) return gl_set_error(ctx, GL_E_INVALID, "coefficients / weights are NULL");
     GL_HIP(ctx, hipSetDevice(ctx->device));
     const size_t E = (size_t)P.n * (P.n - 1) / 2;
-    GL_HIP(ctx, hipMemcpyAsync(P.C, coefficients, (size_t)P.K * P.T * 8, hipMemcpyHostToDevice, ctx->stream));
+    GL_TRY(gl_h2d(ctx, P.C, coefficients, (size_t)P.K * P.T * 8));
     GL_HIP(ctx, hipMemsetAsync(P.CT, 0, (size_t)P.Tp * P.KP * 8, ctx->stream));
     k_gd_pack_c<<<dim3((unsigned)(((size_t)P.K * P.T + 255) / 256)), 256, 0, ctx->stream>>>(P);
-    GL_HIP(ctx, hipMemcpyAsync(s->stage, weights, (size_t)P.K * E * 8, hipMemcpyHostToDevice, ctx->stream));
+    GL_TRY(gl_h2d(ctx, s->stage, weights, (size_t)P.K * E * 8));
     GL_HIP(ctx, hipMemsetAsync(P.WS, 0, (size_t)P.n_pad * P.n_pad * P.KP * 8, ctx->stream));
     k_gd_pack_w<<<dim3((unsigned)(((size_t)P.n * P.n + 255) / 256)), 256, 0, ctx->stream>>>(s->stage, P);
     if (dual)
-        GL_HIP(ctx, hipMemcpyAsync(P.dual, dual, (size_t)P.Tw * P.n * 8, hipMemcpyHostToDevice, ctx->stream));
+        GL_TRY(gl_h2d(ctx, P.dual, dual, (size_t)P.Tw * P.n * 8));
     else
         GL_HIP(ctx, hipMemsetAsync(P.dual, 0, (size_t)P.Tw * P.n * 8, ctx->stream));
     GL_TRY(gd_degrees(s, P.deg));
@@ -872,13 +872,13 @@ GL_API int gl_graphdict_get_state(gl_graphdict *s, double *coefficients, double 
     GL_HIP(ctx, hipSetDevice(ctx->device));
     const size_t E = (size_t)P.n * (P.n - 1) / 2;
     if (coefficients)
-        GL_HIP(ctx, hipMemcpyAsync(coefficients, P.C, (size_t)P.K * P.T * 8, hipMemcpyDeviceToHost, ctx->stream));
+        GL_TRY(gl_d2h(ctx, coefficients, P.C, (size_t)P.K * P.T * 8));
     if (weights) {
         k_gd_unpack_w<<<dim3((unsigned)(((size_t)P.n * P.n + 255) / 256)), 256, 0, ctx->stream>>>(s->stage, P);
         GL_HIP(ctx, hipGetLastError());
-        GL_HIP(ctx, hipMemcpyAsync(weights, s->stage, (size_t)P.K * E * 8, hipMemcpyDeviceToHost, ctx->stream));
+        GL_TRY(gl_d2h(ctx, weights, s->stage, (size_t)P.K * E * 8));
     }
-    if (dual) GL_HIP(ctx, hipMemcpyAsync(dual, P.dual, (size_t)P.Tw * P.n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (dual) GL_TRY(gl_d2h(ctx, dual, P.dual, (size_t)P.Tw * P.n * 8));
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GL_OK;
 }

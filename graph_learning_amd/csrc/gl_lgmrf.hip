@@ -832,7 +832,7 @@ int relative_error_dev(gl_ctx *ctx, const double *a_dev, const double *b_dev, in
     k_relerr_part<<<blocks, 256, 0, ctx->stream>>>(a_dev, b_dev, count, part_dev);
     GL_HIP(ctx, hipGetLastError());
     std::vector<double> host((size_t)3 * blocks);
-    GL_HIP(ctx, hipMemcpyAsync(host.data(), part_dev, host.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GL_TRY(gl_d2h(ctx, host.data(), part_dev, host.size() * 8));
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     double d2 = 0, a2 = 0, am = 0;
     for (int b = 0; b < blocks; ++b) {
@@ -855,8 +855,8 @@ GL_API int gl_relative_error(gl_ctx *ctx, const double *y_true, const double *y_
     GL_HIP(ctx, hipMalloc(&a.p, (size_t)count * 8));
     GL_HIP(ctx, hipMalloc(&b.p, (size_t)count * 8));
     GL_HIP(ctx, hipMalloc(&part.p, 3 * 256 * 8));
-    GL_HIP(ctx, hipMemcpyAsync(a.p, y_true, (size_t)count * 8, hipMemcpyHostToDevice, ctx->stream));
-    GL_HIP(ctx, hipMemcpyAsync(b.p, y_pred, (size_t)count * 8, hipMemcpyHostToDevice, ctx->stream));
+    GL_TRY(gl_h2d(ctx, a.p, y_true, (size_t)count * 8));
+    GL_TRY(gl_h2d(ctx, b.p, y_pred, (size_t)count * 8));
     return relative_error_dev(ctx, (double *)a.p, (double *)b.p, count, (double *)part.p, out);
 }
 
@@ -902,14 +902,14 @@ GL_API int gl_nonneg_qp_solve(gl_ctx *ctx, const double *mat, const double *vec,
         hv[(size_t)(4 * m + i)] = (0.0 - 0.0) + step * vec[i];
         hv[(size_t)(6 * m + i)] = 1.0;
     }
-    GL_HIP(ctx, hipMemcpyAsync(D.W, hw.data(), hw.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    GL_HIP(ctx, hipMemcpyAsync(V, hv.data(), hv.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    GL_TRY(gl_h2d(ctx, D.W, hw.data(), hw.size() * 8));
+    GL_TRY(gl_h2d(ctx, V, hv.data(), hv.size() * 8));
     GL_HIP(ctx, hipMemsetAsync(D.scal, 0, 16 * 8, ctx->stream));
     GL_TRY(invert_spd_inplace(ctx, D.W, m, pivrow));
     GL_TRY(ares.one ? run_admm_one(ctx, D, ares, max_iter)
                     : (ares.on ? run_admm_res(ctx, D, ares, max_iter) : run_admm(ctx, D, max_iter)));
     double sc[9];
-    GL_HIP(ctx, hipMemcpyAsync(z_out, D.z, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GL_TRY(gl_d2h(ctx, z_out, D.z, (size_t)m * 8));
     GL_HIP(ctx, hipMemcpyAsync(sc, D.scal, 9 * 8, hipMemcpyDeviceToHost, ctx->stream));
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (sc[8] != 0.0) return gl_set_error(ctx, GL_E_HIP, "ADMM: grid barrier timed out (workgroups not co-resident; GRAPHLEARN_AMD_LGMRF_ADMM=launch avoids it)");
@@ -946,7 +946,7 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
     GL_HIP(ctx, hipMalloc(&bW.p, nn));
     if (adj_mask && !full_mask) {
         GL_HIP(ctx, hipMalloc(&bMask.p, nn));
-        GL_HIP(ctx, hipMemcpyAsync(bMask.p, adj_mask, nn, hipMemcpyHostToDevice, ctx->stream));
+        GL_TRY(gl_h2d(ctx, bMask.p, adj_mask, nn));
     }
     GL_HIP(ctx, hipMalloc(&bVec.p, (size_t)16 * n * 8));
     GL_HIP(ctx, hipMalloc(&bScal.p, 16 * 8));
@@ -990,7 +990,7 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
 
     // x = x / np.mean(x) * norm_par   (lgmrf.py:229; the mean uses numpy's pairwise summation)
     const double mean = np_pairwise_sum(x, n * n) / (double)(n * n);
-    GL_HIP(ctx, hipMemcpyAsync(bx.p, x, nn, hipMemcpyHostToDevice, ctx->stream));
+    GL_TRY(gl_h2d(ctx, bx.p, x, nn));
     const dim3 g2((unsigned)((n + 255) / 256), (unsigned)n);
     k_lg_prepare<<<g2, 256, 0, ctx->stream>>>((const double *)bx.p, D, mean, norm_par,
                                               regularization_type == 1 ? 2.0 : 1.0);
@@ -1047,8 +1047,8 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
             GL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // bound the launch queue
         }
     }
-    GL_HIP(ctx, hipMemcpyAsync(laplacian_out, D.Th, nn, hipMemcpyDeviceToHost, ctx->stream));
-    GL_HIP(ctx, hipMemcpyAsync(inv_laplacian_out, D.C, nn, hipMemcpyDeviceToHost, ctx->stream));
+    GL_TRY(gl_d2h(ctx, laplacian_out, D.Th, nn));
+    GL_TRY(gl_d2h(ctx, inv_laplacian_out, D.C, nn));
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (converged_out) *converged_out = converged;
     if (cycles_out) *cycles_out = cycles;

@@ -96,12 +96,12 @@ int check_dims(gl_ctx *ctx, const void *a, const void *b, int64_t B, int64_t n) 
     DevBuf din, dout;                                                                              \
     GL_HIP(ctx, hipMalloc((void **)&din.p, (size_t)(in_elems) * 8));                               \
     GL_HIP(ctx, hipMalloc((void **)&dout.p, (size_t)(out_elems) * 8));                             \
-    GL_HIP(ctx, hipMemcpyAsync(din.p, in, (size_t)(in_elems) * 8, hipMemcpyHostToDevice, ctx->stream)); \
+    GL_TRY(gl_h2d(ctx, din.p, in, (size_t)(in_elems) * 8)); \
     const dim3 grid((unsigned)((n + 255) / 256), (unsigned)n, (unsigned)B), block(256)
 
 #define OPS_EPILOGUE(out_elems)                                                                    \
     GL_HIP(ctx, hipGetLastError());                                                                \
-    GL_HIP(ctx, hipMemcpyAsync(out, dout.p, (size_t)(out_elems) * 8, hipMemcpyDeviceToHost, ctx->stream)); \
+    GL_TRY(gl_d2h(ctx, out, dout.p, (size_t)(out_elems) * 8)); \
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));                                                \
     return GL_OK
 
@@ -138,7 +138,7 @@ GL_API int gl_theta_from_distances(gl_ctx *ctx, const double *zsq, int64_t n, in
     DevBuf dz, dt;
     GL_HIP(ctx, hipMalloc((void **)&dz.p, (size_t)n * n * 8));
     GL_HIP(ctx, hipMalloc((void **)&dt.p, (size_t)2 * n * 8));
-    GL_HIP(ctx, hipMemcpyAsync(dz.p, zsq, (size_t)n * n * 8, hipMemcpyHostToDevice, ctx->stream));
+    GL_TRY(gl_h2d(ctx, dz.p, zsq, (size_t)n * n * 8));
     return gl_theta_from_square(ctx, dz.p, n, avg_degree, dt.p, theta_out);
 }
 
@@ -151,6 +151,6 @@ GL_API int gl_theta_from_matrix(gl_ctx *ctx, const double *zsq, int64_t rows, in
     DevBuf dz, dt;
     GL_HIP(ctx, hipMalloc((void **)&dz.p, (size_t)rows * cols * 8));
     GL_HIP(ctx, hipMalloc((void **)&dt.p, (size_t)2 * rows * 8));
-    GL_HIP(ctx, hipMemcpyAsync(dz.p, zsq, (size_t)rows * cols * 8, hipMemcpyHostToDevice, ctx->stream));
+    GL_TRY(gl_h2d(ctx, dz.p, zsq, (size_t)rows * cols * 8));
     return gl_theta_from_rows(ctx, dz.p, rows, cols, avg_degree, dt.p, theta_out);
 }
