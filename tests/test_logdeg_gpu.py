@@ -256,3 +256,27 @@ def test_resident_engine_falls_back_when_workgroups_do_not_meet(golden, engine, 
         w = s.weights_condensed()
         assert s.engine == "stream" and s.total_iterations == 50
     np.testing.assert_allclose(w, g["raw_w_it50"], rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("n", [2600, 3000])
+def test_resident_matches_streaming_at_ragged_large_sizes(n, engine, monkeypatch):
+    """Resident engine on lattices with a ragged last block (n not a multiple of 64) and many fringe
+    tiles: 60 iterations agree with the streaming engine up to summation order, and the dual too."""
+    if engine != "resident":
+        pytest.skip("compares the two large-size engines once")
+    rng = np.random.default_rng(n)
+    e = n * (n - 1) // 2
+    z = rng.uniform(0.05, 3.0, size=e)
+    out = {}
+    for eng in ("stream", "resident"):
+        monkeypatch.setenv("GRAPHLEARN_AMD_ENGINE", eng)
+        with _lib.LogDegreeSession(n) as s:
+            s.set_distances(z)
+            s.init(1.2, 0.8, 0.5, None)
+            assert s.engine == eng
+            n_it, conv, rel = s.iterate(60, 0.0)
+            out[eng] = (s.weights_condensed(), s.dual(), rel)
+    np.testing.assert_allclose(out["resident"][0], out["stream"][0], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(out["resident"][1], out["stream"][1], rtol=0, atol=1e-12)
+    assert out["resident"][2][0] == pytest.approx(out["stream"][2][0], rel=1e-9)
+    assert out["resident"][2][1] == pytest.approx(out["stream"][2][1], rel=1e-9)
