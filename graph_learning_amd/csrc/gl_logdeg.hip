@@ -1406,12 +1406,17 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
             ~Free() { (void)hipFree(p); }
         } guard{small_scratch};
         double rp = std::numeric_limits<double>::infinity(), rd = rp;
-        bool have_exact = false, converged = false;
+        bool have_exact = false, converged = false, small_failed = false;
         int64_t n_iter = 0;
         while (n_iter < maxit) {
             int64_t ran = 0;
             bool need_exact = false;
-            GL_TRY(gl_small_batch_run(sessions, B, maxit - n_iter, tol, small_scratch, &ran, &need_exact));
+            const int rc = gl_small_batch_run(sessions, B, maxit - n_iter, tol, small_scratch, &ran, &need_exact);
+            if (rc == GL_E_STATE && n_iter == 0) {  // workgroups not co-resident: per-iteration launches instead
+                small_failed = true;
+                break;
+            }
+            if (rc != GL_OK) return rc;
             n_iter += ran;
             if (ran > 0) have_exact = false;
             if (!need_exact) break;  // maxit reached
@@ -1422,14 +1427,16 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                 break;
             }
         }
-        if (!have_exact && n_iter > 1) GL_TRY(exact(rp, rd));
-        if (n_iter_out) *n_iter_out = n_iter;
-        if (converged_out) *converged_out = converged ? 1 : 0;
-        if (rel_out) {
-            rel_out[0] = rp;
-            rel_out[1] = rd;
+        if (!small_failed) {
+            if (!have_exact && n_iter > 1) GL_TRY(exact(rp, rd));
+            if (n_iter_out) *n_iter_out = n_iter;
+            if (converged_out) *converged_out = converged ? 1 : 0;
+            if (rel_out) {
+                rel_out[0] = rp;
+                rel_out[1] = rd;
+            }
+            return GL_OK;
         }
-        return GL_OK;
     }
 
     double *diag = (double *)ctx->pinned + 1024;

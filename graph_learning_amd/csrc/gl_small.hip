@@ -48,6 +48,7 @@ struct SmallBatch {
     long long *status;     // [0] iterations run by this launch, [1] 0 = maxit reached, 1 = the host must decide, 2 = barrier lost
     unsigned *bar;         // grid barrier words (gl_gridbar.h)
     int B;
+    int rendezvous;        // workgroups expected at the start-up rendezvous (= B; B + 1 in the fallback test)
 };
 
 __device__ __forceinline__ int64_t tiled_offset(int i, int j, int nb) {  // i < j
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(T) void k_small(SmallDev P1, SmallBatch Q) {
         pb_l[tid] = P.pbar[tid];
         dp_l[tid] = P.dprev[tid];
     }
-    const GlGridBar gb{BATCH ? Q.bar : nullptr, BATCH ? Q.B : 0};
+    const GlGridBar gb{BATCH ? Q.bar : nullptr, BATCH ? Q.rendezvous : 0};
     GlBarState bs{};
     bool alive = true;
     if (BATCH) {
@@ -366,7 +367,7 @@ int gl_small_batch_run(gl_logdeg **sessions, int B, int64_t iters, double tol, v
     GL_TRY(small_set_attrs(ctx));
     const int n = host[0].n;
     const size_t lds = small_lds_bytes(n, host[0].E);
-    const SmallBatch Q{devs, diag, status, bar, B};
+    const SmallBatch Q{devs, diag, status, bar, B, B + (getenv("GRAPHLEARN_AMD_RES_TEST_NOT_RESIDENT") ? 1 : 0)};
     if (n <= 64)
         k_small<256, true><<<B, 256, lds, ctx->stream>>>(host[0], Q);
     else
@@ -377,10 +378,16 @@ int gl_small_batch_run(gl_logdeg **sessions, int B, int64_t iters, double tol, v
     for (int a = 0; a < B; ++a)  // the done / final-iteration words belong to the per-graph rule: re-arm
         GL_HIP(ctx, hipMemsetAsync(sessions[a]->dev.ctr, 0, 2 * 8, ctx->stream));
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (st[1] == 2)
-        return gl_set_error(ctx, GL_E_HIP, "small batched engine: grid barrier timed out (workgroups not co-resident)");
     for (int a = 0; a < B; ++a) sessions[a]->it += st[0];
     *ran_out = st[0];
     *need_exact_out = st[1] == 1;
+    if (st[1] == 2) {
+        // the workgroups did not all meet (GPU shared with another process).  At the start-up rendezvous
+        // nothing has been modified and the caller falls back to per-iteration launches; later it is an error.
+        if (st[0] != 0)
+            return gl_set_error(ctx, GL_E_HIP, "small batched engine: grid barrier timed out in mid-run");
+        *need_exact_out = false;
+        return GL_E_STATE;  // not an error message: "not co-resident", handled by gl_logdeg_batch_iterate
+    }
     return GL_OK;
 }

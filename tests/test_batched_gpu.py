@@ -56,3 +56,22 @@ def test_windowlogmodel_fit_reference_smoke(window_size, avg_degree):
 def test_batched_errors():
     with pytest.raises(ValueError):
         gsp_learn_graph_log_degrees(np.ones((2, 10)), 1, 1, edge_init=np.ones((2, 10)))
+
+
+@pytest.mark.parametrize("engine", ["stream", "auto"])
+def test_batched_paths_agree_and_fall_back(golden, engine, monkeypatch):
+    """The coupled loop has two device paths: one persistent launch with a workgroup per graph (n <= 128,
+    the default here) and per-iteration batched launches (any n; forced with ENGINE=stream).  Both stop at
+    the reference's iteration; when the persistent one cannot gather its workgroups (shared GPU, simulated)
+    nothing has been modified and the other path takes over."""
+    g = golden("batched_B3_n12")
+    if engine == "stream":
+        monkeypatch.setenv("GRAPHLEARN_AMD_ENGINE", "stream")
+    else:
+        monkeypatch.setenv("GRAPHLEARN_AMD_RES_TEST_NOT_RESIDENT", "1")  # rendezvous expects one workgroup too many
+    out, info = gsp_learn_graph_log_degrees(g["z"].copy(), 1, 1, maxit=5000, tol=1e-4, edge_tol=1e-3, return_info=True)
+    assert info["converged"] and abs(info["n_iter"] - int(g["n_iter_converged"])) <= 1
+    raw, _ = old.learn_log_degrees(g["z"].copy(), 1, 1, maxit=int(g["n_iter_converged"]), tol=0.0, edge_tol=-np.inf,
+                                   return_info=True)
+    near = np.abs(raw - 1e-3) < 1e-6
+    np.testing.assert_allclose(out[~near], g["w_converged"][~near], rtol=0, atol=1e-6)
