@@ -192,7 +192,7 @@ def main():
                          # algorithmic 24 E bytes, so `frac` (algorithmic bytes / time / peak) can exceed 1
                          "measured_traffic_rate": (traffic / (launch_us * 1e-6) / 1e9) if traffic else None},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
             z = sess.get_distances() * theta
             out["cpu_baseline"] = cpu_baseline(z)
         print(json.dumps(out), flush=True)
