@@ -190,7 +190,11 @@ def main():
                                            "FETCH x2 per MI355X_MICROARCH.md)" if traffic else None,
                          # the resident engine does not stream the iterate: its real fabric traffic is below the
                          # algorithmic 24 E bytes, so `frac` (algorithmic bytes / time / peak) can exceed 1
-                         "measured_traffic_rate": (traffic / (launch_us * 1e-6) / 1e9) if traffic else None},
+                         "measured_traffic_rate": (traffic / (launch_us * 1e-6) / 1e9) if traffic else None,
+                         "note": ("achieved = ALGORITHMIC bytes (24 E per iteration, SURVEY 8d) / time.  The resident engine "
+                                  "keeps the iterate in registers / LDS and streams only z, so its real fabric traffic "
+                                  "(`traffic`, PMC) is ~0.45 of the algorithmic figure and `frac` may exceed 1: the kernel is "
+                                  "fp64-issue / barrier bound, not HBM bound (DESIGN.md 3a)") if engine == "resident" else None},
         }
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
             z = sess.get_distances() * theta
