@@ -75,3 +75,18 @@ def test_batched_paths_agree_and_fall_back(golden, engine, monkeypatch):
                                    return_info=True)
     near = np.abs(raw - 1e-3) < 1e-6
     np.testing.assert_allclose(out[~near], g["w_converged"][~near], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,b", [(2, 3), (5, 1), (64, 5), (65, 4), (128, 3), (129, 3)])
+def test_batched_sizes_against_oracle(n, b):
+    """Both sides of the small-engine limits (64 / 128 nodes), a batch of one, tiny graphs: same stopping
+    iteration and iterates as the oracle's 2-D branch."""
+    rng = default_rng(100 * n + b)
+    e = n * (n - 1) // 2
+    z = rng.uniform(0.1, 3.0, size=(b, e))
+    ref, info = old.learn_log_degrees(z, 1.1, 0.9, maxit=400, tol=1e-4, edge_tol=-np.inf, return_info=True)
+    out, got = gsp_learn_graph_log_degrees(z, 1.1, 0.9, maxit=400, tol=1e-4, edge_tol=-np.inf, return_info=True)
+    assert got["n_iter"] == info["n_iter"]
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-10)
+    assert got["rel_primal"] == pytest.approx(info["rel"][0], rel=1e-8)
+    assert got["rel_dual"] == pytest.approx(info["rel"][1], rel=1e-8)

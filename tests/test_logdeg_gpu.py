@@ -136,7 +136,7 @@ def test_resume_equals_single_run(golden):
     np.testing.assert_array_equal(raw_iterate(zt, 1, 1, 12)[0], raw_iterate(zt, 1, 1, 12)[0])
 
 
-@pytest.mark.parametrize("n", [2, 3, 5, 63, 64, 65, 129, 200])
+@pytest.mark.parametrize("n", [2, 3, 5, 63, 64, 65, 127, 128, 129, 200])
 def test_ragged_sizes_against_oracle(n):
     """Tile edges: n below / at / just above multiples of the 64-wide tile."""
     rng = np.random.default_rng(n)
