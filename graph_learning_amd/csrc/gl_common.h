@@ -27,6 +27,7 @@ struct gl_ctx {
     void *pinned_dev = nullptr;  // the same memory as the device sees it (mapped)
     size_t pinned_bytes = 0;  // status area only (the staging area follows it)
     bool stage_busy = false;  // an asynchronous staged upload may still be reading the staging area
+    bool small_attrs_set = false;  // dynamic-LDS limit of the small-engine kernels raised on this device
 };
 
 int gl_set_error(gl_ctx *ctx, int code, const char *fmt, ...);

@@ -309,13 +309,12 @@ SmallDev small_dev_of(const gl_logdeg *s, double tol, int64_t iters) {
 
 size_t small_lds_bytes(int n, int E) { return ((size_t)2 * E + 4 * n + 64) * 8; }
 
-int small_set_attrs(gl_ctx *ctx) {
-    static bool done = false;
-    if (done) return GL_OK;
+int small_set_attrs(gl_ctx *ctx) {  // per context: one process may drive several GPUs
+    if (ctx->small_attrs_set) return GL_OK;
     const int most = (int)small_lds_bytes(SMALL_MAX_N, SMALL_MAX_N * (SMALL_MAX_N - 1) / 2);
     GL_HIP(ctx, hipFuncSetAttribute((const void *)k_small<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, most));
     GL_HIP(ctx, hipFuncSetAttribute((const void *)k_small<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, most));
-    done = true;
+    ctx->small_attrs_set = true;
     return GL_OK;
 }
 
