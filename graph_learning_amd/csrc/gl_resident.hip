@@ -10,10 +10,10 @@
 //
 // Geometry: one workgroup of 8 waves per CU (it owns 128 KiB of the CU's LDS, so exactly one
 // workgroup is resident per CU); wave slot s = 8*workgroup + wave owns
-//   - one "bulk" tile (64x64, off-diagonal, fully inside n): half of its w lives in 64 VGPRs per
+//   - one "bulk" tile (64x64, off-diagonal; columns beyond n masked): half of its w lives in 64 VGPRs per
 //     lane, the other half in a wave-private 16 KiB slice of LDS (one ds_read/ds_write_b128 per
 //     row pair and iteration -- never in HBM),
-//   - a share of the "fringe" (diagonal and ragged tiles, with masked entries), split at row-pair
+//   - a share of the "fringe" (the diagonal tiles, with masked entries), split at row-pair
 //     granularity over all slots and streamed from memory every iteration.
 // Per iteration: edge phase (all slots) -> grid barrier -> node phase (workgroup b updates node
 // block b) -> grid barrier -> stopping rule (every workgroup, same data, same order).
@@ -105,6 +105,10 @@ __device__ __forceinline__ double2 ld_z(const double *base, unsigned byte_off) {
     return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
+// MASKED (lattices whose last block column is ragged): columns beyond n are kept at zero and out of every
+// sum by a 0 / 1 factor per lane column (x 1.0 is exact, so full tiles compute bit-identical values; one
+// code path, no select chains).  Lattices with n a multiple of 64 run the unmasked instantiation.
+template <bool MASKED>
 __device__ __forceinline__ void bulk_tile_pass(const ResDev &P, double2 (&wreg)[RS], double2 *wl, double2 (&zr)[8],
                                                const NodeVals &nv, const int I, const int J, const unsigned zb_in,
                                                const int entry, const int lane, double &nqy, double &nw) {
@@ -114,6 +118,7 @@ __device__ __forceinline__ void bulk_tile_pass(const ResDev &P, double2 (&wreg)[
     unsigned zb = zb_in;
     int rbase = J * (int)P.n_pad + I * TB + 2 * ((lane >> 2) & 7) + half;  // this lane's row-slab entry of group 0
     asm volatile("" : "+v"(zb), "+v"(rbase));  // not loop-invariant for the compiler: addresses are recomputed, not spilled
+    const double m0 = (!MASKED || J * TB + c0 < P.n) ? 1.0 : 0.0, m1 = (!MASKED || J * TB + c0 + 1 < P.n) ? 1.0 : 0.0;
     double colp0 = 0, colp1 = 0, colw0 = 0, colw1 = 0;
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
@@ -135,10 +140,17 @@ __device__ __forceinline__ void bulk_tile_pass(const ResDev &P, double2 (&wreg)[
                 const double tt = y - g2 * z;                           // :150
                 const double pr = tt > 0 ? tt : 0.0;
                 const double q = c * pr - g * (pi + (e ? pj1 : pj0));   // :153
-                wn[e] = (w - y) + q;                                    // :163
-                pp[e] = pr;
                 const double dq = q - y;                                // == -y + q (:158)
-                nq2[e] = dq * dq;
+                if (MASKED) {
+                    const double m = e ? m1 : m0;
+                    wn[e] = m * ((w - y) + q);
+                    pp[e] = m * pr;
+                    nq2[e] = m * (dq * dq);
+                } else {
+                    wn[e] = (w - y) + q;                                // :163
+                    pp[e] = pr;
+                    nq2[e] = dq * dq;
+                }
                 nw2[e] = w * w;
             }
             nqy += nq2[0] + nq2[1];
@@ -182,6 +194,7 @@ __device__ __forceinline__ void bulk_tile_pass(const ResDev &P, double2 (&wreg)[
 }
 
 // The grid barrier (XCD-hierarchical, bounded spins) is in gl_gridbar.h.
+template <bool MASKED>
 __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
     __shared__ double2 s_w[RW][SLOTS - RS][64];  // 128 KiB: the LDS half of every wave's tile
     __shared__ double s_sum[2][RW][TB];
@@ -226,6 +239,11 @@ __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
     const int64_t fr0 = (int64_t)slot * P.R / P.S, fr1 = (int64_t)(slot + 1) * P.R / P.S;
 
     const int my_e0 = wg < P.nb ? P.col_ptr[wg] : 0, my_e1 = wg < P.nb ? P.col_ptr[wg + 1] : 0;
+    // tile ids of my first two fringe pairs and the colslab rows of my first two fringe segments: known
+    // before the loop, so that the pair's data loads do not wait for index loads every iteration
+    const int64_t ft0 = fr0 < fr1 ? P.fr_tile[fr0 >> 5] : -1, ft1 = fr0 + 1 < fr1 ? P.fr_tile[(fr0 + 1) >> 5] : -1;
+    const int frow0 = fr0 < fr1 ? P.col_ent[P.F + slot * P.KF] : 0;
+    const int frow1 = fr0 + 1 < fr1 && P.KF > 1 ? P.col_ent[P.F + slot * P.KF + 1] : 0;
     const GlGridBar gb{P.bar, P.rendezvous};
     GlBarState bs{};
     if (tid == 0) s_ok = gl_barrier_setup(gb, bs) ? 1 : 0;
@@ -240,7 +258,7 @@ __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
         const bool stamp = P.dbg != nullptr && iter >= 8 && iter < 24;
         if (stamp) ts[0] = __builtin_amdgcn_s_memrealtime();
         // ================= edge phase: my resident bulk tile =================
-        if (has_bulk) bulk_tile_pass(P, wreg, wl, zr, load_node_vals(P, I, J, lane), I, J, zb, bulk_row, lane, nqy, nw);
+        if (has_bulk) bulk_tile_pass<MASKED>(P, wreg, wl, zr, load_node_vals(P, I, J, lane), I, J, zb, bulk_row, lane, nqy, nw);
         // ================= edge phase: my fringe row pairs (streamed, masked, in place) =================
         if (fr0 < fr1) {
             int seg = 0;
@@ -249,7 +267,7 @@ __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
             double dj0 = 0, dj1 = 0, pj0 = 0, pj1 = 0;
             double colp0 = 0, colp1 = 0, colw0 = 0, colw1 = 0;
             for (int64_t fp = fr0; fp < fr1; ++fp) {
-                const int64_t t = P.fr_tile[fp >> 5];
+                const int64_t t = fp == fr0 ? ft0 : (fp == fr0 + 1 ? ft1 : P.fr_tile[fp >> 5]);
                 const int a = (int)(fp & (SLOTS - 1));
                 if (t != tcur) {
                     if (tcur >= 0) {  // flush the previous tile's column partials
@@ -258,7 +276,8 @@ __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
                         colw0 = add_xor32(colw0);
                         colw1 = add_xor32(colw1);
                         if (half == 0) {
-                            double *dst = P.colslab + (int64_t)P.col_ent[P.F + slot * P.KF + seg] * (2 * TB) + c0;
+                            const int row = seg == 0 ? frow0 : (seg == 1 ? frow1 : P.col_ent[P.F + slot * P.KF + seg]);
+                            double *dst = P.colslab + (int64_t)row * (2 * TB) + c0;
                             st_sc1(dst, colp0);
                             st_sc1(dst + 1, colp1);
                             st_sc1(dst + TB, colw0);
@@ -314,7 +333,8 @@ __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
             colw0 = add_xor32(colw0);
             colw1 = add_xor32(colw1);
             if (half == 0) {
-                double *dst = P.colslab + (int64_t)P.col_ent[P.F + slot * P.KF + seg] * (2 * TB) + c0;
+                const int row = seg == 0 ? frow0 : (seg == 1 ? frow1 : P.col_ent[P.F + slot * P.KF + seg]);
+                double *dst = P.colslab + (int64_t)row * (2 * TB) + c0;
                 st_sc1(dst, colp0);
                 st_sc1(dst + 1, colp1);
                 st_sc1(dst + TB, colw0);
@@ -532,12 +552,11 @@ int gl_resident_prepare(gl_logdeg *s) {
     }
     const LogdegDev &D = s->dev;
     const int ncu = ctx->prop.multiProcessorCount;
-    // bulk = off-diagonal tiles fully inside n; fringe = the rest
+    // bulk = off-diagonal tiles (the last block column may be ragged: masked in the pass); fringe = diagonal tiles
     std::vector<int> bulk, fringe;
     for (int64_t I = 0; I < D.nb; ++I)
         for (int64_t J = I; J < D.nb; ++J) {
-            const bool full = (I < J) && (J * GL_TB + GL_TB <= D.n);
-            (full ? bulk : fringe).push_back((int)gl_tile_id(I, J, D.nb));
+            (I < J ? bulk : fringe).push_back((int)gl_tile_id(I, J, D.nb));
         }
     const int F = (int)bulk.size(), NF = (int)fringe.size();
     if (F > ncu * RW) return GL_OK;  // does not fit: the streaming engine handles it
@@ -661,7 +680,10 @@ int gl_resident_launch(gl_logdeg *s, int64_t iters, double tol) {
     P.maxit = (int)std::min<int64_t>(iters, 1 << 30);
     P.rendezvous = P.NWG + (getenv("GRAPHLEARN_AMD_RES_TEST_NOT_RESIDENT") ? 1 : 0);
     GL_HIP(ctx, hipMemsetAsync(r->bar, 0, GL_BAR_WORDS * 4, ctx->stream));
-    k_resident<<<dim3((unsigned)P.NWG), dim3(RT), 0, ctx->stream>>>(P);
+    if (D.n % GL_TB == 0)
+        k_resident<false><<<dim3((unsigned)P.NWG), dim3(RT), 0, ctx->stream>>>(P);
+    else  // ragged last block column: its tiles are masked bulk tiles
+        k_resident<true><<<dim3((unsigned)P.NWG), dim3(RT), 0, ctx->stream>>>(P);
     GL_HIP(ctx, hipGetLastError());
     return GL_OK;
 }
