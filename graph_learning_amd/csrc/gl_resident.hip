@@ -33,7 +33,7 @@
 #include "gl_logdeg.h"
 
 #ifndef GL_RES_MIN_BULK_TILES
-#define GL_RES_MIN_BULK_TILES 700
+#define GL_RES_MIN_BULK_TILES 600
 #endif
 
 namespace {
@@ -560,9 +560,9 @@ int gl_resident_prepare(gl_logdeg *s) {
         }
     const int F = (int)bulk.size(), NF = (int)fringe.size();
     if (F > ncu * RW) return GL_OK;  // does not fit: the streaming engine handles it
-    // One iteration of this engine costs ~23-25 us almost independently of n (two grid barriers and a
-    // single wave per tile), the streaming engine ~2.5 us per 100 tiles: it pays off from ~700
-    // bulk tiles (n >~ 2400) on.  GRAPHLEARN_AMD_ENGINE=resident forces it wherever it fits.
+    // One iteration of this engine costs ~20-24 us almost independently of n (two grid barriers and a
+    // single wave per tile), the streaming engine ~1 us per 100 tiles on top of ~10: measured break-even
+    // at n ~ 2150; it is chosen from 600 bulk tiles (n > 2240) on.  GRAPHLEARN_AMD_ENGINE=resident forces it wherever it fits.
     if (!forced && F < GL_RES_MIN_BULK_TILES) return GL_OK;
     int NWG = std::max(1, (F + RW - 1) / RW);
     NWG = std::max<int>(NWG, (int)std::min<int64_t>(D.nb, ncu));  // enough workgroups for the node phase / fringe

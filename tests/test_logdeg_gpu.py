@@ -29,7 +29,7 @@ CASES = ["logmodel_n7_d23", "logmodel_n16_d40", "logmodel_n64_d256"]
 def engine(request, monkeypatch):
     """Every test of this file runs on the three iteration engines: streaming (one edge-pass + one
     node-pass launch per iteration), resident (iterate held in registers / LDS, grid barriers; by default
-    only chosen for n >~ 2400, forced here) and small (n <= 128: one workgroup, one launch per call; where
+    only chosen for n > 2240, forced here) and small (n <= 128: one workgroup, one launch per call; where
     it does not apply the automatic choice takes over)."""
     monkeypatch.setenv("GRAPHLEARN_AMD_ENGINE", request.param)
     return request.param
