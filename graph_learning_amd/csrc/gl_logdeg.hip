@@ -668,15 +668,15 @@ struct BatchPtrs {
 __global__ __launch_bounds__(256) void k_batch_dots(const BatchPtrs *__restrict__ ptrs, const int2 *__restrict__ pairs,
                                                     int64_t n_tiled, int64_t n_nodes, double *__restrict__ part) {
     __shared__ double sh[4][4];
-    const int2 pr = pairs[blockIdx.y];
+    const int2 pr = pairs[blockIdx.x];  // pairs on grid x (up to B (B + 1) / 2 of them), blocks on y
     const BatchPtrs A = ptrs[pr.x], Bq = ptrs[pr.y];
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_tiled; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < n_tiled; i += (int64_t)gridDim.y * 256) {
         const double ao = A.w_old[i], bo = Bq.w_old[i];
         s0 += (A.w_new[i] - ao) * (Bq.w_new[i] - bo);
         s1 += ao * bo;
     }
-    if (blockIdx.x == 0)
+    if (blockIdx.y == 0)
         for (int64_t i = threadIdx.x; i < n_nodes; i += 256) {
             s2 += (A.d_new[i] - A.d_old[i]) * (Bq.d_new[i] - Bq.d_old[i]);
             s3 += A.d_old[i] * Bq.d_old[i];
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(256) void k_batch_dots(const BatchPtrs *__restrict_
     }
     __syncthreads();
     if (threadIdx.x < 4)
-        part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + threadIdx.x] =
+        part[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 4 + threadIdx.x] =
             ((sh[threadIdx.x][0] + sh[threadIdx.x][1]) + sh[threadIdx.x][2]) + sh[threadIdx.x][3];
 }
 // out[pair][q] = sum over the blocks of part[pair][block][q], fixed order
@@ -1374,7 +1374,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
 
     auto exact = [&](double &rp, double &rd) -> int {  // spectral-norm ratios from the full Gram matrices
         const int64_t it = sessions[0]->it;
-        k_batch_dots<<<dim3((unsigned)blocks, (unsigned)npairs), 256, 0, ctx->stream>>>(
+        k_batch_dots<<<dim3((unsigned)npairs, (unsigned)blocks), 256, 0, ctx->stream>>>(
             (const BatchPtrs *)sc.ptrs + (size_t)(it & 1) * B, (const int2 *)sc.pairs, n_tiled, sessions[0]->n,
             (double *)sc.part);
         k_batch_dots_reduce<<<dim3((unsigned)((npairs * 4 + 255) / 256)), 256, 0, ctx->stream>>>((const double *)sc.part,
@@ -1439,10 +1439,14 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
         }
     }
 
-    double *diag = (double *)ctx->pinned + 1024;
-    const bool use_graph = maxit >= 8 && !getenv("GRAPHLEARN_AMD_NO_GRAPH") &&
-                           (size_t)(1024 + 4 * B) * 8 <= ctx->pinned_bytes;
-    if ((size_t)(1024 + 4 * B) * 8 > ctx->pinned_bytes) return gl_set_error(ctx, GL_E_INVALID, "batch too large (B = %d)", B);
+    // the B x 4 diagonal entries land in the context's pinned staging area (no staged copy runs in this loop)
+    if ((size_t)4 * B * 8 > GL_STAGE_BYTES) return gl_set_error(ctx, GL_E_INVALID, "batch too large (B = %d)", B);
+    if (ctx->stage_busy) {
+        GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->stage_busy = false;
+    }
+    double *diag = (double *)((char *)ctx->pinned + GL_STATUS_BYTES);
+    const bool use_graph = maxit >= 8 && !getenv("GRAPHLEARN_AMD_NO_GRAPH");
     struct Graphs {
         hipGraphExec_t g[2] = {nullptr, nullptr};
         ~Graphs() {
@@ -1453,7 +1457,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
     auto step_and_diag = [&](int par_after) {
         k_edge_batch<<<dim3((unsigned)D0.G, (unsigned)B), dim3(64), 0, ctx->stream>>>((const LogdegDev *)sc.devs);
         k_node_batch<<<dim3((unsigned)D0.nb, (unsigned)B), dim3(NODE_WAVES * 64), 0, ctx->stream>>>((const LogdegDev *)sc.devs);
-        k_batch_dots<<<dim3((unsigned)blocks, (unsigned)B), 256, 0, ctx->stream>>>(
+        k_batch_dots<<<dim3((unsigned)B, (unsigned)blocks), 256, 0, ctx->stream>>>(
             (const BatchPtrs *)sc.ptrs + (size_t)par_after * B, (const int2 *)sc.pairs, n_tiled, sessions[0]->n,
             (double *)sc.part);
         k_batch_dots_reduce<<<dim3((unsigned)((B * 4 + 255) / 256)), 256, 0, ctx->stream>>>((const double *)sc.part, B, blocks,
