@@ -77,7 +77,7 @@ def test_batched_paths_agree_and_fall_back(golden, engine, monkeypatch):
     np.testing.assert_allclose(out[~near], g["w_converged"][~near], rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize("n,b", [(2, 3), (5, 1), (64, 5), (65, 4), (128, 3), (129, 3)])
+@pytest.mark.parametrize("n,b", [(2, 3), (5, 1), (5, 300), (64, 5), (65, 4), (128, 3), (129, 3)])
 def test_batched_sizes_against_oracle(n, b):
     """Both sides of the small-engine limits (64 / 128 nodes), a batch of one, tiny graphs: same stopping
     iteration and iterates as the oracle's 2-D branch."""
