@@ -608,10 +608,11 @@ int admm_res_plan(gl_ctx *ctx, int64_t n, AdmmRes &A) {
     const size_t lds = (size_t)R * n * 8;
     if (R > ADMM_RES_MAXR || lds > 150 * 1024) return GL_OK;
     // A persistent step costs ~6-7 us whatever n is (barrier + one exchange of v through memory); a
-    // launch-per-step costs ~5 us + the stream of W: measured break-even near n = 1000
-    // (n = 256: 0.76 vs 0.70 ms per node-update, 1024: 0.92 vs 0.97, 2048: 1.24 vs 1.63).
+    // launch-per-step costs ~5 us + the stream of W and a host poll every 16-24 steps.  Measured per
+    // node-update (persistent vs launched): n = 256: 0.76 vs 0.70 ms, 400: 0.77 vs 0.90, 700: 0.85 vs 0.89,
+    // 1000: 0.90 vs 1.09, 2048: 1.19 vs 1.63.
     const char *force = getenv("GRAPHLEARN_AMD_LGMRF_ADMM");
-    if (n < 1024 && !(force && !strcmp(force, "resident"))) return GL_OK;
+    if (n < 384 && !(force && !strcmp(force, "resident"))) return GL_OK;
     A.R = R;
     A.nwg = (int)((n + R - 1) / R);
     A.lds = lds;

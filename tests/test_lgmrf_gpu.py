@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True, params=["launch", "resident", "auto"])
 def admm_form(request, monkeypatch):
     """Every test runs with the three forms of the QP's ADMM loop: one launch per step, the persistent
-    multi-workgroup kernel (matrix rows resident in LDS, grid barriers; default from n = 1024) and the
+    multi-workgroup kernel (matrix rows resident in LDS, grid barriers; default from n = 384) and the
     automatic choice, which for n <= 64 is the single-workgroup kernel."""
     if request.param == "auto":
         monkeypatch.delenv("GRAPHLEARN_AMD_LGMRF_ADMM", raising=False)
