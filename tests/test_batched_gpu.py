@@ -90,3 +90,38 @@ def test_batched_sizes_against_oracle(n, b):
     np.testing.assert_allclose(out, ref, rtol=0, atol=1e-10)
     assert got["rel_primal"] == pytest.approx(info["rel"][0], rel=1e-8)
     assert got["rel_dual"] == pytest.approx(info["rel"][1], rel=1e-8)
+
+
+def test_batch_gram_entry_point():
+    """gl_logdeg_batch_gram (diagnostic entry point): the four B x B Gram matrices of the last iteration."""
+    import ctypes as C
+
+    from graph_learning_amd import _lib
+
+    n, b = 12, 3
+    e = n * (n - 1) // 2
+    z = default_rng(7).uniform(0.2, 2.0, size=(b, e))
+    ctx = _lib.default_context()
+    sessions = [_lib.LogDegreeSession(n, ctx) for _ in range(b)]
+    try:
+        prev_w, prev_d = [], []
+        for s, zz in zip(sessions, z):
+            s.set_distances(zz)
+            s.init(1, 1, 0.5, None)
+            s.iterate_async(4)
+            prev_w.append(s.weights_condensed())
+            prev_d.append(s.dual())
+            s.iterate_async(1)
+        new_w = [s.weights_condensed() for s in sessions]
+        new_d = [s.dual() for s in sessions]
+        handles = (C.c_void_p * b)(*[s._h for s in sessions])
+        gram = np.empty((4, b, b))
+        ctx.check(ctx._lib.gl_logdeg_batch_gram(handles, b, _lib.ptr(gram)), "batch_gram")
+    finally:
+        for s in sessions:
+            s.close()
+    dw = np.array(new_w) - np.array(prev_w)
+    dd = np.array(new_d) - np.array(prev_d)
+    for got, want in zip(gram, (dw @ dw.T, np.array(prev_w) @ np.array(prev_w).T, dd @ dd.T,
+                                np.array(prev_d) @ np.array(prev_d).T)):
+        np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-14)
