@@ -1,0 +1,79 @@
+"""The one-shot C entry points a reference-side ctypes stub binds:
+gl_log_degrees_fit, gl_logmodel_fit_signals, gl_theta_from_distances -- called here exactly as that
+stub calls them, against the golden vectors of the reference.  Needs an MI355X."""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+from scipy.spatial.distance import squareform
+
+from graph_learning_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["logmodel_n7_d23", "logmodel_n16_d40", "logmodel_n64_d256"]
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_log_degrees_fit_one_shot(golden, case):
+    g = golden(case)
+    ctx = _lib.default_context()
+    lib = ctx._lib
+    deg = int(g["deg"])
+    z = np.ascontiguousarray(g["z"] * float(g[f"theta_deg{deg}"]))
+    n = g["x"].shape[1]
+    # fixed iterations, no threshold
+    w = np.empty_like(z)
+    it, rel = C.c_int64(), (C.c_double * 2)()
+    ctx.check(lib.gl_log_degrees_fit(ctx.handle, _p(z), n, 1.0, 1.0, None, 50, 0.0, 0.5, -np.inf, _p(w), C.byref(it), rel),
+              "log_degrees_fit")
+    assert it.value == 50
+    np.testing.assert_allclose(w, g["raw_w_it50"], rtol=0, atol=1e-10)
+    # warm start
+    ei = np.ascontiguousarray(g["edge_init"])
+    ctx.check(lib.gl_log_degrees_fit(ctx.handle, _p(z), n, 1.0, 1.0, _p(ei), 30, 0.0, 0.5, -np.inf, _p(w), C.byref(it), rel),
+              "log_degrees_fit")
+    np.testing.assert_allclose(w, g["raw_w_warm_it30"], rtol=0, atol=1e-10)
+    # run to the reference's stopping iteration
+    ctx.check(lib.gl_log_degrees_fit(ctx.handle, _p(z), n, 1.0, 1.0, None, 100000, 1e-5, 0.5, -np.inf, _p(w), C.byref(it), rel),
+              "log_degrees_fit")
+    assert abs(it.value - int(g["n_iter_converged"])) <= 1
+    if it.value == int(g["n_iter_converged"]):
+        np.testing.assert_allclose(w, g["raw_w_converged"], rtol=0, atol=1e-10)
+    assert rel[0] < 1e-5 and rel[1] < 1e-5
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_logmodel_fit_signals_one_shot(golden, case):
+    g = golden(case)
+    ctx = _lib.default_context()
+    lib = ctx._lib
+    x = np.ascontiguousarray(g["x"])
+    d, n = x.shape
+    deg = int(g["deg"])
+    big_w = np.empty((n, n))
+    th, it, rel = C.c_double(), C.c_int64(), (C.c_double * 2)()
+    ctx.check(lib.gl_logmodel_fit_signals(ctx.handle, _p(x), d, n, deg, None, 1000, 1e-5, 0.5, 1e-3, _p(big_w),
+                                          C.byref(th), C.byref(it), rel), "logmodel_fit_signals")
+    assert th.value == pytest.approx(float(g[f"theta_deg{deg}"]), rel=1e-10)
+    assert abs(it.value - int(g["n_iter_default"])) <= 1
+    ref = g["weights_default"]
+    assert np.array_equal(big_w, big_w.T) and np.all(np.diag(big_w) == 0)
+    near = np.abs(squareform(g["raw_w_converged"], checks=False) - 1e-3) < 1e-6 if g["raw_w_converged"].ndim == 1 else False
+    ok = np.isclose(big_w, ref, rtol=0, atol=1e-6) | near
+    assert ok.all()
+
+
+def test_theta_from_distances_one_shot(golden):
+    g = golden("theta")
+    ctx = _lib.default_context()
+    zsq = np.ascontiguousarray(g["z"])
+    for k, ref in zip(g["k"], g["theta"]):
+        th = C.c_double()
+        ctx.check(ctx._lib.gl_theta_from_distances(ctx.handle, _p(zsq), zsq.shape[0], int(k), C.byref(th)), "theta")
+        assert (np.isinf(ref) and np.isinf(th.value)) or th.value == pytest.approx(ref, rel=1e-12)
