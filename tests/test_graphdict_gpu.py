@@ -194,3 +194,33 @@ def test_baseline_config5_size_first_step_closed_form():
     # relative changes reported by the step = the reference's relative_error(old, new)
     assert hist[0, 0] == pytest.approx(np.linalg.norm(c1 - c0) / np.linalg.norm(c0), rel=1e-10)
     assert hist[0, 1] == pytest.approx(np.linalg.norm(w1 - w0) / np.linalg.norm(w0), rel=1e-10)
+
+
+def test_predict_with_windows_against_oracle():
+    """predict (base_model.py:647-676) with window_size > 1, log_c reset active, more atoms."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((48, 9)) * 0.6
+    kw = dict(n_atoms=4, window_size=4, l1_c=0.01, log_c=0.02, step=0.3, max_iter=15, tol=0.0, random_state=8)
+    o = GraphDictLogOracle(**kw).fit(x)
+    m = GraphDictLog(**kw).fit(x)
+    close(m.weights_, o.weights_, 1e-10)
+    xp = rng.standard_normal((24, 9)) * 0.6
+    o.random_state = np.random.RandomState(5)
+    m.random_state = np.random.RandomState(5)
+    o.max_iter = m.max_iter = 25
+    o.tol = m.tol = 1e-6
+    close(m.predict(xp), o.predict(xp), 1e-10)
+
+
+def test_n_init_keeps_one_of_the_single_fits():
+    """n_init > 1 (base_model.py:611-640): every initialisation is fitted and the one with the lowest score
+    kept; the score's log-determinant term is rounding-fragile (see above), so the check is structural."""
+    x = np.random.default_rng(1).standard_normal((30, 6))
+    kw = dict(n_atoms=2, l1_w=0.05, step=0.5, max_iter=20, tol=0.0)
+    m = GraphDictLog(n_init=3, random_state=4, **kw).fit(x)
+    singles = []
+    rs = np.random.RandomState(4)
+    for _ in range(3):
+        singles.append(GraphDictLog(random_state=rs, **kw).fit(x).weights_)
+    assert any(np.array_equal(m.weights_, w) for w in singles)
+    assert m.coefficients_.shape == (2, 30) and m.history_.shape == (20, 2)
