@@ -30,6 +30,45 @@ def _spectral(gram: np.ndarray) -> float:
     return float(np.sqrt(max(np.linalg.eigvalsh(gram)[-1], 0.0)))
 
 
+def _run_sessions(sessions, ctx, maxit, tol, edge_tol):
+    """The coupled loop over initialised sessions -> ((B, E) thresholded weights, info)."""
+    n_batch = len(sessions)
+    handles = (C.c_void_p * n_batch)(*[s._h for s in sessions])
+    n_it, conv, rel = C.c_int64(0), C.c_int(0), (C.c_double * 2)(np.inf, np.inf)
+    ctx.check(ctx._lib.gl_logdeg_batch_iterate(handles, n_batch, int(maxit), float(tol), C.byref(n_it), C.byref(conv), rel),
+              "batch_iterate")
+    out = np.stack([s.weights_condensed(edge_tol) for s in sessions])  # (B, E) == edge_w.T (:174)
+    return out, {"n_iter": n_it.value, "rel_primal": float(rel[0]), "rel_dual": float(rel[1]),
+                 "converged": bool(conv.value)}
+
+
+def learn_log_degrees_from_signals(signal_blocks, avg_degree, alpha, beta, edge_init=None, maxit=1000, tol=1e-5,
+                                   step_size=0.5, edge_tol=1e-3, ctx=None):
+    """The batched solver fed with signals: block b (samples x nodes) gives graph b's squared distances (MFMA
+    Gram kernel) and theta on the device, where they stay -- no distance matrix travels to the host and back.
+    Used by ``WindowLogModel``.  -> (weights (B, E), thetas (B,), info)."""
+    blocks = [_lib.as_f64(b) for b in signal_blocks]
+    n = blocks[0].shape[1]
+    n_edges = n * (n - 1) // 2
+    n_batch = len(blocks)
+    if edge_init is not None:
+        edge_init = _lib.as_f64(edge_init)
+        if edge_init.shape != (n_edges, n_batch):
+            raise ValueError(f"edge_init must have shape ({n_edges}, {n_batch}) for batched input")
+    ctx = ctx or _lib.default_context()
+    sessions = [_lib.LogDegreeSession(n, ctx) for _ in range(n_batch)]
+    try:
+        thetas = []
+        for b, s in enumerate(sessions):
+            thetas.append(s.set_signals(blocks[b], avg_degree))  # distances scaled by theta, resident
+            s.init(alpha, beta, step_size, None if edge_init is None else np.ascontiguousarray(edge_init[:, b]))
+        out, info = _run_sessions(sessions, ctx, maxit, tol, edge_tol)
+    finally:
+        for s in sessions:
+            s.close()
+    return out, np.array(thetas), info
+
+
 def learn_log_degrees_batch(distances, alpha, beta, edge_init=None, maxit=1000, tol=1e-5, step_size=0.5,
                             edge_tol=1e-3, ctx=None, return_info=False):
     distances = _lib.as_f64(distances)
@@ -49,15 +88,10 @@ def learn_log_degrees_batch(distances, alpha, beta, edge_init=None, maxit=1000, 
         for b, s in enumerate(sessions):
             s.set_distances(distances[b])
             s.init(alpha, beta, step_size, None if edge_init is None else np.ascontiguousarray(edge_init[:, b]))
-        handles = (C.c_void_p * n_batch)(*[s._h for s in sessions])
-        n_it, conv, rel = C.c_int64(0), C.c_int(0), (C.c_double * 2)(np.inf, np.inf)
-        ctx.check(lib.gl_logdeg_batch_iterate(handles, n_batch, int(maxit), float(tol), C.byref(n_it), C.byref(conv), rel),
-                  "batch_iterate")
-        n_iter, converged, rel_p, rel_d = n_it.value, bool(conv.value), rel[0], rel[1]
-        out = np.stack([s.weights_condensed(edge_tol) for s in sessions])  # (B, E) == edge_w.T (:174)
+        out, info = _run_sessions(sessions, ctx, maxit, tol, edge_tol)
     finally:
         for s in sessions:
             s.close()
     if return_info:
-        return out, {"n_iter": n_iter, "rel_primal": float(rel_p), "rel_dual": float(rel_d), "converged": converged}
+        return out, info
     return out

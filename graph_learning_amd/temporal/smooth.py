@@ -47,10 +47,21 @@ class WindowLogModel(LogModel):
         return np.stack(dists)
 
     def fit(self, x, ctx=None):
-        sq_pdists = self._initialize(x, ctx)
-        out, info = gsp_learn_graph_log_degrees(sq_pdists * self.theta_, 1, 1, edge_init=self.edge_init,
-                                                maxit=self.maxit, tol=self.tol, step_size=self.step_size,
-                                                edge_tol=self.edge_tol, ctx=ctx, return_info=True)
+        """Same result as the reference's ``fit`` (``_initialize`` + the 2-D solver, :41-61 and
+        smooth_learning.py:286-300), with the windows' distances and thetas kept on the device."""
+        from ..batched import learn_log_degrees_from_signals
+
+        x = _lib.as_f64(x)
+        if x.ndim != 2:
+            raise ValueError(f"x must be (n_samples, n_nodes), got shape {x.shape}")
+        n_samples, n_nodes = x.shape
+        if (pad := n_samples % self.window_size) > 0:  # zero rows complete the last window (:44-45)
+            x = np.vstack((x, np.zeros((self.window_size - pad, n_nodes))))
+        windows = x.reshape(-1, self.window_size, n_nodes)
+        out, thetas, info = learn_log_degrees_from_signals(windows, self.avg_degree, 1, 1, edge_init=self.edge_init,
+                                                          maxit=self.maxit, tol=self.tol, step_size=self.step_size,
+                                                          edge_tol=self.edge_tol, ctx=ctx)
+        self.theta_ = 1 if self.avg_degree is None else thetas[:, None]
         self.weights_ = out
         self.n_iter_ = info["n_iter"]
         self.converged_ = info["converged"]
