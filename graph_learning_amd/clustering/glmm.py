@@ -42,6 +42,15 @@ def _estimate_gauss_laplacian_parameters(x, resp, delta: float, *, theta=None, a
     means = resp.T @ x / weights[:, np.newaxis]
     weights = weights / n_nodes
 
+    if avg_degree is not None and blocks is None:
+        # common case (KGraphs / GLMM with a scalar degree): distances and thetas of every cluster stay on the
+        # device and go straight into the batched solver
+        from ..batched import learn_log_degrees_from_signals
+
+        ys = [resp[:, k, np.newaxis] * (x - means[k]) for k in range(n_comp)]  # :65
+        out, _thetas, _info = learn_log_degrees_from_signals(ys, int(avg_degree), 1, 1, edge_init=edge_init, ctx=ctx)
+        return weights, means, laplacian_squareform_vec(delta * out, ctx=ctx)
+
     n_edges = n_nodes * (n_nodes - 1) // 2
     sq_dist = np.empty((n_comp, n_edges))
     theta_inv = None if avg_degree is None else []
