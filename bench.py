@@ -119,6 +119,8 @@ def main():
         gpu_ms = comm.max_over_ranks(gpu_ms)
 
     engine = sess.engine                                 # "resident" (n=4096 default) or "stream"
+    if engine == "resident" and args.steps < 16:         # calls shorter than 16 iterations run on the streaming engine
+        engine = "stream"
     edge_us = sess.time_edge_pass(200)                   # streaming edge pass alone, HIP events on its stream
     if comm is not None:
         edge_us = comm.max_over_ranks(edge_us)
