@@ -87,6 +87,7 @@ SIGNATURES = {
     "gl_graphdict_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gl_graphdict_set_params": (C.c_int, [C.c_void_p] + [C.c_double] * 8),
     "gl_graphdict_get_steps": (C.c_int, [C.c_void_p, _c_double_p]),
+    "gl_graphdict_engine": (C.c_int, [C.c_void_p]),
     "gl_graphdict_fit": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_void_p, _c_int64_p, _c_int64_p,
                                    _c_int_p]),
     "gl_graphdict_predict": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_void_p, _c_int64_p, _c_int_p]),
@@ -370,6 +371,11 @@ class GraphDictSession:
         out = (C.c_double * 3)()
         self.ctx.check(self._lib.gl_graphdict_get_steps(self._h, out), "graphdict_get_steps")
         return out[0], out[1], out[2]
+
+    @property
+    def engine(self) -> str:
+        """"small" (whole loop in one launch of one workgroup) or "launch" (one graph of kernels per step)."""
+        return "small" if self._lib.gl_graphdict_engine(self._h) == 1 else "launch"
 
     def fit(self, max_iter, tol, reduce_step_on_plateau=False):
         """-> (history (max_iter, 2), steps_run, converged_, flags)."""

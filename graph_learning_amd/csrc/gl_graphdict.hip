@@ -22,6 +22,7 @@
 // Weights live in WS: n_pad x n_pad x KP doubles, entry (i, j, k) for i < j < n, zero elsewhere
 // (the zero lower triangle doubles as the mask of the pair loops).  KP = K rounded up to 4/8/16.
 #include "gl_common.h"
+#include "gl_graphdict.h"
 #include "gl_lanes.h"
 
 #include <algorithm>
@@ -30,41 +31,6 @@
 #include <vector>
 
 namespace {
-
-constexpr int GD_MAXK = 16;
-constexpr int GD_SPL = 4;        // samples per lane in k_gd_grad_c
-constexpr int GD_SB = 64 * GD_SPL;  // samples per wave
-static inline int gd_rows_c(int KP) { return KP <= 8 ? 2 : 1; }  // rows per strip in k_gd_grad_c (SGPR budget)
-constexpr int GD_NORM_SLOTS = 8;
-
-struct GdDev {
-    int n, n_pad, T, Tp, Tw, W, K, KP;
-    int NG;     // strip groups of k_gd_grad_c (slabs of SC)
-    int TS;     // sample splits of k_gd_grad_w (slabs of GS)
-    int MS;     // sample splits of k_gd_m
-    double *X;        // Tp x n_pad
-    double *XT;       // n_pad x Tp
-    double *WS;       // n_pad x n_pad x KP
-    double *C;        // K x T: coefficients_, reference layout (repeated over windows)
-    double *CT;       // Tp x KP: the same, sample-major, zero padded
-    double *Cw;       // KP x Tw: new window coefficients of the running step
-    double *dual;     // Tw x n
-    double *deg;      // KP x n_pad: S W' of the current weights
-    double *deg_new;  // KP x n_pad: of the updated weights
-    double *SC;       // NG x KP x Tp: partial coefficient gradients
-    double *SCR;      // KP x Tp: their sum over the strip groups
-    double *cnorm;    // 256 x 3: per-workgroup partials of the coefficient change
-    double *GS;       // TS x n_pad x n_pad x KP: partial weight gradients
-    double *MSL;      // MS x KP x n_pad: partial sums of C @ dual
-    double *M;        // KP x n_pad
-    double *cpart;    // Tw: max |c_new| per window
-    double *wpart;    // (n * nbj) x 3: sum (w_new - w)^2, sum w^2, max |w| per (row, column block)
-    int2 *wtasks;     // (row strip, column block) tasks of k_gd_grad_w
-    int nwtasks;
-    double *stat;     // [0] rel change C, [1] rel change W, [2] flag "all coefficients dropped to 0"
-    // parameters of the step
-    double l1_w, ortho_w, l1_c, log_c, l1_diff_c, step_c, step_w, step_dual;
-};
 
 __device__ __forceinline__ double gd_wave_sum(double v) { return wave_sum(v); }  // gl_lanes.h
 __device__ __forceinline__ double gd_wave_max(double v) {
@@ -584,19 +550,6 @@ __global__ void k_gd_pack_c(GdDev P) {  // CT from C
 
 }  // namespace
 
-struct gl_graphdict {
-    gl_ctx *ctx = nullptr;
-    GdDev dev{};
-    double *stage = nullptr;  // device staging for host <-> device transfers of W (K x E) / x (T x n)
-    size_t stage_elems = 0;
-    bool have_x = false, have_state = false;
-    // one step (memset + 14 kernels + copy of the status words) captured per parity of the degree
-    // ping-pong and replayed: one graph launch per step instead of 16 enqueues (matters below ~1 ms/step)
-    hipGraphExec_t step_graph[2] = {nullptr, nullptr};
-    int step_parity = 0;  // which of (deg, deg_new) is current: flips with every step
-    double *dbgbuf = nullptr;  // tuning aid (GD_EXP & 8): 4 doubles per wave of k_gd_grad_w
-    std::vector<void *> allocs;
-};
 
 namespace {
 
@@ -904,6 +857,11 @@ GL_API int gl_graphdict_get_steps(gl_graphdict *s, double *steps3_out) {
     return GL_OK;
 }
 
+GL_API int gl_graphdict_engine(gl_graphdict *s) {
+    if (gd_check(s) != GL_OK) return -1;
+    return gd_small_applicable(s) ? 1 : 0;
+}
+
 // The loop of _single_fit (base_model.py:552-581).
 GL_API int gl_graphdict_fit(gl_graphdict *s, int64_t max_iter, double tol, int reduce_step_on_plateau,
                             double *history_out, int64_t *steps_run_out, int64_t *converged_out, int *flags_out) {
@@ -913,6 +871,12 @@ GL_API int gl_graphdict_fit(gl_graphdict *s, int64_t max_iter, double tol, int r
     if (max_iter < 0 || !history_out) return gl_set_error(ctx, GL_E_INVALID, "bad argument");
     GL_HIP(ctx, hipSetDevice(ctx->device));
     GdDev &P = s->dev;
+    if (gd_small_applicable(s)) {  // small problems: the whole loop in one launch of one workgroup
+        const double sc = P.step_c;
+        const int rc = gd_small_fit(s, max_iter, tol, reduce_step_on_plateau, history_out, steps_run_out, converged_out, flags_out);
+        if (P.step_c != sc) gd_drop_graphs(s);  // the plateau rule changed the steps frozen in the captured graphs
+        return rc;
+    }
     double *st = (double *)ctx->pinned;
     int64_t converged = -1, i = 0;
     int flags = 0;
@@ -962,6 +926,11 @@ GL_API int gl_graphdict_predict(gl_graphdict *s, int64_t max_iter, double tol, d
     hipStream_t st_ = ctx->stream;
     double *st = (double *)ctx->pinned;
     GL_HIP(ctx, hipMemsetAsync(P.dual, 0, (size_t)P.Tw * P.n * 8, st_));
+    if (gd_small_applicable(s)) {
+        GL_TRY(gd_small_predict(s, max_iter, tol, steps_run_out, flags_out));
+        GL_TRY(gl_d2h(ctx, coefficients_out, P.C, (size_t)P.K * P.T * 8));
+        return GL_OK;
+    }
     GL_TRY(gd_launch_grad_c(s));  // the weights never change: one pass over the pairs
     k_gd_sc_reduce<<<dim3((unsigned)(((int64_t)P.KP * P.Tp + 63) / 64)), dim3(64, 4), 0, st_>>>(P);
     int flags = 0;

@@ -221,6 +221,10 @@ int gl_graphdict_set_params(gl_graphdict *s, double l1_w, double ortho_w, double
                             double l1_diff_c, double step_c, double step_w, double step_dual);
 /* current (step_c, step_w, step_dual): reduce_step_on_plateau shrinks them (base_model.py:571-573) */
 int gl_graphdict_get_steps(gl_graphdict *s, double *steps3_out);
+/* Which form fit / predict will take for this session: 1 = the whole loop in one launch of one workgroup
+ * (state in LDS; small problems such as the reference's tests/test_models.py shape), 0 = one captured graph
+ * of kernels per step.  GRAPHLEARN_AMD_GD_ENGINE = launch | small overrides the choice. */
+int gl_graphdict_engine(gl_graphdict *s);
 /* The loop of _single_fit (base_model.py:552-581): up to max_iter steps of _fit_step (:485-527);
  * history_out is (max_iter, 2) = relative change of coefficients / weights per step (-1 where not
  * run); converged_out = converged_ (step index or -1; the loop stops only at an index > 0, :578);

@@ -31,6 +31,14 @@ def quiet():
         yield
 
 
+@pytest.fixture(autouse=True, params=["launch", "small"])
+def engine(request, monkeypatch):
+    """Every case runs on both forms of the loop: one captured graph of kernels per step, and the
+    single-workgroup kernel that holds the state in LDS (taken wherever the problem fits it)."""
+    monkeypatch.setenv("GRAPHLEARN_AMD_GD_ENGINE", request.param)
+    return request.param
+
+
 def close(a, b, tol):
     np.testing.assert_allclose(a, b, rtol=tol, atol=tol)
 
@@ -140,6 +148,20 @@ def test_reduce_step_on_plateau_against_oracle(golden):
     m = GraphDictLog(**kw).fit(g["A_x"])
     assert (m.step_c, m.step_w, m.step_dual) == pytest.approx((o.step_c, o.step_w, o.step_dual))
     close(m.history_.to_numpy(), o.history_, 1e-6)
+
+
+def test_engine_choice(monkeypatch, engine):
+    """The reference's own test shape (7 nodes, 23 samples) takes the single-workgroup form by default."""
+    with _lib.GraphDictSession(7, 23, 3) as s:
+        assert s.engine == engine
+    monkeypatch.delenv("GRAPHLEARN_AMD_GD_ENGINE")
+    with _lib.GraphDictSession(7, 23, 3) as s:
+        assert s.engine == "small"
+    with _lib.GraphDictSession(256, 512, 8) as s:
+        assert s.engine == "launch"
+    monkeypatch.setenv("GRAPHLEARN_AMD_GD_ENGINE", "small")  # forced, but it has to fit the LDS of one CU
+    with _lib.GraphDictSession(256, 512, 8) as s:
+        assert s.engine == "launch"
 
 
 def test_errors():
