@@ -339,6 +339,7 @@ __global__ __launch_bounds__(256) void k_lg_admm_res(LgDev D, GlGridBar gb, int 
     __shared__ double s_acc[4][ADMM_RES_MAXR];
     __shared__ double s_x[ADMM_RES_MAXR];
     __shared__ int s_ok, s_stop;
+    if (D.scal[8] != 0.0) return;  // an earlier QP could not run (workgroups not co-resident): the host redoes the cycle
     const int64_t n = D.n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = gridDim.x;
@@ -476,6 +477,248 @@ __global__ __launch_bounds__(256) void k_lg_admm_res(LgDev D, GlGridBar gb, int 
 }
 
 // ------------------------------------------------------------------------------------------
+// The persistent ADMM without a grid barrier ("tagged" form).  The only thing a step needs from the other
+// workgroups is the right-hand side v, so v itself carries the synchronisation: entry j is published as
+// a 16-byte record of two self-validating 8-byte granules {low word, tag}, {high word, tag} (one
+// write-through store), tag = step the value is the input of, and a consumer simply re-reads its
+// columns (sc1 loads, served past the L1) until every tag matches -- the hand-off recipe "R2: the data is
+// the flag" of the CDNA4 guide.  One memory round trip per step instead of store + barrier + load, and
+// one workgroup barrier.
+//   * ping-pong of the record array by step parity is enough: a workgroup publishes tag s+1 only after it
+//     has read every record of tag s, so nobody still reads the records (tag s-1) it overwrites;
+//   * the stopping rule (lgmrf.py:66-69) needs all workgroups' norm partials of a step.  They are stored
+//     (sc1) after the records of that step, and the storing wave drains (s_waitcnt vmcnt(0), free by then)
+//     before it publishes the next records: whoever has seen a workgroup's tag s+2 may read its partials
+//     of step s.  They are requested at the end of step s+2 and summed at step s+3 (their latency, 1.8 us
+//     when waited for, hides behind a whole step), by every workgroup from the same values in the same
+//     order, and three generations of the row state stay in registers to return the one of step s.
+//     Partials live in a ring of four slots: a writer is never more than three steps ahead of a reader.
+// Needs all workgroups co-resident like the barrier form (start-up rendezvous, bounded spins).
+typedef unsigned int lg_u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double lg_pack(unsigned lo, unsigned hi) {
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+__global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, GlGridBar gb, lg_u4 *gran, unsigned tag0, int R, int max_iter) {
+    extern __shared__ double s_W[];  // R rows of W, row-major (R * n doubles)
+    __shared__ double s_acc[2][4][ADMM_RES_MAXR];
+    __shared__ int s_ok, s_fail, s_stop[2];
+    if (D.scal[8] != 0.0) return;  // an earlier QP could not run (workgroups not co-resident): the host redoes the cycle
+    const int64_t n = D.n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * R;
+    const int nrows = (int)max((int64_t)0, min((int64_t)R, n - r0));
+
+    for (int64_t q = tid; q < (int64_t)nrows * n; q += 256) s_W[q] = D.W[r0 * n + q];
+    GlBarState bs{};
+    if (tid == 0) {
+        s_ok = gl_barrier_setup(gb, bs) ? 1 : 0;
+        s_fail = 0;
+    }
+    __syncthreads();
+    if (!s_ok) {
+        if (blockIdx.x == 0 && tid == 0) D.scal[8] = 1.0;
+        return;
+    }
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)gran, 0, (int)(2 * n * 16), 0x00020000);
+    const auto prsrc = __builtin_amdgcn_make_buffer_rsrc((void *)D.part, 0, (int)(4 * nblk * 48), 0x00020000);
+    auto publish = [&](int parity, int64_t i, double v, unsigned tag) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        lg_u4 g;
+        g.x = (unsigned)b, g.y = tag, g.z = (unsigned)(b >> 32), g.w = tag;
+        __builtin_amdgcn_raw_buffer_store_b128(g, rsrc, (int)((parity * n + i) * 16), 0, 16);  // aux 16 = sc1
+    };
+    // thread r < nrows owns row r0 + r; three generations of its ADMM state stay in registers
+    double xo = 0, zo = 0, uo = 0, pi = 0, on = 0;
+    double x1 = 0, z1 = 0, u1 = 0, x2g = 0, z2g = 0, u2g = 0;  // the state one / two steps earlier
+    if (tid < nrows) {
+        const int64_t i = r0 + tid;
+        xo = D.x[i];
+        zo = D.z[i];
+        uo = D.uu[i];
+        pi = D.p[i];
+        on = D.act[i];
+        publish(0, i, D.v[i], tag0);  // the input of step 0
+    }
+    lg_u4 pr[4][3];  // wave 0: the partials {dx2, x2 | xm, dz2 | z2, zm} of workgroups lane, lane + 64, ...
+    bool pending = false;
+    int steps = 0;
+    bool stopped = false, failed = false;
+    for (int it = 0; it <= max_iter + 1; ++it) {
+        // (1) my columns of v: thread t takes columns t, t + 256, ...; re-read until every record carries this step's tag
+        const unsigned tag = tag0 + (unsigned)it;
+        double vj[ADMM_RES_MAXR];
+        if (it <= max_iter) {
+            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+            bool good = true;
+            for (unsigned spins = 0;; ++spins) {
+                bool ok = true;
+#pragma unroll
+                for (int c = 0; c < ADMM_RES_MAXR; ++c) {
+                    const int64_t j = tid + 256 * (int64_t)c;
+                    lg_u4 g = {0u, tag, 0u, tag};
+                    if (j < n) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((((it & 1) * n) + j) * 16), 0, 16);
+                    ok = ok && g.y == tag && g.w == tag;
+                    vj[c] = lg_pack(g.x, g.z);
+                }
+                asm volatile("" ::: "memory");  // the loads stay in the loop
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(4);  // ~0.1 us: leave the fabric to the stores we wait for
+                if ((spins & 63u) == 63u &&
+                    (gl_ld_u32(gb.bar + 32) != 0u || __builtin_amdgcn_s_memrealtime() - t_start > 100000000ull)) {
+                    good = false;  // 1 s: a producer is gone
+                    break;
+                }
+            }
+            if (!good) s_fail = 1;
+        }
+        // (2) the rule of step it-3 from the partials requested one step ago (all arrived by now)
+        if (wave == 0) {
+            int stop = 0;
+            if (pending) {
+                double a0 = 0, a1 = 0, a3 = 0, a4 = 0, m2 = 0, m5 = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (lane + 64 * q < nblk) {
+                        a0 += lg_pack(pr[q][0].x, pr[q][0].y);
+                        a1 += lg_pack(pr[q][0].z, pr[q][0].w);
+                        m2 = fmax(m2, lg_pack(pr[q][1].x, pr[q][1].y));
+                        a3 += lg_pack(pr[q][1].z, pr[q][1].w);
+                        a4 += lg_pack(pr[q][2].x, pr[q][2].y);
+                        m5 = fmax(m5, lg_pack(pr[q][2].z, pr[q][2].w));
+                    }
+                a0 = wsum(a0);
+                a1 = wsum(a1);
+                a3 = wsum(a3);
+                a4 = wsum(a4);
+                m2 = wmax(m2);
+                m5 = wmax(m5);
+                // relative_error(prev, new): plain norm when prev is allclose to 0 (atol 1e-8)
+                const double rx = (m2 <= 1e-8) ? sqrt(a0) : sqrt(a0) / sqrt(a1);
+                const double rz = (m5 <= 1e-8) ? sqrt(a3) : sqrt(a3) / sqrt(a4);
+                stop = (rx < D.qp_tol && rz < D.qp_tol) ? 1 : 0;
+            }
+            if (lane == 0) s_stop[it & 1] = stop;
+        }
+        // (3) my rows times v
+        if (it < max_iter) {
+            double acc[ADMM_RES_MAXR];
+#pragma unroll
+            for (int r = 0; r < ADMM_RES_MAXR; ++r) acc[r] = 0.0;
+#pragma unroll
+            for (int c = 0; c < ADMM_RES_MAXR; ++c) {
+                const int64_t j = tid + 256 * (int64_t)c;
+                if (j < n) {
+#pragma unroll
+                    for (int r = 0; r < ADMM_RES_MAXR; ++r)
+                        if (r < nrows) acc[r] += s_W[(int64_t)r * n + j] * vj[c];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < ADMM_RES_MAXR; ++r) acc[r] = wsum(acc[r]);
+            if (lane == 0) {
+#pragma unroll
+                for (int r = 0; r < ADMM_RES_MAXR; ++r) s_acc[it & 1][wave][r] = acc[r];
+            }
+        }
+        __syncthreads();
+        if (s_fail) {
+            failed = true;
+            break;
+        }
+        if (s_stop[it & 1]) {  // step it-3 met the rule: its z is the result, the steps after it are dropped
+            stopped = true;
+            if (it <= max_iter) xo = x2g, zo = z2g, uo = u2g;
+            else xo = x1, zo = z1, uo = u1;  // the last pass follows a pass without an update
+            steps = it - 2;
+            break;
+        }
+        // (4) row-local updates (lgmrf.py:57-69), the records of the next step, the partial norms of this one
+        if (it < max_iter) {
+            double dx2 = 0, x2 = 0, xm = 0, dz2 = 0, z2 = 0, zm = 0;
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my partials of step it-1 have left before tag it+1 does
+            if (tid < nrows) {
+                const bool active = on != 0.0;
+                const double sx = ((s_acc[it & 1][0][tid] + s_acc[it & 1][1][tid]) + s_acc[it & 1][2][tid]) + s_acc[it & 1][3][tid];
+                const double xn = active ? sx : 0.0;
+                double zn = xn + uo;
+                zn = zn < 0 ? 0.0 : zn;
+                const double un = uo + (xn - zn);
+                if (active) {
+                    dx2 = (xn - xo) * (xn - xo);
+                    x2 = xo * xo;
+                    xm = fabs(xo);
+                    dz2 = (zn - zo) * (zn - zo);
+                    z2 = zo * zo;
+                    zm = fabs(zo);
+                }
+                x2g = x1, z2g = z1, u2g = u1;
+                x1 = xo, z1 = zo, u1 = uo;
+                xo = xn;
+                zo = active ? zn : 0.0;
+                uo = active ? un : 0.0;
+                publish((it + 1) & 1, r0 + tid, active ? (zn - un) + D.rho * pi : 0.0, tag + 1u);
+            }
+            if (wave == 0) {  // rows live in lanes 0..R-1 of wave 0: fixed-order sums over those lanes
+                dx2 = wsum(dx2);
+                x2 = wsum(x2);
+                xm = wmax(xm);
+                dz2 = wsum(dz2);
+                z2 = wsum(z2);
+                zm = wmax(zm);
+                if (lane == 0) {
+                    const int off = ((it & 3) * nblk + (int)blockIdx.x) * 48;
+                    auto st2 = [&](int o, double a, double b) {
+                        const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+                        lg_u4 g;
+                        g.x = (unsigned)ua, g.y = (unsigned)(ua >> 32), g.z = (unsigned)ub, g.w = (unsigned)(ub >> 32);
+                        __builtin_amdgcn_raw_buffer_store_b128(g, prsrc, off + o, 0, 16);
+                    };
+                    st2(0, dx2, x2);
+                    st2(16, xm, dz2);
+                    st2(32, z2, zm);
+                }
+            }
+            steps = it + 1;
+        }
+        // (5) request the partials of step it-2 (every workgroup's tag `it` has been seen); summed one step later
+        pending = false;
+        if (it <= max_iter && it >= 3) {  // never for step 0 (`it > 0` in the reference's rule)
+            pending = true;
+            if (wave == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (lane + 64 * q < nblk) {
+                        const int off = (((it - 2) & 3) * nblk + lane + 64 * q) * 48;
+                        pr[q][0] = __builtin_amdgcn_raw_buffer_load_b128(prsrc, off, 0, 16);
+                        pr[q][1] = __builtin_amdgcn_raw_buffer_load_b128(prsrc, off + 16, 0, 16);
+                        pr[q][2] = __builtin_amdgcn_raw_buffer_load_b128(prsrc, off + 32, 0, 16);
+                    }
+            }
+        }
+    }
+    if (failed) {
+        if (tid == 0) {
+            __hip_atomic_store(gb.bar + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (blockIdx.x == 0) D.scal[8] = 2.0;  // a hand-off was lost in mid-run
+        }
+        return;
+    }
+    if (tid < nrows) {
+        const int64_t i = r0 + tid;
+        D.x[i] = xo;
+        D.z[i] = zo;
+        D.uu[i] = uo;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        D.scal[1] = (double)steps;
+        D.scal[0] = stopped ? 1.0 : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // The same ADMM for small problems (n <= 64) in ONE launch of ONE workgroup: the whole explicit inverse
 // (<= 128 KiB) in LDS (transposed, so a wave's lanes read consecutive addresses), v double-buffered in
 // LDS, 8 threads per row, row sums combined by DPP, the
@@ -588,35 +831,44 @@ struct AdmmRes {
     int R = 0, nwg = 0;
     size_t lds = 0;
     unsigned *bar = nullptr;
+    // "tagged" form (k_lg_admm_tag): v travels as self-validating records, no grid barrier
+    bool tagged = false;
+    lg_u4 *gran = nullptr;  // [2][n] records of 16 bytes
+    unsigned seq = 0;       // launches so far: the tags of a launch are 128 seq + 1 + step
 };
 
+// Which form the QP's ADMM loop takes.  GRAPHLEARN_AMD_LGMRF_ADMM = launch | one | resident | tagged forces
+// one (where it applies).  Measured per node-update, one cycle of the config-3 input (every QP runs its
+// 100 steps), launch / grid-barrier / tagged:  n = 128: 0.66 / 0.61 / 0.38 ms,  256: 0.67 / 0.72 / 0.39,
+// 500: 0.90 / 0.81 / 0.46,  1024: 0.96 / 0.89 / 0.56,  2048: 1.62 / 1.20 / 0.80;  single workgroup
+// against tagged at n = 32: 0.26 / 0.20, n = 64: 0.48 / 0.30.
+constexpr int ADMM_ONE_AUTO = 16;  // below this the single-workgroup form is the default
+
 int admm_res_plan(gl_ctx *ctx, int64_t n, AdmmRes &A) {
-    A.on = A.one = false;
-    if (const char *e = getenv("GRAPHLEARN_AMD_LGMRF_ADMM"))
-        if (!strcmp(e, "launch")) return GL_OK;
-    if (n <= ADMM_ONE_MAXN) {
-        const char *e = getenv("GRAPHLEARN_AMD_LGMRF_ADMM");
-        if (!(e && !strcmp(e, "resident"))) {  // "resident" asks for the multi-workgroup form (tests)
-            A.lds = ((size_t)n * n + 2 * n + 6 * 16) * 8;
-            GL_HIP(ctx, hipFuncSetAttribute((const void *)k_lg_admm_one, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A.lds));
-            A.one = true;
-            return GL_OK;
-        }
+    A.on = A.one = A.tagged = false;
+    const char *force = getenv("GRAPHLEARN_AMD_LGMRF_ADMM");
+    auto is = [&](const char *v) { return force && !strcmp(force, v); };
+    if (is("launch")) return GL_OK;
+    if (n <= ADMM_ONE_MAXN && (is("one") || (!force && n <= ADMM_ONE_AUTO))) {
+        A.lds = ((size_t)n * n + 2 * n + 6 * 16) * 8;
+        GL_HIP(ctx, hipFuncSetAttribute((const void *)k_lg_admm_one, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A.lds));
+        A.one = true;
+        return GL_OK;
     }
     const int ncu = ctx->prop.multiProcessorCount;
-    const int R = (int)((n + ncu - 1) / ncu);
+    int R = (int)((n + ncu - 1) / ncu);
+    // a few rows per workgroup even when there are CUs to spare: fewer parties in the hand-off of v
+    // (n = 256: 1 / 2 / 4 / 8 rows: 0.455 / 0.399 / 0.385 / 0.397 ms per node-update)
+    R = std::max<int>(R, (int)std::min<int64_t>(4, (n + 63) / 64));
+    if (const char *e = getenv("GRAPHLEARN_AMD_LGMRF_R")) R = std::max(R, std::min(ADMM_RES_MAXR, atoi(e)));  // tuning aid
     const size_t lds = (size_t)R * n * 8;
-    if (R > ADMM_RES_MAXR || lds > 150 * 1024) return GL_OK;
-    // A persistent step costs ~6-7 us whatever n is (barrier + one exchange of v through memory); a
-    // launch-per-step costs ~5 us + the stream of W and a host poll every 16-24 steps.  Measured per
-    // node-update (persistent vs launched): n = 256: 0.76 vs 0.70 ms, 400: 0.77 vs 0.90, 700: 0.85 vs 0.89,
-    // 1000: 0.90 vs 1.09, 2048: 1.19 vs 1.63.
-    const char *force = getenv("GRAPHLEARN_AMD_LGMRF_ADMM");
-    if (n < 384 && !(force && !strcmp(force, "resident"))) return GL_OK;
+    if (R > ADMM_RES_MAXR || lds > 150 * 1024) return GL_OK;  // one launch per step
     A.R = R;
     A.nwg = (int)((n + R - 1) / R);
     A.lds = lds;
-    GL_HIP(ctx, hipFuncSetAttribute((const void *)k_lg_admm_res, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    A.tagged = !is("resident");  // "resident" keeps the grid-barrier form (tests, comparison)
+    GL_HIP(ctx, hipFuncSetAttribute(A.tagged ? (const void *)k_lg_admm_tag : (const void *)k_lg_admm_res,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     A.on = true;
     return GL_OK;
 }
@@ -627,9 +879,21 @@ int run_admm_one(gl_ctx *ctx, const LgDev &D, const AdmmRes &A, int max_iter) {
     return GL_OK;
 }
 
-int run_admm_res(gl_ctx *ctx, const LgDev &D, const AdmmRes &A, int max_iter) {
+int run_admm_res(gl_ctx *ctx, const LgDev &D, AdmmRes &A, int max_iter) {
     GL_HIP(ctx, hipMemsetAsync(A.bar, 0, GL_BAR_WORDS * 4, ctx->stream));
-    const GlGridBar gb{A.bar, A.nwg};
+    const bool test_not_resident = getenv("GRAPHLEARN_AMD_LGMRF_TEST_NOT_RESIDENT") != nullptr;  // tests: the rendezvous can never complete
+    const GlGridBar gb{A.bar, A.nwg + (test_not_resident ? 1 : 0)};
+    if (A.tagged) {
+        if (max_iter > 120) return gl_set_error(ctx, GL_E_INVALID, "tagged ADMM form: max_iter <= 120");
+        if (A.seq >= (1u << 24)) {  // tags would wrap into old ones: start over on clean records
+            GL_HIP(ctx, hipMemsetAsync(A.gran, 0, (size_t)2 * D.n * 16, ctx->stream));
+            A.seq = 0;
+        }
+        const unsigned tag0 = 128u * A.seq++ + 1u;
+        k_lg_admm_tag<<<dim3((unsigned)A.nwg), 256, A.lds, ctx->stream>>>(D, gb, A.gran, tag0, A.R, max_iter);
+        GL_HIP(ctx, hipGetLastError());
+        return GL_OK;
+    }
     k_lg_admm_res<<<dim3((unsigned)A.nwg), 256, A.lds, ctx->stream>>>(D, gb, A.R, max_iter);
     GL_HIP(ctx, hipGetLastError());
     return GL_OK;
@@ -870,11 +1134,15 @@ GL_API int gl_nonneg_qp_solve(gl_ctx *ctx, const double *mat, const double *vec,
     GL_HIP(ctx, hipSetDevice(ctx->device));
     Buf W, vecs, scal, part, bar;
     GL_HIP(ctx, hipMalloc(&W.p, (size_t)m * m * 8));
-    GL_HIP(ctx, hipMalloc(&part.p, (size_t)2 * m * 6 * 8));  // one entry per workgroup, either ADMM form
+    Buf gran;
+    GL_HIP(ctx, hipMalloc(&part.p, (size_t)4 * m * 6 * 8));  // one entry per workgroup and ring slot, any ADMM form
     GL_HIP(ctx, hipMalloc(&bar.p, GL_BAR_WORDS * 4));
+    GL_HIP(ctx, hipMalloc(&gran.p, (size_t)2 * m * 16));
+    GL_HIP(ctx, hipMemsetAsync(gran.p, 0, (size_t)2 * m * 16, ctx->stream));
     AdmmRes ares;
     GL_TRY(admm_res_plan(ctx, m, ares));
     ares.bar = (unsigned *)bar.p;
+    ares.gran = (lg_u4 *)gran.p;
     GL_HIP(ctx, hipMalloc(&vecs.p, (size_t)16 * m * 8));
     GL_HIP(ctx, hipMalloc(&scal.p, 16 * 8));
     double *V = (double *)vecs.p;
@@ -910,10 +1178,16 @@ GL_API int gl_nonneg_qp_solve(gl_ctx *ctx, const double *mat, const double *vec,
     GL_TRY(ares.one ? run_admm_one(ctx, D, ares, max_iter)
                     : (ares.on ? run_admm_res(ctx, D, ares, max_iter) : run_admm(ctx, D, max_iter)));
     double sc[9];
-    GL_TRY(gl_d2h(ctx, z_out, D.z, (size_t)m * 8));
     GL_HIP(ctx, hipMemcpyAsync(sc, D.scal, 9 * 8, hipMemcpyDeviceToHost, ctx->stream));
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (sc[8] != 0.0) return gl_set_error(ctx, GL_E_HIP, "ADMM: grid barrier timed out (workgroups not co-resident; GRAPHLEARN_AMD_LGMRF_ADMM=launch avoids it)");
+    if (ares.on && sc[8] == 1.0) {  // the workgroups were not co-resident; nothing was touched: one launch per step instead
+        GL_HIP(ctx, hipMemsetAsync(D.scal, 0, 16 * 8, ctx->stream));
+        GL_TRY(run_admm(ctx, D, max_iter));
+        GL_HIP(ctx, hipMemcpyAsync(sc, D.scal, 9 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (sc[8] != 0.0) return gl_set_error(ctx, GL_E_HIP, "ADMM: a hand-off between workgroups was lost in mid-run (GRAPHLEARN_AMD_LGMRF_ADMM=launch avoids the persistent forms)");
+    GL_TRY(gl_d2h(ctx, z_out, D.z, (size_t)m * 8));
     if (iters_out) *iters_out = (int)sc[1];
     return GL_OK;
 }
@@ -953,11 +1227,16 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
     GL_HIP(ctx, hipMalloc(&bScal.p, 16 * 8));
     GL_HIP(ctx, hipMalloc(&bPart.p, 3 * 256 * 8));
     Buf bAdmm, bBar;
-    GL_HIP(ctx, hipMalloc(&bAdmm.p, (size_t)2 * n * 6 * 8));  // one entry per workgroup, either ADMM form
+    Buf bGran, bCprev;
+    GL_HIP(ctx, hipMalloc(&bAdmm.p, (size_t)4 * n * 6 * 8));  // one entry per workgroup and ring slot, any ADMM form
     GL_HIP(ctx, hipMalloc(&bBar.p, GL_BAR_WORDS * 4));
+    GL_HIP(ctx, hipMalloc(&bGran.p, (size_t)2 * n * 16));
+    GL_HIP(ctx, hipMemsetAsync(bGran.p, 0, (size_t)2 * n * 16, ctx->stream));
     AdmmRes ares;
     GL_TRY(admm_res_plan(ctx, n, ares));
     ares.bar = (unsigned *)bBar.p;
+    ares.gran = (lg_u4 *)bGran.p;
+    if (ares.on) GL_HIP(ctx, hipMalloc(&bCprev.p, (size_t)n * n * 8));
     GL_HIP(ctx, hipMemsetAsync(bVec.p, 0, (size_t)16 * n * 8, ctx->stream));
     GL_HIP(ctx, hipMemsetAsync(bScal.p, 0, 16 * 8, ctx->stream));
 
@@ -1002,6 +1281,7 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
     int converged = -1, cycles = 0;
     for (int cycle = 0; cycle < max_cycle; ++cycle) {
         GL_HIP(ctx, hipMemcpyAsync(D.ThPrev, D.Th, nn, hipMemcpyDeviceToDevice, ctx->stream));  // l_pre (:173)
+        if (ares.on) GL_HIP(ctx, hipMemcpyAsync(bCprev.p, D.C, nn, hipMemcpyDeviceToDevice, ctx->stream));  // to redo the cycle
         if (fast) {  // fresh G = (Theta + rho I)^-1 once per cycle; rank-2 corrections in between
             k_lg_shift<<<g2, 256, 0, ctx->stream>>>(D.Th, D.G, n, D.rho);
             GL_TRY(invert_spd_inplace(ctx, D.G, n, pivrow));
@@ -1033,9 +1313,18 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
             double flag = 0;
             GL_HIP(ctx, hipMemcpyAsync(&flag, D.scal + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
             GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (flag == 1.0) {  // the workgroups were not co-resident (another process holds CUs): every later QP of the
+                                // cycle has left at once; restore the cycle's start and redo it with one launch per step
+                GL_HIP(ctx, hipMemcpyAsync(D.Th, D.ThPrev, nn, hipMemcpyDeviceToDevice, ctx->stream));
+                GL_HIP(ctx, hipMemcpyAsync(D.C, bCprev.p, nn, hipMemcpyDeviceToDevice, ctx->stream));
+                GL_HIP(ctx, hipMemsetAsync(D.scal, 0, 16 * 8, ctx->stream));
+                ares.on = false;
+                --cycle;
+                continue;
+            }
             if (flag != 0.0)
-                return gl_set_error(ctx, GL_E_HIP, "LGMRF: grid barrier of the ADMM kernel timed out (workgroups not "
-                                                    "co-resident; GRAPHLEARN_AMD_LGMRF_ADMM=launch avoids it)");
+                return gl_set_error(ctx, GL_E_HIP, "LGMRF: a hand-off between the workgroups of the ADMM kernel was lost in "
+                                                    "mid-run (GRAPHLEARN_AMD_LGMRF_ADMM=launch avoids the persistent forms)");
         }
         if (cycle > 4) {  // :221
             double rel = 0;

@@ -16,11 +16,12 @@ from oracle import lgmrf as olg
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["launch", "resident", "auto"])
+@pytest.fixture(autouse=True, params=["launch", "one", "resident", "tagged", "auto"])
 def admm_form(request, monkeypatch):
-    """Every test runs with the three forms of the QP's ADMM loop: one launch per step, the persistent
-    multi-workgroup kernel (matrix rows resident in LDS, grid barriers; default from n = 384) and the
-    automatic choice, which for n <= 64 is the single-workgroup kernel."""
+    """Every test runs with every form of the QP's ADMM loop: one launch per step, the single-workgroup
+    kernel (n <= 64, whole inverse in LDS), the persistent multi-workgroup kernels (matrix rows resident
+    in LDS; steps separated by grid barriers, or the right-hand side handed over as self-validating
+    tagged records) and the automatic choice (single workgroup to n = 16, tagged above)."""
     if request.param == "auto":
         monkeypatch.delenv("GRAPHLEARN_AMD_LGMRF_ADMM", raising=False)
     else:
@@ -110,3 +111,18 @@ def test_fast_path_matches_general_path_and_oracle_n96():
         m = LGMRF().fit(cov.copy(), path=path)
         assert m.converged_ == o.converged_
         assert close(m.laplacian_, o.laplacian_) and close(m.inv_laplacian_, o.inv_laplacian_)
+
+
+def test_persistent_forms_fall_back_when_not_co_resident(golden, monkeypatch, admm_form):
+    """The persistent kernels need all their workgroups on the chip at once.  With the test hook the
+    start-up rendezvous can never complete: the QP entry point reruns with one launch per step, the fit
+    restores the start of the cycle and redoes it that way -- same results, about a second later."""
+    if admm_form not in ("resident", "tagged"):
+        pytest.skip("only the persistent forms have a rendezvous")
+    monkeypatch.setenv("GRAPHLEARN_AMD_LGMRF_TEST_NOT_RESIDENT", "1")
+    g = golden("lgmrf")
+    z = nonnegative_qp_solver(g["qp_a_Q"], g["qp_a_p"], step=0.1, tol=float(g["qp_a_tol"]), max_iter=int(g["qp_a_maxit"]))
+    np.testing.assert_allclose(z, g["qp_a_z"], rtol=0, atol=1e-7)
+    m = LGMRF().fit(g["cov_16"].copy())
+    assert m.converged_ == int(g["conv_16_np1_rt1"])
+    assert close(m.laplacian_, g["lapl_16_np1_rt1"]) and close(m.inv_laplacian_, g["inv_16_np1_rt1"])
