@@ -493,17 +493,20 @@ __global__ __launch_bounds__(256) void k_lg_admm_res(LgDev D, GlGridBar gb, int 
 //     when waited for, hides behind a whole step), by every workgroup from the same values in the same
 //     order, and three generations of the row state stay in registers to return the one of step s.
 //     Partials live in a ring of four slots: a writer is never more than three steps ahead of a reader.
-// Needs all workgroups co-resident like the barrier form (start-up rendezvous, bounded spins).
+// Needs all workgroups co-resident like the barrier form; there is no rendezvous: the first poll is one (a
+// workgroup that is not on the chip never publishes tag 0), every spin is bounded by the wall clock, and a
+// run that gives up has written nothing but records.
 typedef unsigned int lg_u4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double lg_pack(unsigned lo, unsigned hi) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-__global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, GlGridBar gb, lg_u4 *gran, unsigned tag0, int R, int max_iter) {
+__global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u4 *gran, unsigned tag0, int R, int max_iter,
+                                                     int64_t u_fast, int test_missing) {
     extern __shared__ double s_W[];  // R rows of W, row-major (R * n doubles)
     __shared__ double s_acc[2][4][ADMM_RES_MAXR];
-    __shared__ int s_ok, s_fail, s_stop[2];
+    __shared__ int s_fail, s_stop[2];
     if (D.scal[8] != 0.0) return;  // an earlier QP could not run (workgroups not co-resident): the host redoes the cycle
     const int64_t n = D.n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -511,17 +514,26 @@ __global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, GlGridBar gb, lg_u
     const int64_t r0 = (int64_t)blockIdx.x * R;
     const int nrows = (int)max((int64_t)0, min((int64_t)R, n - r0));
 
-    for (int64_t q = tid; q < (int64_t)nrows * n; q += 256) s_W[q] = D.W[r0 * n + q];
-    GlBarState bs{};
-    if (tid == 0) {
-        s_ok = gl_barrier_setup(gb, bs) ? 1 : 0;
-        s_fail = 0;
+    if (u_fast >= 0) {
+        // fast path: my rows of the explicit inverse straight from G = (Theta + rho I)^-1, the formula of
+        // k_lg_build_winv:  inv(I + rho M) = I - rho (G_mm - g g'/G_uu),  g = G[:,u] (left in gcol by
+        // k_lg_qp_setup), identity on row / column u -- W itself is never written or read
+        const double guu = D.G[u_fast * n + u_fast];
+        for (int r = 0; r < nrows; ++r) {
+            const int64_t i = r0 + r;
+            const double gi = D.gcol[i];
+            const double *grow = D.G + i * n;
+            for (int j = tid; j < (int)n; j += 256) {
+                double w = (i == j) ? 1.0 : 0.0;
+                if (i != u_fast && j != u_fast) w -= D.rho * (grow[j] - (gi * D.gcol[j]) / guu);
+                s_W[r * (int)n + j] = w;
+            }
+        }
+    } else {
+        for (int64_t q = tid; q < (int64_t)nrows * n; q += 256) s_W[q] = D.W[r0 * n + q];
     }
+    if (tid == 0) s_fail = 0;
     __syncthreads();
-    if (!s_ok) {
-        if (blockIdx.x == 0 && tid == 0) D.scal[8] = 1.0;
-        return;
-    }
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)gran, 0, (int)(2 * n * 16), 0x00020000);
     const auto prsrc = __builtin_amdgcn_make_buffer_rsrc((void *)D.part, 0, (int)(4 * nblk * 48), 0x00020000);
     auto publish = [&](int parity, int64_t i, double v, unsigned tag) {
@@ -540,7 +552,7 @@ __global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, GlGridBar gb, lg_u
         uo = D.uu[i];
         pi = D.p[i];
         on = D.act[i];
-        publish(0, i, D.v[i], tag0);  // the input of step 0
+        if (!(test_missing && blockIdx.x == 0)) publish(0, i, D.v[i], tag0);  // the input of step 0
     }
     lg_u4 pr[4][3];  // wave 0: the partials {dx2, x2 | xm, dz2 | z2, zm} of workgroups lane, lane + 64, ...
     bool pending = false;
@@ -567,8 +579,8 @@ __global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, GlGridBar gb, lg_u
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(4);  // ~0.1 us: leave the fabric to the stores we wait for
                 if ((spins & 63u) == 63u &&
-                    (gl_ld_u32(gb.bar + 32) != 0u || __builtin_amdgcn_s_memrealtime() - t_start > 100000000ull)) {
-                    good = false;  // 1 s: a producer is gone
+                    (gl_ld_u32(err) != 0u || __builtin_amdgcn_s_memrealtime() - t_start > 100000000ull)) {
+                    good = false;  // 1 s: a producer is not on the chip
                     break;
                 }
             }
@@ -626,6 +638,7 @@ __global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, GlGridBar gb, lg_u
         __syncthreads();
         if (s_fail) {
             failed = true;
+            steps = it;
             break;
         }
         if (s_stop[it & 1]) {  // step it-3 met the rule: its z is the result, the steps after it are dropped
@@ -699,10 +712,12 @@ __global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, GlGridBar gb, lg_u
             }
         }
     }
-    if (failed) {
+    if (failed) {  // nothing of the QP's state has been written: the rows live in registers until the end
         if (tid == 0) {
-            __hip_atomic_store(gb.bar + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (blockIdx.x == 0) D.scal[8] = 2.0;  // a hand-off was lost in mid-run
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // at step 0: the workgroups are not all on the chip (the host falls back to one launch per step);
+            // later: a hand-off was lost in mid-run
+            D.scal[8] = steps == 0 ? 1.0 : 2.0;
         }
         return;
     }
@@ -879,9 +894,9 @@ int run_admm_one(gl_ctx *ctx, const LgDev &D, const AdmmRes &A, int max_iter) {
     return GL_OK;
 }
 
-int run_admm_res(gl_ctx *ctx, const LgDev &D, AdmmRes &A, int max_iter) {
-    GL_HIP(ctx, hipMemsetAsync(A.bar, 0, GL_BAR_WORDS * 4, ctx->stream));
+int run_admm_res(gl_ctx *ctx, const LgDev &D, AdmmRes &A, int max_iter, int64_t u_fast = -1) {
     const bool test_not_resident = getenv("GRAPHLEARN_AMD_LGMRF_TEST_NOT_RESIDENT") != nullptr;  // tests: the rendezvous can never complete
+    if (!A.tagged) GL_HIP(ctx, hipMemsetAsync(A.bar, 0, GL_BAR_WORDS * 4, ctx->stream));
     const GlGridBar gb{A.bar, A.nwg + (test_not_resident ? 1 : 0)};
     if (A.tagged) {
         if (max_iter > 120) return gl_set_error(ctx, GL_E_INVALID, "tagged ADMM form: max_iter <= 120");
@@ -890,7 +905,9 @@ int run_admm_res(gl_ctx *ctx, const LgDev &D, AdmmRes &A, int max_iter) {
             A.seq = 0;
         }
         const unsigned tag0 = 128u * A.seq++ + 1u;
-        k_lg_admm_tag<<<dim3((unsigned)A.nwg), 256, A.lds, ctx->stream>>>(D, gb, A.gran, tag0, A.R, max_iter);
+        // error word: bar[32], zero since the allocation (a failure ends the use of this form)
+        k_lg_admm_tag<<<dim3((unsigned)A.nwg), 256, A.lds, ctx->stream>>>(D, A.bar + 32, A.gran, tag0, A.R, max_iter, u_fast,
+                                                                           test_not_resident ? 1 : 0);
         GL_HIP(ctx, hipGetLastError());
         return GL_OK;
     }
@@ -1137,6 +1154,7 @@ GL_API int gl_nonneg_qp_solve(gl_ctx *ctx, const double *mat, const double *vec,
     Buf gran;
     GL_HIP(ctx, hipMalloc(&part.p, (size_t)4 * m * 6 * 8));  // one entry per workgroup and ring slot, any ADMM form
     GL_HIP(ctx, hipMalloc(&bar.p, GL_BAR_WORDS * 4));
+    GL_HIP(ctx, hipMemsetAsync(bar.p, 0, GL_BAR_WORDS * 4, ctx->stream));
     GL_HIP(ctx, hipMalloc(&gran.p, (size_t)2 * m * 16));
     GL_HIP(ctx, hipMemsetAsync(gran.p, 0, (size_t)2 * m * 16, ctx->stream));
     AdmmRes ares;
@@ -1230,6 +1248,7 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
     Buf bGran, bCprev;
     GL_HIP(ctx, hipMalloc(&bAdmm.p, (size_t)4 * n * 6 * 8));  // one entry per workgroup and ring slot, any ADMM form
     GL_HIP(ctx, hipMalloc(&bBar.p, GL_BAR_WORDS * 4));
+    GL_HIP(ctx, hipMemsetAsync(bBar.p, 0, GL_BAR_WORDS * 4, ctx->stream));
     GL_HIP(ctx, hipMalloc(&bGran.p, (size_t)2 * n * 16));
     GL_HIP(ctx, hipMemsetAsync(bGran.p, 0, (size_t)2 * n * 16, ctx->stream));
     AdmmRes ares;
@@ -1288,14 +1307,16 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
         }
         for (int64_t u = 0; u < n; ++u) {
             k_lg_qp_setup<<<1, VT, 0, ctx->stream>>>(D, u);
-            if (fast) {
+            const bool fused_winv = fast && ares.on && ares.tagged;  // the ADMM kernel forms its rows of the inverse itself
+            if (fused_winv) {
+            } else if (fast) {
                 k_lg_build_winv<<<g2, 256, 0, ctx->stream>>>(D, u);
             } else {
                 k_lg_build_w<<<g2, 256, 0, ctx->stream>>>(D, u);
                 GL_TRY(invert_spd_inplace(ctx, D.W, n, pivrow));
             }
             GL_TRY(ares.one ? run_admm_one(ctx, D, ares, max_qp_iter)
-                            : (ares.on ? run_admm_res(ctx, D, ares, max_qp_iter) : run_admm(ctx, D, max_qp_iter)));
+                            : (ares.on ? run_admm_res(ctx, D, ares, max_qp_iter, fused_winv ? u : -1) : run_admm(ctx, D, max_qp_iter)));
             k_lg_beta<<<1, VT, 0, ctx->stream>>>(D, u);
             k_matvec<<<mvb, 256, 0, ctx->stream>>>(D.C, D.beta, D.t, n, D.scal, 0);
             k_lg_snap_col<<<1, VT, 0, ctx->stream>>>(D, u);
