@@ -35,7 +35,10 @@ struct GdDev {
     double *wpart;    // (n * nbj) x 3: sum (w_new - w)^2, sum w^2, max |w| per (row, column block)
     int2 *wtasks;     // (row strip, column block) tasks of k_gd_grad_w
     int nwtasks;
-    double *stat;     // [0] rel change C, [1] rel change W, [2] flag "all coefficients dropped to 0"
+    double *stat;     // [0] rel change C, [1] rel change W, [2] flag "all coefficients dropped to 0", [3] ||dC||,
+                      // [4] steps done, [5] done (later kernels fall through), [6] tol, [7] converged_
+    double *hist;     // history of the running fit: 2 doubles per step
+    long long hist_cap;
     // parameters of the step
     double l1_w, ortho_w, l1_c, log_c, l1_diff_c, step_c, step_w, step_dual;
 };
@@ -48,7 +51,7 @@ struct gl_graphdict {
     bool have_x = false, have_state = false;
     // one step (memset + 14 kernels + copy of the status words) captured per parity of the degree
     // ping-pong and replayed: one graph launch per step instead of 16 enqueues (matters below ~1 ms/step)
-    hipGraphExec_t step_graph[2] = {nullptr, nullptr};
+    hipGraphExec_t step_graph[4] = {nullptr, nullptr, nullptr, nullptr};  // [2 * fit_mode + parity]
     int step_parity = 0;  // which of (deg, deg_new) is current: flips with every step
     double *dbgbuf = nullptr;  // tuning aid (GD_EXP & 8): 4 doubles per wave of k_gd_grad_w
     // small engine (gl_graphdict_small.hip): result words + history of a run, on the device

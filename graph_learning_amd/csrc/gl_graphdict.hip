@@ -44,7 +44,9 @@ __device__ __forceinline__ double gd_wave_max(double v) {
 // (base_model.py:375 `self.weights_ @ sq_pdiffs.T`).  grid (Tp / 128, NG), one wave per workgroup.
 template <int KP, int RC>
 __global__ __launch_bounds__(64) void k_gd_grad_c(const double *__restrict__ XT, const double *__restrict__ WS,
-                                                  double *__restrict__ SC, int n, int n_pad, int Tp, int NG) {
+                                                  double *__restrict__ SC, int n, int n_pad, int Tp, int NG,
+                                                  const double *__restrict__ done) {
+    if (done[0] != 0.0) return;  // the stopping rule was met earlier in this chunk of steps
     const int lane = threadIdx.x;
     const int g = blockIdx.y;
     const int64_t t0 = (int64_t)blockIdx.x * GD_SB + lane;  // this lane's samples: t0 + 64 q, q < GD_SPL
@@ -122,7 +124,9 @@ __global__ __launch_bounds__(64) void k_gd_grad_c(const double *__restrict__ XT,
 template <int KP, int SW>
 __global__ __launch_bounds__(256, 3) void k_gd_grad_w(const double *__restrict__ X, const double *__restrict__ CT,
                                                    double *__restrict__ GS, const int2 *__restrict__ tasks, int ntasks,
-                                                   int n_pad, int Tp, int tchunk, double *dbg) {
+                                                   int n_pad, int Tp, int tchunk, double *dbg,
+                                                   const double *__restrict__ done) {
+    if (done[0] != 0.0) return;
     // the four waves of a workgroup take a quarter of the split's samples each and add their
     // partial sums through LDS: finer tasks (even load per SIMD) without more slabs in HBM
     __shared__ double2 s_red[3][KP / 2][64];
@@ -218,6 +222,7 @@ __global__ __launch_bounds__(256, 3) void k_gd_grad_w(const double *__restrict__
 // ------------------------------------------------------------------------------------------
 // log_c reset (base_model.py:385-387): columns of the strided view whose sum is < 1e-8
 __global__ void k_gd_logc_reset(GdDev P) {
+    if (P.stat[5] != 0.0) return;
     const int tw = blockIdx.x * blockDim.x + threadIdx.x;
     if (tw >= P.Tw) return;
     const int64_t t = (int64_t)tw * P.W;
@@ -233,6 +238,7 @@ __global__ void k_gd_logc_reset(GdDev P) {
 // sum of the strip-group partials of k_gd_grad_c, fixed order: 4 interleaved partial sums per
 // element (threadIdx.y), then ((p0 + p1) + p2) + p3
 __global__ __launch_bounds__(256) void k_gd_sc_reduce(GdDev P) {
+    if (P.stat[5] != 0.0) return;
     __shared__ double s_p[4][64];
     const int64_t q = (int64_t)blockIdx.x * 64 + threadIdx.x;  // (k, t)
     const int gy = threadIdx.y;
@@ -251,6 +257,7 @@ __global__ __launch_bounds__(256) void k_gd_sc_reduce(GdDev P) {
 // coefficient update (base_model.py:373-401), one wave per window
 template <int KP>
 __global__ __launch_bounds__(64) void k_gd_coef_update(GdDev P) {
+    if (P.stat[5] != 0.0) return;
     const int lane = threadIdx.x, tw = blockIdx.x;
     // adjoint term  W @ (S' dual')  ==  <S W_k, dual_tw>   (log_model.py:33-34)
     double dt[KP];
@@ -294,6 +301,7 @@ __global__ __launch_bounds__(64) void k_gd_coef_update(GdDev P) {
 
 // all-zero guard (:406-408); one workgroup
 __global__ __launch_bounds__(256) void k_gd_coef_finish(GdDev P) {
+    if (P.stat[5] != 0.0) return;
     __shared__ double s_a[256];
     const int tid = threadIdx.x;
     double mx = 0.0;
@@ -313,6 +321,7 @@ __global__ __launch_bounds__(256) void k_gd_coef_finish(GdDev P) {
 // ------------------------------------------------------------------------------------------
 // M[k][i] = sum_t C[k,t] dual[t / W, i]  (log_model.py:36-37: C @ (S' dual_rep')' = S'(C @ dual_rep) pairwise)
 __global__ __launch_bounds__(64) void k_gd_m(GdDev P, int tchunk) {
+    if (P.stat[5] != 0.0) return;
     const int i = blockIdx.x * 64 + threadIdx.x, ms = blockIdx.y;
     double acc[GD_MAXK];
     for (int k = 0; k < P.K; ++k) acc[k] = 0.0;
@@ -325,6 +334,7 @@ __global__ __launch_bounds__(64) void k_gd_m(GdDev P, int tchunk) {
     for (int k = 0; k < P.K; ++k) P.MSL[((int64_t)ms * P.KP + k) * P.n_pad + i] = i < P.n ? acc[k] : 0.0;
 }
 __global__ __launch_bounds__(256) void k_gd_m_reduce(GdDev P) {
+    if (P.stat[5] != 0.0) return;
     __shared__ double s_p[4][64];
     const int64_t q = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int gy = threadIdx.y;
@@ -343,6 +353,7 @@ __global__ __launch_bounds__(256) void k_gd_m_reduce(GdDev P) {
 // weight update (base_model.py:444-461): one wave per (row i, column block); in place
 template <int KP>
 __global__ __launch_bounds__(64) void k_gd_weight_update(GdDev P) {
+    if (P.stat[5] != 0.0) return;
     const int lane = threadIdx.x, jb = blockIdx.x, i = blockIdx.y;
     const int nbj = gridDim.x;
     const int j = jb * 64 + lane;
@@ -398,6 +409,7 @@ __global__ __launch_bounds__(64) void k_gd_weight_update(GdDev P) {
 }
 
 __global__ __launch_bounds__(1024) void k_gd_weight_finish(GdDev P, int64_t nparts) {
+    if (P.stat[5] != 0.0) return;
     __shared__ double s_a[1024], s_b[1024], s_c[1024];
     const int tid = threadIdx.x;
     double num = 0, den = 0, mx = 0;
@@ -422,7 +434,8 @@ __global__ __launch_bounds__(1024) void k_gd_weight_finish(GdDev P, int64_t npar
 }
 
 // degrees S W_k' of the weights in WS: one wave per node
-__global__ __launch_bounds__(64) void k_gd_degree(GdDev P, double *__restrict__ out) {
+__global__ __launch_bounds__(64) void k_gd_degree(GdDev P, double *__restrict__ out, int chk_done) {
+    if (chk_done && P.stat[5] != 0.0) return;
     const int lane = threadIdx.x, v = blockIdx.x;
     double acc[GD_MAXK];
     for (int k = 0; k < P.K; ++k) acc[k] = 0.0;
@@ -443,6 +456,7 @@ __global__ __launch_bounds__(64) void k_gd_degree(GdDev P, double *__restrict__ 
 // (base_model.py:509-514).  fixed_weights: predict() passes the weights themselves (:665-669).
 template <int KP>
 __global__ void k_gd_dual_update(GdDev P, int fixed_weights) {
+    if (P.stat[5] != 0.0) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
     double dv[KP];  // overshoot degrees of node i, shared by the 8 windows of this thread
@@ -465,6 +479,7 @@ __global__ void k_gd_dual_update(GdDev P, int fixed_weights) {
 // coefficients_ <- repeat(new window coefficients) (base_model.py:495-501,519) and the partial sums
 // of relative_error(coefficients_.ravel(), new.ravel()) (:516); grid of <= 256 workgroups
 __global__ __launch_bounds__(256) void k_gd_coef_commit(GdDev P) {
+    if (P.stat[5] != 0.0) return;
     __shared__ double s_a[256], s_b[256], s_c[256];
     const int tid = threadIdx.x;
     double num = 0.0, den = 0.0, omax = 0.0;
@@ -496,8 +511,11 @@ __global__ __launch_bounds__(256) void k_gd_coef_commit(GdDev P) {
     }
 }
 // stat[0] = relative change of the coefficients (plain norm if the old ones were ~ 0, evaluation.py:21-23),
-// stat[3] = ||new - old|| (predict's stopping norm, base_model.py:671)
-__global__ __launch_bounds__(64) void k_gd_coef_stat(GdDev P, int nblocks) {
+// stat[3] = ||new - old|| (predict's stopping norm, base_model.py:671).  fit_mode: the bookkeeping of
+// _single_fit (base_model.py:552-581) -- history row, converged_, and the "done" word that turns every
+// kernel of the steps already enqueued behind this one into a no-op (the host looks once per chunk).
+__global__ __launch_bounds__(64) void k_gd_coef_stat(GdDev P, int nblocks, int fit_mode) {
+    if (P.stat[5] != 0.0) return;
     const int lane = threadIdx.x;
     double num = 0, den = 0, omax = 0;
     for (int b = lane; b < nblocks; b += 64) {
@@ -509,8 +527,20 @@ __global__ __launch_bounds__(64) void k_gd_coef_stat(GdDev P, int nblocks) {
     den = gd_wave_sum(den);
     omax = gd_wave_max(omax);
     if (lane == 0) {
-        P.stat[0] = omax <= 1e-8 ? sqrt(num) : sqrt(num) / sqrt(den);
+        const double dc = omax <= 1e-8 ? sqrt(num) : sqrt(num) / sqrt(den);
+        P.stat[0] = dc;
         P.stat[3] = sqrt(num);
+        if (fit_mode) {
+            const double dw = P.stat[1], tol = P.stat[6];
+            const long long i = (long long)P.stat[4];
+            if (i < P.hist_cap) {
+                P.hist[2 * i] = dc;
+                P.hist[2 * i + 1] = dw;
+            }
+            if (dc < tol && dw < tol) P.stat[7] = (double)i;
+            P.stat[4] = (double)(i + 1);
+            if (P.stat[7] > 0.0) P.stat[5] = 1.0;  // sic: a stop at step 0 is not taken (:578)
+        }
     }
 }
 
@@ -579,9 +609,9 @@ int gd_launch_grad_c(gl_graphdict *s) {
     dim3 grid((unsigned)(P.Tp / GD_SB), (unsigned)P.NG);
     hipStream_t st = s->ctx->stream;
     switch (P.KP) {
-        case 4: k_gd_grad_c<4, 2><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG); break;
-        case 8: k_gd_grad_c<8, 2><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG); break;
-        default: k_gd_grad_c<16, 1><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG); break;
+        case 4: k_gd_grad_c<4, 2><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5); break;
+        case 8: k_gd_grad_c<8, 2><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5); break;
+        default: k_gd_grad_c<16, 1><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5); break;
     }
     GL_HIP(s->ctx, hipGetLastError());
     return GL_OK;
@@ -611,22 +641,22 @@ int gd_launch_grad_w(gl_graphdict *s) {
     hipStream_t st = s->ctx->stream;
     dim3 grid((unsigned)(P.nwtasks * P.TS));
     switch (P.KP) {
-        case 4: k_gd_grad_w<4, 8><<<grid, 256, 0, st>>>(P.X, P.CT, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, s->dbgbuf); break;
-        case 8: k_gd_grad_w<8, 8><<<grid, 256, 0, st>>>(P.X, P.CT, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, s->dbgbuf); break;
-        default: k_gd_grad_w<16, 4><<<grid, 256, 0, st>>>(P.X, P.CT, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, s->dbgbuf); break;
+        case 4: k_gd_grad_w<4, 8><<<grid, 256, 0, st>>>(P.X, P.CT, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, s->dbgbuf, P.stat + 5); break;
+        case 8: k_gd_grad_w<8, 8><<<grid, 256, 0, st>>>(P.X, P.CT, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, s->dbgbuf, P.stat + 5); break;
+        default: k_gd_grad_w<16, 4><<<grid, 256, 0, st>>>(P.X, P.CT, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, s->dbgbuf, P.stat + 5); break;
     }
     GL_HIP(s->ctx, hipGetLastError());
     return GL_OK;
 }
 
-int gd_degrees(gl_graphdict *s, double *out) {
-    k_gd_degree<<<dim3((unsigned)s->dev.n), 64, 0, s->ctx->stream>>>(s->dev, out);
+int gd_degrees(gl_graphdict *s, double *out, int chk_done = 0) {
+    k_gd_degree<<<dim3((unsigned)s->dev.n), 64, 0, s->ctx->stream>>>(s->dev, out, chk_done);
     GL_HIP(s->ctx, hipGetLastError());
     return GL_OK;
 }
 
 // one primal-dual step (base_model.py:485-527); the relative changes land in stat[0..1]
-int gd_step(gl_graphdict *s) {
+int gd_step(gl_graphdict *s, int fit_mode = 0) {
     gl_ctx *ctx = s->ctx;
     GdDev &P = s->dev;
     hipStream_t st = ctx->stream;
@@ -646,36 +676,30 @@ int gd_step(gl_graphdict *s) {
         default: k_gd_weight_update<16><<<dim3((unsigned)nbj, (unsigned)P.n), 64, 0, st>>>(P); break;
     }
     k_gd_weight_finish<<<1, 1024, 0, st>>>(P, (int64_t)P.n * nbj);
-    GL_TRY(gd_degrees(s, P.deg_new));
+    GL_TRY(gd_degrees(s, P.deg_new, 1));
     gd_launch_dual_update(P, st, 0);
     const int cb = gd_commit_blocks(P);
     k_gd_coef_commit<<<dim3((unsigned)cb), 256, 0, st>>>(P);
-    k_gd_coef_stat<<<1, 64, 0, st>>>(P, cb);
+    k_gd_coef_stat<<<1, 64, 0, st>>>(P, cb, fit_mode);
     GL_HIP(ctx, hipGetLastError());
     std::swap(P.deg, P.deg_new);
     s->step_parity ^= 1;
     return GL_OK;
 }
 
-// one step + the copy of the status words to pinned memory, through the captured graph of the current
-// parity (captured on first use; the kernels' arguments -- pointers, regularisers, step sizes -- are
-// frozen in it, so set_params and the plateau rule drop the graphs)
-int gd_step_replayed(gl_graphdict *s, double *pinned_stat) {
+// one step through the captured graph of the current parity (captured on first use; the kernels'
+// arguments -- pointers, regularisers, step sizes -- are frozen in it, so set_params, the plateau rule and
+// a new history buffer drop the graphs).  fit_mode steps keep the books of _single_fit on the device.
+int gd_step_replayed(gl_graphdict *s, int fit_mode) {
     gl_ctx *ctx = s->ctx;
     GdDev &P = s->dev;
-    if (getenv("GRAPHLEARN_AMD_NO_GRAPH")) {
-        GL_HIP(ctx, hipMemsetAsync(P.stat + 2, 0, 8, ctx->stream));
-        GL_TRY(gd_step(s));
-        GL_HIP(ctx, hipMemcpyAsync(pinned_stat, P.stat, 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
-        return GL_OK;
-    }
+    if (getenv("GRAPHLEARN_AMD_NO_GRAPH")) return gd_step(s, fit_mode);
     const int par = s->step_parity;
-    if (!s->step_graph[par]) {
+    hipGraphExec_t &exec = s->step_graph[2 * fit_mode + par];
+    if (!exec) {
         hipGraph_t graph = nullptr;
         GL_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-        (void)hipMemsetAsync(P.stat + 2, 0, 8, ctx->stream);
-        const int rc = gd_step(s);  // flips the parity and the degree buffers: undone below, replay redoes it
-        (void)hipMemcpyAsync(pinned_stat, P.stat, 4 * 8, hipMemcpyDeviceToHost, ctx->stream);
+        const int rc = gd_step(s, fit_mode);  // flips the parity and the degree buffers: undone below, replay redoes it
         hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
         std::swap(P.deg, P.deg_new);
         s->step_parity ^= 1;
@@ -683,11 +707,11 @@ int gd_step_replayed(gl_graphdict *s, double *pinned_stat) {
             if (graph) (void)hipGraphDestroy(graph);
             return rc;
         }
-        if (e == hipSuccess) e = hipGraphInstantiate(&s->step_graph[par], graph, nullptr, nullptr, 0);
+        if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         if (graph) (void)hipGraphDestroy(graph);
         if (e != hipSuccess) return gl_set_error(ctx, GL_E_HIP, "step graph capture failed: %s", hipGetErrorString(e));
     }
-    GL_HIP(ctx, hipGraphLaunch(s->step_graph[par], ctx->stream));
+    GL_HIP(ctx, hipGraphLaunch(exec, ctx->stream));
     std::swap(P.deg, P.deg_new);
     s->step_parity ^= 1;
     return GL_OK;
@@ -881,31 +905,75 @@ GL_API int gl_graphdict_fit(gl_graphdict *s, int64_t max_iter, double tol, int r
     int64_t converged = -1, i = 0;
     int flags = 0;
     for (int64_t q = 0; q < 2 * max_iter; ++q) history_out[q] = -1.0;
-    for (i = 0; i < max_iter; ++i) {
-        GL_TRY(gd_step_replayed(s, st));
-        GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        const double dc = st[0], dw = st[1];
-        history_out[2 * i] = dc;
-        history_out[2 * i + 1] = dw;
-        if (st[2] != 0.0) flags |= 1;  // "All coefficients dropped to 0"
-        if (dc < tol && dw < tol) converged = i;
-        if (reduce_step_on_plateau && i > 100) {  // :563-574
-            double mc = 0, mw = 0;
-            for (int64_t q = i - 10; q < i; ++q) {
-                mc += history_out[2 * q];
-                mw += history_out[2 * q + 1];
-            }
-            if (dc >= mc / 10 && dw >= mw / 10) {
-                P.step_c *= 0.7, P.step_w *= 0.7, P.step_dual *= 0.7;
-                gd_drop_graphs(s);  // the step sizes are frozen in the captured kernels' arguments
-                flags |= 2;  // "Divergence detected ..., reducing step size"
-            }
+    if (P.hist_cap < max_iter) {  // history of the run on the device; the captured steps hold its address
+        double *h = nullptr;
+        GL_HIP(ctx, hipMalloc((void **)&h, (size_t)std::max<int64_t>(max_iter, 1) * 2 * sizeof(double)));
+        if (P.hist) {
+            auto itp = std::find(s->allocs.begin(), s->allocs.end(), (void *)P.hist);
+            if (itp != s->allocs.end()) s->allocs.erase(itp);
+            GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(P.hist);
         }
-        if (converged > 0) {  // sic: a stop at step 0 is not taken (:578)
-            ++i;
-            break;
-        }
+        P.hist = h;
+        P.hist_cap = max_iter;
+        s->allocs.push_back(h);
+        gd_drop_graphs(s);
     }
+    // status words: [2] all-zero flag (sticky over the run), [4] steps done, [5] done, [6] tol, [7] converged_
+    const double init[6] = {0.0, 0.0, 0.0, 0.0, tol, -1.0};
+    GL_TRY(gl_h2d(ctx, P.stat + 2, init, sizeof init));
+    const int par0 = s->step_parity;
+    if (!reduce_step_on_plateau) {
+        // steps are enqueued a chunk at a time; the device keeps the books (k_gd_coef_stat) and, once the rule
+        // is met, the rest of the chunk falls through -- no host round trip per step
+        int64_t enq = 0;
+        bool done = false;
+        while (!done && enq < max_iter) {
+            const int64_t chunk = std::min<int64_t>(max_iter - enq, enq == 0 ? 4 : 16);
+            for (int64_t c = 0; c < chunk; ++c) GL_TRY(gd_step_replayed(s, 1));
+            enq += chunk;
+            GL_HIP(ctx, hipMemcpyAsync(st, P.stat, 8 * 8, hipMemcpyDeviceToHost, ctx->stream));
+            GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            done = st[5] != 0.0;
+        }
+        i = (int64_t)st[4];
+        converged = (int64_t)st[7];
+        if (st[2] != 0.0) flags |= 1;  // "All coefficients dropped to 0"
+        if (((enq - i) & 1) != 0) {  // the steps that fell through flipped the host's view of the degree ping-pong only
+            std::swap(P.deg, P.deg_new);
+            s->step_parity ^= 1;
+        }
+        if (i > 0) GL_TRY(gl_d2h(ctx, history_out, P.hist, (size_t)(2 * i) * 8));
+    } else {
+        for (i = 0; i < max_iter; ++i) {
+            GL_TRY(gd_step_replayed(s, 1));
+            GL_HIP(ctx, hipMemcpyAsync(st, P.stat, 8 * 8, hipMemcpyDeviceToHost, ctx->stream));
+            GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            const double dc = st[0], dw = st[1];
+            history_out[2 * i] = dc;
+            history_out[2 * i + 1] = dw;
+            if (dc < tol && dw < tol) converged = i;
+            if (i > 100) {  // :563-574
+                double mc = 0, mw = 0;
+                for (int64_t q = i - 10; q < i; ++q) {
+                    mc += history_out[2 * q];
+                    mw += history_out[2 * q + 1];
+                }
+                if (dc >= mc / 10 && dw >= mw / 10) {
+                    P.step_c *= 0.7, P.step_w *= 0.7, P.step_dual *= 0.7;
+                    gd_drop_graphs(s);  // the step sizes are frozen in the captured kernels' arguments
+                    flags |= 2;  // "Divergence detected ..., reducing step size"
+                }
+            }
+            if (converged > 0) {  // sic: a stop at step 0 is not taken (:578)
+                ++i;
+                break;
+            }
+        }
+        if (st[2] != 0.0) flags |= 1;
+    }
+    (void)par0;
+    GL_HIP(ctx, hipMemsetAsync(P.stat + 5, 0, 8, ctx->stream));  // the kernels are usable again (set_state, predict, probes)
     if (steps_run_out) *steps_run_out = i;
     if (converged_out) *converged_out = converged;
     if (flags_out) *flags_out = flags;
@@ -926,6 +994,7 @@ GL_API int gl_graphdict_predict(gl_graphdict *s, int64_t max_iter, double tol, d
     hipStream_t st_ = ctx->stream;
     double *st = (double *)ctx->pinned;
     GL_HIP(ctx, hipMemsetAsync(P.dual, 0, (size_t)P.Tw * P.n * 8, st_));
+    GL_HIP(ctx, hipMemsetAsync(P.stat + 2, 0, 6 * 8, st_));
     if (gd_small_applicable(s)) {
         GL_TRY(gd_small_predict(s, max_iter, tol, steps_run_out, flags_out));
         GL_TRY(gl_d2h(ctx, coefficients_out, P.C, (size_t)P.K * P.T * 8));
@@ -943,7 +1012,7 @@ GL_API int gl_graphdict_predict(gl_graphdict *s, int64_t max_iter, double tol, d
         gd_launch_dual_update(P, st_, 1);
         const int cb = gd_commit_blocks(P);
         k_gd_coef_commit<<<dim3((unsigned)cb), 256, 0, st_>>>(P);
-        k_gd_coef_stat<<<1, 64, 0, st_>>>(P, cb);
+        k_gd_coef_stat<<<1, 64, 0, st_>>>(P, cb, 0);
         GL_HIP(ctx, hipGetLastError());
         GL_HIP(ctx, hipMemcpyAsync(st, P.stat, 4 * 8, hipMemcpyDeviceToHost, st_));
         GL_HIP(ctx, hipStreamSynchronize(st_));
