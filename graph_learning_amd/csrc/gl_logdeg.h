@@ -73,9 +73,9 @@ int gl_resident_finish(gl_logdeg *s, int64_t *iters_done, bool *stopped, bool *n
 // gl_small.hip
 bool gl_small_applicable(const gl_logdeg *s);
 int gl_small_launch(gl_logdeg *s, int64_t iters, double tol);
-size_t gl_small_batch_scratch_bytes(int B);
+size_t gl_small_batch_scratch_bytes(int B, int n);
 int gl_small_batch_run(gl_logdeg **sessions, int B, int64_t iters, double tol, void *dev_scratch, int64_t *ran_out,
-                       bool *need_exact_out);
+                       bool *need_exact_out, bool *stopped_out);
 // gl_logdeg.hip: layout conversions of an edge vector (tiled <-> condensed, device to device)
 int gl_logdeg_tiled_to_condensed(gl_logdeg *s, const double *src_tiled, double *dst_condensed);
 int gl_logdeg_condensed_to_tiled(gl_logdeg *s, const double *src_condensed, double *dst_tiled);

@@ -1400,7 +1400,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
     // on the device (gl_small.hip); the host only steps in when the exact spectral norms are needed.
     if (maxit >= 8 && gl_small_applicable(sessions[0]) && B <= ctx->prop.multiProcessorCount) {
         void *small_scratch = nullptr;
-        GL_HIP(ctx, hipMalloc(&small_scratch, gl_small_batch_scratch_bytes(B)));
+        GL_HIP(ctx, hipMalloc(&small_scratch, gl_small_batch_scratch_bytes(B, (int)sessions[0]->n)));
         struct Free {
             void *p;
             ~Free() { (void)hipFree(p); }
@@ -1410,8 +1410,8 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
         int64_t n_iter = 0;
         while (n_iter < maxit) {
             int64_t ran = 0;
-            bool need_exact = false;
-            const int rc = gl_small_batch_run(sessions, B, maxit - n_iter, tol, small_scratch, &ran, &need_exact);
+            bool need_exact = false, stopped = false;
+            const int rc = gl_small_batch_run(sessions, B, maxit - n_iter, tol, small_scratch, &ran, &need_exact, &stopped);
             if (rc == GL_E_STATE && n_iter == 0) {  // workgroups not co-resident: per-iteration launches instead
                 small_failed = true;
                 break;
@@ -1419,6 +1419,10 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
             if (rc != GL_OK) return rc;
             n_iter += ran;
             if (ran > 0) have_exact = false;
+            if (stopped) {  // the rule (:166-167) holds for every value the four spectral norms can take (device brackets)
+                converged = true;
+                break;
+            }
             if (!need_exact) break;  // maxit reached
             GL_TRY(exact(rp, rd));
             have_exact = true;

@@ -14,8 +14,13 @@
 // iteration to exchange the four squared norms of every graph.  They are the diagonals of the Gram
 // matrices whose largest eigenvalues decide the coupled stopping rule, and lambda_max lies in
 // [max diagonal, trace]: while those bounds keep the ratios above tol the loop goes on; when they
-// straddle tol (or allow a stop) all workgroups leave with their state saved and the host evaluates
-// the exact rule (gl_logdeg_batch_iterate), then re-enters.
+// straddle tol (or allow a stop) the workgroups tighten them in place (B <= 32 and LDS permitting): every graph publishes
+// its update and its previous iterate, workgroup b forms row b of the four B x B Gram matrices, and four
+// waves bracket lambda_max of one matrix each by repeated squaring (A <- A^2 / tr A^2: the bracket
+// [tr A_m^2, sqrt(tr A_m^2)] of the m-th power contracts by a square root per level on the way back, to
+// 1e-9 after 30 levels whatever the spectrum) -- every workgroup from the same numbers, so they agree.
+// Only a genuine tie (|rel / tol - 1| < 1e-9), a degenerate norm or B > 32 still goes to the host
+// (gl_logdeg_batch_iterate: full Gram matrices, Jacobi eigenvalues), which then re-enters.
 //
 // The kernels read and write the session's tiled layout directly (edge (i, j) -> tile offset), so every
 // other entry point sees a consistent state afterwards.
@@ -42,14 +47,162 @@ struct SmallDev {
     int maxit;
 };
 
+constexpr int SMALL_GRAM_MAXB = 32;  // the in-kernel brackets of lambda_max: B^2 entries over one wave (<= 16 per lane)
+
 struct SmallBatch {
     const SmallDev *devs;  // one per graph (device array)
     double *diag;          // [B][4] squared norms of the last iteration
-    long long *status;     // [0] iterations run by this launch, [1] 0 = maxit reached, 1 = the host must decide, 2 = barrier lost
+    long long *status;     // [0] iterations run by this launch, [1] 0 = maxit reached, 1 = the host must decide,
+                           //     2 = barrier lost, 3 = the coupled rule is met (decided on the device)
     unsigned *bar;         // grid barrier words (gl_gridbar.h)
     int B;
     int rendezvous;        // workgroups expected at the start-up rendezvous (= B; B + 1 in the fallback test)
+    double *vec;           // [B][vstride]: w_new - w_old (E), w_old (E), d_new - d_old (n), d_old (n) of every graph
+    double *gram;          // [4][B][B]
+    int vstride;
+    int use_gram;          // B <= SMALL_GRAM_MAXB
 };
+
+__device__ __forceinline__ double sm_ld(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ double sm_wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ void sm_st(double *p, double v) {
+    __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One wave: rigorous bracket [lo, hi] of the largest eigenvalue of the symmetric positive semi-definite
+// B x B matrix A (LDS, destroyed), B <= 32.  With A_0 = A / tr A and A_{k+1} = A_k^2 / t_k, t_k = tr A_k^2:
+// mu_k = lambda_max(A_k) obeys mu_k = sqrt(t_k mu_{k+1}), and a trace-1 PSD matrix has tr A^2 <= mu <= sqrt(tr A^2).
+// So log mu_0 = sum_k 2^-(k+1) log t_k + 2^-m log mu_m with mu_m in [t_m, sqrt t_m]: the width of the bracket
+// is 2^-(m+1) |log t_m| <= 2^-(m+1) log B in the logarithm.  Stops early once A_k is rank one (t_k -> 1).
+template <int EPL>  // matrix entries per lane: 4 (B <= 16) or 16 (B <= 32)
+__device__ __forceinline__ void sm_lambda_bracket(double *A, int B, int lane, double &lo, double &hi) {
+    const int nn = B * B;
+    double tr = 0.0;
+    for (int i = lane; i < B; i += 64) tr += A[i * B + i];
+    tr = wave_sum(tr);
+    if (!(tr > 0.0)) {
+        lo = hi = 0.0;
+        return;
+    }
+    for (int idx = lane; idx < nn; idx += 64) A[idx] = A[idx] / tr;
+    double L = 0.0, wgt = 0.5;
+    for (int k = 0; k < 34; ++k) {
+        double sv[EPL], dsum = 0.0;
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) {
+            const int idx = lane + 64 * r;
+            sv[r] = 0.0;
+            if (idx < nn) {
+                const int i = idx / B, j = idx - i * B;
+                double acc = 0.0;
+                for (int l = 0; l < B; ++l) acc += A[i * B + l] * A[l * B + j];
+                sv[r] = acc;
+                if (i == j) dsum += acc;
+            }
+        }
+        const double t = wave_sum(dsum);  // tr A_k^2, in (1/B, 1]
+#pragma unroll
+        for (int r = 0; r < EPL; ++r)
+            if (lane + 64 * r < nn) A[lane + 64 * r] = sv[r] / t;
+        L += wgt * log(t);
+        wgt *= 0.5;
+        if (t > 1.0 - 1e-13) break;
+    }
+    double fro = 0.0;
+    for (int idx = lane; idx < nn; idx += 64) fro += A[idx] * A[idx];
+    const double tm = fmin(wave_sum(fro), 1.0);  // tr A_m^2 (A_m symmetric)
+    const double lt = log(tm);                   // <= 0
+    lo = tr * exp(L + 2.0 * wgt * lt) * (1.0 - 1e-12);
+    hi = tr * exp(L + wgt * lt) * (1.0 + 1e-12);
+}
+
+// The in-kernel tightening of the coupled rule's brackets (see the header).  Kept out of line and fed from LDS
+// only (w_new in w_l, w_old in wo_l, d in d_l, the previous d in dp_l): the iteration loop around it keeps
+// its register allocation.  All threads of every workgroup call it in the same iteration.
+// Returns reason (0 go on, 1 host decides, 2 barrier lost, 3 rule met) | barrier epoch << 32.
+template <int ST>
+__device__ __noinline__ unsigned long long sm_tighten(SmallBatch Q, GlBarState bs, const double *w_l, const double *wo_l,
+                                                      const double *d_l, const double *dp_l, double *gred, double *gA,
+                                                      int *s_ok, int n, int E, double tol) {
+    constexpr int NW = ST / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = Q.B;
+    const GlGridBar gb{Q.bar, Q.rendezvous};
+    int reason = 0;
+    // (a) everybody publishes update and previous iterate
+    double *mv = Q.vec + (size_t)blockIdx.x * Q.vstride;
+    for (int e = tid; e < E; e += ST) {
+        sm_st(mv + e, w_l[e] - wo_l[e]);
+        sm_st(mv + E + e, wo_l[e]);
+    }
+    if (tid < n) {
+        sm_st(mv + 2 * E + tid, d_l[tid] - dp_l[tid]);
+        sm_st(mv + 2 * E + n + tid, dp_l[tid]);
+    }
+    if (!gl_grid_barrier(gb, bs, s_ok)) return 2ull | ((unsigned long long)bs.epoch << 32);
+    // (b) my row of the four Gram matrices, one column at a time, fixed summation order
+    for (int cg = 0; cg < B; ++cg) {
+        const double *ov = Q.vec + (size_t)cg * Q.vstride;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int e = tid; e < E; e += ST) {
+            a0 += (w_l[e] - wo_l[e]) * sm_ld(ov + e);
+            a1 += wo_l[e] * sm_ld(ov + E + e);
+        }
+        if (tid < n) {
+            a2 = (d_l[tid] - dp_l[tid]) * sm_ld(ov + 2 * E + tid);
+            a3 = dp_l[tid] * sm_ld(ov + 2 * E + n + tid);
+        }
+        a0 = wave_sum(a0);
+        a1 = wave_sum(a1);
+        a2 = wave_sum(a2);
+        a3 = wave_sum(a3);
+        if (lane == 0) {
+            gred[0 * NW + wave] = a0;
+            gred[1 * NW + wave] = a1;
+            gred[2 * NW + wave] = a2;
+            gred[3 * NW + wave] = a3;
+        }
+        __syncthreads();
+        if (tid < 4) {
+            double t = 0.0;
+            for (int v = 0; v < NW; ++v) t += gred[tid * NW + v];
+            sm_st(Q.gram + ((size_t)tid * B + blockIdx.x) * B + cg, t);
+        }
+        __syncthreads();
+    }
+    if (!gl_grid_barrier(gb, bs, s_ok)) return 2ull | ((unsigned long long)bs.epoch << 32);
+    // (c) brackets of the four largest eigenvalues: wave q takes matrix q
+    for (int idx = tid; idx < 4 * B * B; idx += ST) gA[idx] = sm_ld(Q.gram + idx);
+    __syncthreads();
+    if (wave < 4) {
+        double lo, hi;
+        if (B <= 16)
+            sm_lambda_bracket<4>(gA + wave * B * B, B, lane, lo, hi);
+        else
+            sm_lambda_bracket<16>(gA + wave * B * B, B, lane, lo, hi);
+        if (lane == 0) {
+            gA[4 * B * B + 2 * wave] = lo;
+            gA[4 * B * B + 2 * wave + 1] = hi;
+        }
+    }
+    __syncthreads();
+    const double *br = gA + 4 * B * B;  // {lo, hi} x {update, iterate, dual update, dual}
+    const double tp = tol * tol * (1 + 1e-9), tm = tol * tol * (1 - 1e-9);
+    const bool not_yet = br[0] > tp * br[3] || br[4] > tp * br[7];
+    const bool met = br[2] > 0 && br[6] > 0 && br[1] < tm * br[2] && br[5] < tm * br[6];
+    __syncthreads();  // gA is rewritten at the next tightening
+    if (met)
+        reason = 3;  // :166-167 holds for every admissible value of the four norms
+    else if (!not_yet)
+        reason = 1;  // a tie to 1e-9: the host's exact evaluation decides
+    return (unsigned long long)reason | ((unsigned long long)bs.epoch << 32);
+}
 
 __device__ __forceinline__ int64_t tiled_offset(int i, int j, int nb) {  // i < j
     const int I = i >> 6, J = j >> 6;
@@ -59,9 +212,14 @@ __device__ __forceinline__ int64_t tiled_offset(int i, int j, int nb) {  // i < 
 
 // T threads: 1024 (n <= 128, 8 threads per node in the node phase) or 256 (n <= 64, 4 per node: fewer
 // waves to synchronise and to reduce over when the graph is tiny).  BATCH: see the header comment.
-template <int T, bool BATCH>
+// TIGHT compiles the in-kernel tightening in.  At 1024 threads it has a price: 8 edges x (z, w, w_old, end
+// points) plus the batch state already fill the 128 registers per thread, and what lives across the call
+// is spilled inside the loop as well (bare iteration 14 -> 24 us at n = 128); the host therefore picks the
+// variant by batch size (from B = 12 on the host's Gram + Jacobi evaluation costs more than that).
+template <int T, bool BATCH, bool TIGHT = false>
 __global__ __launch_bounds__(T) void k_small(SmallDev P1, SmallBatch Q) {
     constexpr int ST = T, NW = T / 64, PARTS = T / 128 >= 8 ? 8 : 4;
+    constexpr int EPT = T == 512 ? 2 * SMALL_EPT : SMALL_EPT;  // edges per thread: 8128 / 512 in the batched form at n > 64
     extern __shared__ double sh[];
     __shared__ int s_ok;
     const SmallDev P = BATCH ? Q.devs[blockIdx.x] : P1;
@@ -73,15 +231,17 @@ __global__ __launch_bounds__(T) void k_small(SmallDev P1, SmallBatch Q) {
     double *pb_l = yb_l + n;        // n
     double *dp_l = pb_l + n;        // n: d of the previous iteration
     double *red = dp_l + n;         // [4][NW] norm partials of the waves
+    double *gred = red + 64;        // [4][NW] partials of a column of Gram entries (batched form)
+    double *gA = gred + 256;        // [4][B][B] Gram matrices, then [8] their brackets (batched form)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double c = P.c, g = P.gamma, g2 = P.g2;
 
     // my edges: e = tid + ST k; z, the packed end points, w and the previous w stay in registers
-    double z[SMALL_EPT], wr[SMALL_EPT], wo[SMALL_EPT];
-    int ij[SMALL_EPT];
+    double z[EPT], wr[EPT], wo[EPT];
+    int ij[EPT];
     const double *w_in = P.w[P.it0 & 1];
 #pragma unroll
-    for (int k = 0; k < SMALL_EPT; ++k) {
+    for (int k = 0; k < EPT; ++k) {
         const int e = tid + ST * k;
         z[k] = wr[k] = wo[k] = 0.0;
         ij[k] = -1;
@@ -123,7 +283,7 @@ __global__ __launch_bounds__(T) void k_small(SmallDev P1, SmallBatch Q) {
         // ---- edge phase (:147-153,163): y, p, q, w <- (w - y) + q, norms of q - y and w
         double nqy = 0, nw = 0;
 #pragma unroll
-        for (int k = 0; k < SMALL_EPT; ++k) {
+        for (int k = 0; k < EPT; ++k) {
             if (ij[k] < 0) continue;
             const int e = tid + ST * k, i = ij[k] & 0xffff, j = ij[k] >> 16;
             const double w = wr[k];
@@ -219,22 +379,52 @@ __global__ __launch_bounds__(T) void k_small(SmallDev P1, SmallBatch Q) {
                 break;
             }
             if (P.it0 + iter >= 1) {
-                double mx[4] = {0, 0, 0, 0}, tr[4] = {0, 0, 0, 0};
-                for (int b = 0; b < Q.B; ++b)  // same data, same order in every workgroup
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const double v = __longlong_as_double((long long)__hip_atomic_load(
-                            (const unsigned long long *)(Q.diag + 4 * b + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                        mx[q] = fmax(mx[q], v);
-                        tr[q] += v;
+                // wave q gathers quantity q of every graph (same data, same order in every workgroup); one
+                // load per lane and 64 graphs -- every thread reading all 4 B words cost 20 us at 1024 threads
+                if (wave < 4) {
+                    double m = 0.0, t = 0.0;
+                    for (int b = lane; b < Q.B; b += 64) {
+                        const double v = sm_ld(Q.diag + 4 * b + wave);
+                        m = fmax(m, v);
+                        t += v;
                     }
+                    m = sm_wave_max(m);
+                    t = wave_sum(t);
+                    if (lane == 0) {
+                        gred[wave] = m;
+                        gred[4 + wave] = t;
+                    }
+                }
+                __syncthreads();
+                double mx[4], tr[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    mx[q] = gred[q];
+                    tr[q] = gred[4 + q];
+                }
                 // rel_p^2 in [mx0 / tr1, tr0 / mx1], rel_d^2 in [mx2 / tr3, tr2 / mx3]
                 const double t2 = P.tol * P.tol * (1 + 1e-9);
                 const bool degenerate = !(mx[1] > 0) || !(mx[3] > 0);
                 const bool surely_not = !degenerate && (mx[0] > t2 * tr[1] || mx[2] > t2 * tr[3]);
                 if (!surely_not) {
-                    reason = 1;  // the exact spectral norms are needed: the host decides
-                    break;
+                    if (!TIGHT || !Q.use_gram || degenerate) {
+                        reason = 1;  // the exact spectral norms are needed: the host decides
+                        break;
+                    }
+                    if (TIGHT) {
+                        // ---- tighten the brackets in place: the previous iterate joins the new one in LDS (the
+                        //      prox point is not needed any more in this iteration)
+#pragma unroll
+                        for (int k = 0; k < EPT; ++k)
+                            if (ij[k] >= 0) p_l[tid + ST * k] = wo[k];
+                        __syncthreads();
+                        const unsigned long long r = sm_tighten<ST>(Q, bs, w_l, p_l, d_l, dp_l, gred, gA, &s_ok, n, E, P.tol);
+                        bs.epoch = (unsigned)(r >> 32);
+                        if ((int)(r & 0xff) != 0) {
+                            reason = (int)(r & 0xff);
+                            break;
+                        }
+                    }
                 }
             }
             // the barrier of the next iteration separates these reads from the next round of writes
@@ -247,7 +437,7 @@ __global__ __launch_bounds__(T) void k_small(SmallDev P1, SmallBatch Q) {
         const long long itf = P.it0 + ran;
         double *w_cur = P.w[itf & 1], *w_prev = P.w[(itf + 1) & 1];
 #pragma unroll
-        for (int k = 0; k < SMALL_EPT; ++k)
+        for (int k = 0; k < EPT; ++k)
             if (ij[k] >= 0) {
                 const int64_t off = tiled_offset(ij[k] & 0xffff, ij[k] >> 16, P.nb);
                 w_cur[off] = wr[k];
@@ -307,13 +497,17 @@ SmallDev small_dev_of(const gl_logdeg *s, double tol, int64_t iters) {
     return P;
 }
 
-size_t small_lds_bytes(int n, int E) { return ((size_t)2 * E + 4 * n + 64) * 8; }
+// gram_b: batch size whose four Gram matrices the kernel holds (0: none)
+size_t small_lds_bytes(int n, int E, int gram_b = 0) { return ((size_t)2 * E + 4 * n + 64 + 256 + 4 * (size_t)gram_b * gram_b + 8) * 8; }
+constexpr size_t SMALL_LDS_MAX = 158 * 1024;
 
 int small_set_attrs(gl_ctx *ctx) {  // per context: one process may drive several GPUs
     if (ctx->small_attrs_set) return GL_OK;
-    const int most = (int)small_lds_bytes(SMALL_MAX_N, SMALL_MAX_N * (SMALL_MAX_N - 1) / 2);
+    const int most = (int)SMALL_LDS_MAX;
     GL_HIP(ctx, hipFuncSetAttribute((const void *)k_small<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, most));
     GL_HIP(ctx, hipFuncSetAttribute((const void *)k_small<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, most));
+    GL_HIP(ctx, hipFuncSetAttribute((const void *)k_small<1024, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, most));
+    GL_HIP(ctx, hipFuncSetAttribute((const void *)k_small<256, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, most));
     ctx->small_attrs_set = true;
     return GL_OK;
 }
@@ -346,13 +540,17 @@ int gl_small_launch(gl_logdeg *s, int64_t iters, double tol) {
 // Batched form: B sessions (same context, same n <= 128, same iteration count) advance together for up
 // to `iters` iterations or until the norm bounds can no longer exclude a stop.  Synchronous; advances
 // every session's iteration count.  need_exact: the host has to evaluate the exact rule now.
-// Device scratch layout: SmallDev[B] | diag[4 B] | status[2] | bar[GL_BAR_WORDS].
-size_t gl_small_batch_scratch_bytes(int B) {
-    return (size_t)B * sizeof(SmallDev) + (size_t)4 * B * 8 + 2 * 8 + GL_BAR_WORDS * 4 + 64;
+// Device scratch layout: SmallDev[B] | diag[4 B] | status[2] | bar[GL_BAR_WORDS] | pad | vec[B][vstride] | gram[4][B][B]
+// (B <= 32).
+// stopped: the coupled rule was met and decided on the device (no exact evaluation needed for the decision).
+static size_t small_vstride(int n) { return ((size_t)n * (n - 1) + 2 * (size_t)n + 15) / 16 * 16; }  // 2 E + 2 n, padded
+size_t gl_small_batch_scratch_bytes(int B, int n) {
+    return (size_t)B * sizeof(SmallDev) + (size_t)4 * B * 8 + 2 * 8 + GL_BAR_WORDS * 4 + 192 +
+           (B <= SMALL_GRAM_MAXB ? ((size_t)B * small_vstride(n) + (size_t)4 * B * B) * 8 : 0);
 }
 
 int gl_small_batch_run(gl_logdeg **sessions, int B, int64_t iters, double tol, void *dev_scratch, int64_t *ran_out,
-                       bool *need_exact_out) {
+                       bool *need_exact_out, bool *stopped_out) {
     gl_ctx *ctx = sessions[0]->ctx;
     char *base = (char *)dev_scratch;
     SmallDev *devs = (SmallDev *)base;
@@ -365,10 +563,19 @@ int gl_small_batch_run(gl_logdeg **sessions, int B, int64_t iters, double tol, v
     GL_HIP(ctx, hipMemsetAsync(status, 0, 2 * 8 + GL_BAR_WORDS * 4, ctx->stream));
     GL_TRY(small_set_attrs(ctx));
     const int n = host[0].n;
-    const size_t lds = small_lds_bytes(n, host[0].E);
-    const SmallBatch Q{devs, diag, status, bar, B, B + (getenv("GRAPHLEARN_AMD_RES_TEST_NOT_RESIDENT") ? 1 : 0)};
+    // the env: tests / comparison
+    const bool use_gram = B <= SMALL_GRAM_MAXB && small_lds_bytes(n, host[0].E, B) <= SMALL_LDS_MAX && (n <= 64 || B >= 12) &&
+                          !getenv("GRAPHLEARN_AMD_BATCH_HOST_RULE");
+    const size_t lds = small_lds_bytes(n, host[0].E, use_gram ? B : 0);
+    double *vec = (double *)(((uintptr_t)(bar + GL_BAR_WORDS) + 63) & ~(uintptr_t)63);
+    const int vstride = (int)small_vstride(n);
+    double *gram = vec + (B <= SMALL_GRAM_MAXB ? (size_t)B * vstride : 0);
+    const SmallBatch Q{devs, diag, status, bar, B, B + (getenv("GRAPHLEARN_AMD_RES_TEST_NOT_RESIDENT") ? 1 : 0),
+                       vec, gram, vstride, use_gram ? 1 : 0};
     if (n <= 64)
-        k_small<256, true><<<B, 256, lds, ctx->stream>>>(host[0], Q);
+        k_small<256, true, true><<<B, 256, lds, ctx->stream>>>(host[0], Q);
+    else if (use_gram)
+        k_small<1024, true, true><<<B, 1024, lds, ctx->stream>>>(host[0], Q);
     else
         k_small<1024, true><<<B, 1024, lds, ctx->stream>>>(host[0], Q);
     GL_HIP(ctx, hipGetLastError());
@@ -380,6 +587,7 @@ int gl_small_batch_run(gl_logdeg **sessions, int B, int64_t iters, double tol, v
     for (int a = 0; a < B; ++a) sessions[a]->it += st[0];
     *ran_out = st[0];
     *need_exact_out = st[1] == 1;
+    *stopped_out = st[1] == 3;
     if (st[1] == 2) {
         // the workgroups did not all meet (GPU shared with another process).  At the start-up rendezvous
         // nothing has been modified and the caller falls back to per-iteration launches; later it is an error.

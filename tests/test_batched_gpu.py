@@ -77,10 +77,16 @@ def test_batched_paths_agree_and_fall_back(golden, engine, monkeypatch):
     np.testing.assert_allclose(out[~near], g["w_converged"][~near], rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize("n,b", [(2, 3), (5, 1), (5, 300), (64, 5), (65, 4), (128, 3), (129, 3)])
-def test_batched_sizes_against_oracle(n, b):
-    """Both sides of the small-engine limits (64 / 128 nodes), a batch of one, tiny graphs: same stopping
-    iteration and iterates as the oracle's 2-D branch."""
+@pytest.mark.parametrize("rule", ["device", "host"])
+@pytest.mark.parametrize("n,b", [(2, 3), (5, 1), (5, 300), (64, 5), (65, 4), (128, 3), (129, 3), (30, 20), (64, 16),
+                                 (100, 32), (128, 20), (128, 32)])
+def test_batched_sizes_against_oracle(n, b, rule, monkeypatch):
+    """Both sides of the small-engine limits (64 / 128 nodes), a batch of one, tiny graphs, batches on both
+    sides of what the in-kernel evaluation of the coupled rule takes (B <= 32, LDS permitting): same stopping
+    iteration and iterates as the oracle's 2-D branch, with the rule's brackets tightened on the device or
+    every ambiguous iteration handed to the host."""
+    if rule == "host":
+        monkeypatch.setenv("GRAPHLEARN_AMD_BATCH_HOST_RULE", "1")
     rng = default_rng(100 * n + b)
     e = n * (n - 1) // 2
     z = rng.uniform(0.1, 3.0, size=(b, e))
