@@ -849,7 +849,7 @@ struct AdmmRes {
     // "tagged" form (k_lg_admm_tag): v travels as self-validating records, no grid barrier
     bool tagged = false;
     lg_u4 *gran = nullptr;  // [2][n] records of 16 bytes
-    unsigned seq = 0;       // launches so far: the tags of a launch are 128 seq + 1 + step
+    unsigned next_tag = 0;  // first tag of the next launch (a launch uses max_iter + 1 consecutive ones)
 };
 
 // Which form the QP's ADMM loop takes.  GRAPHLEARN_AMD_LGMRF_ADMM = launch | one | resident | tagged forces
@@ -899,12 +899,14 @@ int run_admm_res(gl_ctx *ctx, const LgDev &D, AdmmRes &A, int max_iter, int64_t 
     if (!A.tagged) GL_HIP(ctx, hipMemsetAsync(A.bar, 0, GL_BAR_WORDS * 4, ctx->stream));
     const GlGridBar gb{A.bar, A.nwg + (test_not_resident ? 1 : 0)};
     if (A.tagged) {
-        if (max_iter > 120) return gl_set_error(ctx, GL_E_INVALID, "tagged ADMM form: max_iter <= 120");
-        if (A.seq >= (1u << 24)) {  // tags would wrap into old ones: start over on clean records
+        // tags of this launch: next_tag .. next_tag + max_iter (never 0, never one a record may still carry)
+        if (max_iter >= (1 << 28)) return gl_set_error(ctx, GL_E_INVALID, "ADMM: max_iter too large");
+        if (A.next_tag == 0u || A.next_tag > 0xE0000000u) {  // first use, or the tags would wrap into old ones
             GL_HIP(ctx, hipMemsetAsync(A.gran, 0, (size_t)2 * D.n * 16, ctx->stream));
-            A.seq = 0;
+            A.next_tag = 1u;
         }
-        const unsigned tag0 = 128u * A.seq++ + 1u;
+        const unsigned tag0 = A.next_tag;
+        A.next_tag += (unsigned)max_iter + 2u;
         // error word: bar[32], zero since the allocation (a failure ends the use of this form)
         k_lg_admm_tag<<<dim3((unsigned)A.nwg), 256, A.lds, ctx->stream>>>(D, A.bar + 32, A.gran, tag0, A.R, max_iter, u_fast,
                                                                            test_not_resident ? 1 : 0);

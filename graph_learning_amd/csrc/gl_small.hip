@@ -10,8 +10,9 @@
 // an iteration are workgroup barriers, and the stopping rule is evaluated in place, exactly when the
 // reference evaluates it (no deferral).  Deterministic: every sum has a fixed order.
 //
-// Batched form (the 2-D branch, :128-129,158-159): one workgroup per graph, a grid barrier per
-// iteration to exchange the four squared norms of every graph.  They are the diagonals of the Gram
+// Batched form (the 2-D branch, :128-129,158-159): one workgroup per graph; after every iteration the
+// four squared norms of every graph go round as tagged records (one memory round trip, no grid barrier:
+// see the exchange in the kernel).  They are the diagonals of the Gram
 // matrices whose largest eigenvalues decide the coupled stopping rule, and lambda_max lies in
 // [max diagonal, trace]: while those bounds keep the ratios above tol the loop goes on; when they
 // straddle tol (or allow a stop) the workgroups tighten them in place (B <= 32 and LDS permitting): every graph publishes
@@ -51,7 +52,7 @@ constexpr int SMALL_GRAM_MAXB = 32;  // the in-kernel brackets of lambda_max: B^
 
 struct SmallBatch {
     const SmallDev *devs;  // one per graph (device array)
-    double *diag;          // [B][4] squared norms of the last iteration
+    unsigned long long *drec;  // [2][B][4][2]: the four squared norms of every graph as tagged records, by iteration parity
     long long *status;     // [0] iterations run by this launch, [1] 0 = maxit reached, 1 = the host must decide,
                            //     2 = barrier lost, 3 = the coupled rule is met (decided on the device)
     unsigned *bar;         // grid barrier words (gl_gridbar.h)
@@ -368,34 +369,59 @@ __global__ __launch_bounds__(T) void k_small(SmallDev P1, SmallBatch Q) {
             }
             __syncthreads();  // red is rewritten next iteration
         } else {
-            // coupled rule: publish my four squared norms, meet, read everybody's
-            if (tid == 0)
-                for (int q = 0; q < 4; ++q)
-                    __hip_atomic_store((unsigned long long *)(Q.diag + 4 * blockIdx.x + q),
-                                       (unsigned long long)__double_as_longlong(tot[q]), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-            if (!gl_grid_barrier(gb, bs, &s_ok)) {
-                reason = 2;  // barrier lost: the host reports it
-                break;
+            // coupled rule: every graph publishes its four squared norms as self-validating records {low word |
+            // tag}, {high word | tag}, tag = iteration + 1 (zeroed by the host before the launch), and wave q
+            // re-reads quantity q of all graphs until every tag matches: one memory round trip, no grid barrier
+            // ("the data is the flag", as in the LGMRF ADMM kernel).  Two record sets by iteration parity: a
+            // graph publishes iteration k + 1 only after it has read everybody's iteration k.
+            if (tid < 4) {
+                const double v = tid == 0 ? tot[0] : (tid == 1 ? tot[1] : (tid == 2 ? tot[2] : tot[3]));
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+                const unsigned long long tg = (unsigned long long)(unsigned)(iter + 1) << 32;
+                unsigned long long *r = Q.drec + (((size_t)(iter & 1) * Q.B + blockIdx.x) * 4 + tid) * 2;
+                __hip_atomic_store(r, (bits & 0xffffffffull) | tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(r + 1, (bits >> 32) | tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (P.it0 + iter >= 1) {
-                // wave q gathers quantity q of every graph (same data, same order in every workgroup); one
-                // load per lane and 64 graphs -- every thread reading all 4 B words cost 20 us at 1024 threads
-                if (wave < 4) {
-                    double m = 0.0, t = 0.0;
-                    for (int b = lane; b < Q.B; b += 64) {
-                        const double v = sm_ld(Q.diag + 4 * b + wave);
+            if (wave < 4) {
+                double m = 0.0, t = 0.0;
+                const unsigned want = (unsigned)(iter + 1);
+                const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+                bool good = true;
+                for (int b0 = 0; good && b0 < Q.B; b0 += 64) {
+                    const int b = b0 + lane;
+                    const unsigned long long *r = Q.drec + (((size_t)(iter & 1) * Q.B + (b < Q.B ? b : 0)) * 4 + wave) * 2;
+                    unsigned long long lo = 0, hi = 0;
+                    for (unsigned spins = 0;; ++spins) {
+                        lo = __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        hi = __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const bool ok = b >= Q.B || ((unsigned)(lo >> 32) == want && (unsigned)(hi >> 32) == want);
+                        if (__all(ok)) break;
+                        __builtin_amdgcn_s_sleep(2);
+                        if ((spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t_start > 100000000ull) {
+                            good = false;  // 1 s: a graph's workgroup is gone
+                            break;
+                        }
+                    }
+                    if (good && b < Q.B) {
+                        const double v = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
                         m = fmax(m, v);
                         t += v;
                     }
-                    m = sm_wave_max(m);
-                    t = wave_sum(t);
-                    if (lane == 0) {
-                        gred[wave] = m;
-                        gred[4 + wave] = t;
-                    }
                 }
-                __syncthreads();
+                m = sm_wave_max(m);
+                t = wave_sum(t);
+                if (lane == 0) {
+                    gred[wave] = m;
+                    gred[4 + wave] = t;
+                    if (!good) s_ok = 0;
+                }
+            }
+            __syncthreads();
+            if (!s_ok) {
+                reason = 2;  // hand-off lost: the host reports it
+                break;
+            }
+            if (P.it0 + iter >= 1) {
                 double mx[4], tr[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -427,7 +453,6 @@ __global__ __launch_bounds__(T) void k_small(SmallDev P1, SmallBatch Q) {
                     }
                 }
             }
-            // the barrier of the next iteration separates these reads from the next round of writes
         }
     }
     __syncthreads();
@@ -540,12 +565,12 @@ int gl_small_launch(gl_logdeg *s, int64_t iters, double tol) {
 // Batched form: B sessions (same context, same n <= 128, same iteration count) advance together for up
 // to `iters` iterations or until the norm bounds can no longer exclude a stop.  Synchronous; advances
 // every session's iteration count.  need_exact: the host has to evaluate the exact rule now.
-// Device scratch layout: SmallDev[B] | diag[4 B] | status[2] | bar[GL_BAR_WORDS] | pad | vec[B][vstride] | gram[4][B][B]
-// (B <= 32).
-// stopped: the coupled rule was met and decided on the device (no exact evaluation needed for the decision).
 static size_t small_vstride(int n) { return ((size_t)n * (n - 1) + 2 * (size_t)n + 15) / 16 * 16; }  // 2 E + 2 n, padded
+// Device scratch layout: SmallDev[B] | status[2] | bar[GL_BAR_WORDS] | drec[2][B][4][2] | pad | vec[B][vstride] |
+// gram[4][B][B] (B <= 32).  status .. drec are zeroed before every launch.
+// stopped: the coupled rule was met and decided on the device (no exact evaluation needed for the decision).
 size_t gl_small_batch_scratch_bytes(int B, int n) {
-    return (size_t)B * sizeof(SmallDev) + (size_t)4 * B * 8 + 2 * 8 + GL_BAR_WORDS * 4 + 192 +
+    return (size_t)B * sizeof(SmallDev) + 2 * 8 + GL_BAR_WORDS * 4 + (size_t)B * 128 + 192 +
            (B <= SMALL_GRAM_MAXB ? ((size_t)B * small_vstride(n) + (size_t)4 * B * B) * 8 : 0);
 }
 
@@ -554,23 +579,24 @@ int gl_small_batch_run(gl_logdeg **sessions, int B, int64_t iters, double tol, v
     gl_ctx *ctx = sessions[0]->ctx;
     char *base = (char *)dev_scratch;
     SmallDev *devs = (SmallDev *)base;
-    double *diag = (double *)(base + (size_t)B * sizeof(SmallDev));
-    long long *status = (long long *)(diag + 4 * B);
+    long long *status = (long long *)(base + (size_t)B * sizeof(SmallDev));
     unsigned *bar = (unsigned *)(status + 2);
+    unsigned long long *drec = (unsigned long long *)(bar + GL_BAR_WORDS);
+    const size_t zero_bytes = 2 * 8 + GL_BAR_WORDS * 4 + (size_t)B * 128;
     std::vector<SmallDev> host((size_t)B);
     for (int a = 0; a < B; ++a) host[(size_t)a] = small_dev_of(sessions[a], tol, iters);
     GL_HIP(ctx, hipMemcpyAsync(devs, host.data(), host.size() * sizeof(SmallDev), hipMemcpyHostToDevice, ctx->stream));
-    GL_HIP(ctx, hipMemsetAsync(status, 0, 2 * 8 + GL_BAR_WORDS * 4, ctx->stream));
+    GL_HIP(ctx, hipMemsetAsync(status, 0, zero_bytes, ctx->stream));
     GL_TRY(small_set_attrs(ctx));
     const int n = host[0].n;
     // the env: tests / comparison
     const bool use_gram = B <= SMALL_GRAM_MAXB && small_lds_bytes(n, host[0].E, B) <= SMALL_LDS_MAX && (n <= 64 || B >= 12) &&
                           !getenv("GRAPHLEARN_AMD_BATCH_HOST_RULE");
     const size_t lds = small_lds_bytes(n, host[0].E, use_gram ? B : 0);
-    double *vec = (double *)(((uintptr_t)(bar + GL_BAR_WORDS) + 63) & ~(uintptr_t)63);
+    double *vec = (double *)(((uintptr_t)(drec + (size_t)B * 16) + 63) & ~(uintptr_t)63);
     const int vstride = (int)small_vstride(n);
     double *gram = vec + (B <= SMALL_GRAM_MAXB ? (size_t)B * vstride : 0);
-    const SmallBatch Q{devs, diag, status, bar, B, B + (getenv("GRAPHLEARN_AMD_RES_TEST_NOT_RESIDENT") ? 1 : 0),
+    const SmallBatch Q{devs, drec, status, bar, B, B + (getenv("GRAPHLEARN_AMD_RES_TEST_NOT_RESIDENT") ? 1 : 0),
                        vec, gram, vstride, use_gram ? 1 : 0};
     if (n <= 64)
         k_small<256, true, true><<<B, 256, lds, ctx->stream>>>(host[0], Q);

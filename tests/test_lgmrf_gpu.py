@@ -126,3 +126,15 @@ def test_persistent_forms_fall_back_when_not_co_resident(golden, monkeypatch, ad
     m = LGMRF().fit(g["cov_16"].copy())
     assert m.converged_ == int(g["conv_16_np1_rt1"])
     assert close(m.laplacian_, g["lapl_16_np1_rt1"]) and close(m.inv_laplacian_, g["inv_16_np1_rt1"])
+
+
+def test_qp_solver_many_iterations():
+    """More steps than the default 100 (the tagged form numbers its hand-offs by step) against the oracle."""
+    rng = np.random.default_rng(5)
+    n = 40
+    a = rng.standard_normal((n, 2 * n))
+    q, p = a @ a.T / (2 * n) + 0.1 * np.eye(n), rng.standard_normal(n)
+    z, iters = nonnegative_qp_solver(q, p, step=0.1, tol=1e-13, max_iter=400, return_iters=True)
+    zr, ref_iters = olg.nonneg_qp_admm(q, p, step=0.1, tol=1e-13, max_iter=400, return_iters=True)
+    assert abs(iters - ref_iters) <= 1 and iters > 120
+    np.testing.assert_allclose(z, zr, rtol=0, atol=1e-10)
