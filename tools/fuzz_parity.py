@@ -1,0 +1,122 @@
+"""Randomised parity sweep (GPU vs the oracle) over shapes and parameters the fixed tests do not list.
+usage: python tools/fuzz_parity.py [seconds=90] [seed=0].  Exit code 1 on the first mismatch."""
+import os, sys, time, warnings
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+warnings.simplefilter("ignore")
+import numpy as np
+from graph_learning_amd import LGMRF, gsp_learn_graph_log_degrees, nonnegative_qp_solver
+from graph_learning_amd.dictionary import GraphDictLog
+from oracle import lgmrf as olg, logdeg as old
+from oracle.graphdict import GraphDictLogOracle
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t_end = time.time() + budget
+counts = dict(logdeg=0, batched=0, lgmrf=0, qp=0, graphdict=0)
+
+
+def fail(kind, desc, msg):
+    print(f"MISMATCH [{kind}] {desc}: {msg}", flush=True)
+    sys.exit(1)
+
+
+while time.time() < t_end:
+    kind = rng.choice(["logdeg", "batched", "lgmrf", "qp", "graphdict"], p=[0.35, 0.25, 0.1, 0.1, 0.2])
+    if kind == "logdeg":
+        n = int(rng.choice([2, 3, 5, 17, 63, 64, 65, 100, 127, 128, 129, 200, 257, 320]))
+        e = n * (n - 1) // 2
+        z = rng.uniform(0.05, 4.0, size=e) * (rng.uniform(size=e) < rng.uniform(0.3, 1.0) if n > 3 else 1)
+        a, b = rng.uniform(0.3, 2.0), rng.uniform(0.3, 2.0)
+        eng = rng.choice(["auto", "stream", "small"])
+        if eng == "auto":
+            os.environ.pop("GRAPHLEARN_AMD_ENGINE", None)
+        else:
+            os.environ["GRAPHLEARN_AMD_ENGINE"] = eng
+        if rng.uniform() < 0.5:   # fixed iterations, raw iterate
+            its = int(rng.integers(1, 60))
+            kw = dict(maxit=its, tol=0.0, edge_tol=-np.inf)
+        else:                      # to tolerance
+            kw = dict(maxit=3000, tol=float(rng.choice([1e-3, 1e-4, 1e-5])), edge_tol=-np.inf)
+        ref, ri = old.learn_log_degrees(z, a, b, return_info=True, **kw)
+        out, gi = gsp_learn_graph_log_degrees(z, a, b, return_info=True, **kw)
+        desc = f"n={n} a={a:.3f} b={b:.3f} engine={eng} {kw}"
+        if abs(gi["n_iter"] - ri["n_iter"]) > 1:
+            fail(kind, desc, f"iterations {gi['n_iter']} vs {ri['n_iter']}")
+        if gi["n_iter"] == ri["n_iter"] and not np.allclose(out, ref, rtol=0, atol=1e-9):
+            fail(kind, desc, f"max diff {np.abs(out - ref).max():.2e}")
+        os.environ.pop("GRAPHLEARN_AMD_ENGINE", None)
+    elif kind == "batched":
+        n = int(rng.choice([2, 4, 9, 30, 64, 65, 100, 128, 140]))
+        bsz = int(rng.choice([1, 2, 5, 11, 12, 16, 17, 32, 33, 40]))
+        e = n * (n - 1) // 2
+        z = rng.uniform(0.1, 3.0, size=(bsz, e))
+        a, b = rng.uniform(0.5, 1.5), rng.uniform(0.5, 1.5)
+        if rng.uniform() < 0.3:
+            os.environ["GRAPHLEARN_AMD_BATCH_HOST_RULE"] = "1"
+        kw = dict(maxit=500, tol=float(rng.choice([1e-3, 1e-4, 1e-6])), edge_tol=-np.inf)
+        ref, ri = old.learn_log_degrees(z, a, b, return_info=True, **kw)
+        out, gi = gsp_learn_graph_log_degrees(z, a, b, return_info=True, **kw)
+        desc = f"n={n} B={bsz} a={a:.3f} b={b:.3f} host_rule={'GRAPHLEARN_AMD_BATCH_HOST_RULE' in os.environ} {kw}"
+        os.environ.pop("GRAPHLEARN_AMD_BATCH_HOST_RULE", None)
+        if gi["n_iter"] != ri["n_iter"]:
+            fail(kind, desc, f"iterations {gi['n_iter']} vs {ri['n_iter']}")
+        if not np.allclose(out, ref, rtol=0, atol=1e-9):
+            fail(kind, desc, f"max diff {np.abs(out - ref).max():.2e}")
+    elif kind == "lgmrf":
+        n = int(rng.choice([3, 6, 12, 17, 33, 48]))
+        x = rng.standard_normal((int(rng.integers(2, 6)) * n, n)) @ (np.eye(n) + 0.3 * rng.standard_normal((n, n)))
+        cov = x.T @ x / x.shape[0]
+        form = rng.choice(["auto", "launch", "one", "resident", "tagged"])
+        if form == "auto":
+            os.environ.pop("GRAPHLEARN_AMD_LGMRF_ADMM", None)
+        else:
+            os.environ["GRAPHLEARN_AMD_LGMRF_ADMM"] = form
+        kw = dict(norm_par=float(rng.choice([1, 3, 10])), regularization_type=int(rng.choice([1, 2])), max_cycle=int(rng.integers(2, 9)))
+        o = olg.LGMRFOracle(**kw).fit(cov.copy())
+        m = LGMRF(**kw).fit(cov.copy(), path=int(rng.choice([0, 1, 2])))
+        os.environ.pop("GRAPHLEARN_AMD_LGMRF_ADMM", None)
+        desc = f"n={n} form={form} {kw}"
+        if not np.isfinite(o.laplacian_).all():
+            continue
+        if m.converged_ != o.converged_:
+            fail(kind, desc, f"converged_ {m.converged_} vs {o.converged_}")
+        err = np.abs(m.laplacian_ - o.laplacian_).max() / max(np.abs(o.laplacian_).max(), 1e-300)
+        if err > 1e-6:
+            fail(kind, desc, f"relative error {err:.2e}")
+    elif kind == "qp":
+        n = int(rng.choice([2, 5, 16, 40, 64, 65, 130, 300]))
+        a = rng.standard_normal((n, n + 3))
+        q, p = a @ a.T / n + rng.uniform(0.01, 1.0) * np.eye(n), rng.standard_normal(n)
+        form = rng.choice(["auto", "launch", "one", "resident", "tagged"])
+        if form == "auto":
+            os.environ.pop("GRAPHLEARN_AMD_LGMRF_ADMM", None)
+        else:
+            os.environ["GRAPHLEARN_AMD_LGMRF_ADMM"] = form
+        kw = dict(step=float(rng.choice([0.05, 0.1, 0.5])), tol=float(rng.choice([1e-4, 1e-6, 1e-9])), max_iter=int(rng.choice([1, 2, 3, 50, 100, 333])))
+        zr, ir = olg.nonneg_qp_admm(q, p, return_iters=True, **kw)
+        z, ig = nonnegative_qp_solver(q, p, return_iters=True, **kw)
+        os.environ.pop("GRAPHLEARN_AMD_LGMRF_ADMM", None)
+        desc = f"n={n} form={form} {kw}"
+        if abs(ig - ir) > 1:
+            fail(kind, desc, f"iterations {ig} vs {ir}")
+        if ig == ir and not np.allclose(z, zr, rtol=0, atol=1e-9):
+            fail(kind, desc, f"max diff {np.abs(z - zr).max():.2e}")
+    else:
+        n, t = int(rng.choice([3, 7, 12, 20, 33, 70])), int(rng.choice([5, 23, 64, 130]))
+        k, w = int(rng.choice([1, 2, 3, 5, 9])), int(rng.choice([1, 1, 2, 5]))
+        x = rng.standard_normal((t, n)) * 0.5
+        eng = rng.choice(["launch", "small"])
+        os.environ["GRAPHLEARN_AMD_GD_ENGINE"] = eng
+        kw = dict(n_atoms=k, window_size=w, l1_w=float(rng.choice([0, 0.01])), l1_c=float(rng.choice([0, 0.002])),
+                  ortho_w=float(rng.choice([0, 0.05])), log_c=float(rng.choice([0, 0.02])), l1_diff_c=float(rng.choice([0, 0.001])),
+                  step=float(rng.choice([0.2, 0.5, 1.0])), max_iter=int(rng.integers(1, 7)), tol=0.0, random_state=int(rng.integers(1 << 30)))
+        o = GraphDictLogOracle(**kw).fit(x)
+        m = GraphDictLog(**kw).fit(x)
+        os.environ.pop("GRAPHLEARN_AMD_GD_ENGINE", None)
+        desc = f"n={n} T={t} engine={eng} {kw}"
+        for name in ("coefficients_", "weights_", "dual_"):
+            if not np.allclose(getattr(m, name), getattr(o, name), rtol=1e-9, atol=1e-9):
+                fail(kind, desc, f"{name} max diff {np.abs(getattr(m, name) - getattr(o, name)).max():.2e}")
+    counts[kind] += 1
+print("fuzz ok:", counts, flush=True)
