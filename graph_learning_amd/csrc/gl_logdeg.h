@@ -38,6 +38,7 @@ struct gl_logdeg {
     gl_ctx *ctx = nullptr;
     LogdegDev dev{};
     int64_t n = 0, n_edges = 0;
+    void *arena = nullptr;        // the one allocation every fixed-size buffer of the session is carved from
     double *zsq = nullptr;        // n x n squared distances (set_signals only)
     double *stage = nullptr;      // device staging for condensed host transfers (E doubles)
     double *xdev = nullptr;       // signals (d x n) on device

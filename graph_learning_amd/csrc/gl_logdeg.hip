@@ -714,7 +714,7 @@ int check(gl_logdeg *s) { return (s && s->ctx) ? GL_OK : GL_E_INVALID; }
 // tile: colslab entries are laid out contiguously per column block J (col_ptr, read
 // by the node pass without indirection) and seg_dest[wave*kmax + seg] tells the edge
 // pass where to put them.
-int build_column_index(gl_logdeg *s) {
+int build_column_index(gl_logdeg *s, std::vector<int> &ptr, std::vector<int> &dest) {
     gl_ctx *ctx = s->ctx;
     LogdegDev &D = s->dev;
     std::vector<std::vector<int>> lists((size_t)D.nb);
@@ -738,21 +738,14 @@ int build_column_index(gl_logdeg *s) {
             p += cnt;
         }
     }
-    std::vector<int> ptr((size_t)D.nb + 1, 0);
-    std::vector<int> dest((size_t)D.G * D.kmax, 0);
+    ptr.assign((size_t)D.nb + 1, 0);
+    dest.assign((size_t)D.G * D.kmax, 0);
     for (int64_t J = 0; J < D.nb; ++J) {
         int pos = ptr[(size_t)J];
         for (int key : lists[(size_t)J]) dest[(size_t)key] = pos++;
         ptr[(size_t)J + 1] = pos;
     }
     s->n_segments = ptr[(size_t)D.nb];
-    GL_HIP(ctx, hipMalloc((void **)&s->col_ptr, ptr.size() * sizeof(int)));
-    GL_HIP(ctx, hipMalloc((void **)&s->seg_dest, dest.size() * sizeof(int)));
-    GL_HIP(ctx, hipMalloc((void **)&D.colslab, (size_t)std::max(s->n_segments, 1) * 2 * GL_TB * 8));
-    GL_HIP(ctx, hipMemcpy(s->col_ptr, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice));
-    GL_HIP(ctx, hipMemcpy(s->seg_dest, dest.data(), dest.size() * sizeof(int), hipMemcpyHostToDevice));
-    D.col_ptr = s->col_ptr;
-    D.seg_dest = s->seg_dest;
     return GL_OK;
 }
 
@@ -841,30 +834,52 @@ GL_API int gl_logdeg_create(gl_ctx *ctx, int64_t n_nodes, gl_logdeg **out) {
     const int64_t maxchunk = (D.npairs + D.G - 1) / D.G;
     D.kmax = (int)((maxchunk + PAIRS_PER_TILE - 1) / PAIRS_PER_TILE) + 1;
     const size_t tiled_bytes = (size_t)D.ntiles * GL_TILE_ELEMS * sizeof(double);
-    auto alloc = [&](void **p, size_t bytes) -> int {
-        hipError_t e = hipMalloc(p, bytes);
-        if (e != hipSuccess) return gl_set_error(ctx, GL_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-        return GL_OK;
-    };
-    int rc = GL_OK;
-    double *zbuf = nullptr;
-    if ((rc = alloc((void **)&D.w[0], tiled_bytes)) || (rc = alloc((void **)&D.w[1], tiled_bytes)) ||
-        (rc = alloc((void **)&zbuf, tiled_bytes)) || (rc = alloc((void **)&D.dvar, D.n_pad * 8)) || (rc = alloc((void **)&D.dprev, D.n_pad * 8)) ||
-        (rc = alloc((void **)&D.ybar, D.n_pad * 8)) || (rc = alloc((void **)&D.pbar, D.n_pad * 8)) ||
-        (rc = alloc((void **)&D.rowslab_p, (size_t)D.nb * D.n_pad * 8)) ||
-        (rc = alloc((void **)&D.rowslab_w, (size_t)D.nb * D.n_pad * 8)) ||
-        (rc = alloc((void **)&D.tnorm, (size_t)D.G * 2 * 8)) || (rc = alloc((void **)&D.bnorm, (size_t)2 * D.nb * 4 * 8)) ||
-        (rc = alloc((void **)&D.dstat, 8 * 8)) || (rc = alloc((void **)&D.ctr, 8 * 8)) ||
-        (rc = alloc((void **)&s->stage, (size_t)s->n_edges * 8))) {
-        D.z = zbuf;
-        gl_logdeg_destroy(s);
+    std::vector<int> ptr, dest;
+    int rc = build_column_index(s, ptr, dest);
+    if (rc != GL_OK) {
+        delete s;
         return rc;
+    }
+    // every buffer of the session in ONE allocation (a session used to cost 17 hipMalloc / hipFree pairs and
+    // two synchronous pageable copies: 150 us, most of the set-up of a batch of small graphs)
+    double *zbuf = nullptr;
+    struct Part {
+        void **p;
+        size_t bytes;
+    };
+    const Part parts[] = {
+        {(void **)&D.w[0], tiled_bytes}, {(void **)&D.w[1], tiled_bytes}, {(void **)&zbuf, tiled_bytes},
+        {(void **)&D.dvar, (size_t)D.n_pad * 8}, {(void **)&D.dprev, (size_t)D.n_pad * 8},
+        {(void **)&D.ybar, (size_t)D.n_pad * 8}, {(void **)&D.pbar, (size_t)D.n_pad * 8},
+        {(void **)&D.rowslab_p, (size_t)D.nb * D.n_pad * 8}, {(void **)&D.rowslab_w, (size_t)D.nb * D.n_pad * 8},
+        {(void **)&D.tnorm, (size_t)D.G * 2 * 8}, {(void **)&D.bnorm, (size_t)2 * D.nb * 4 * 8},
+        {(void **)&D.dstat, 8 * 8}, {(void **)&D.ctr, 8 * 8}, {(void **)&s->stage, (size_t)s->n_edges * 8},
+        {(void **)&s->col_ptr, ptr.size() * sizeof(int)}, {(void **)&s->seg_dest, dest.size() * sizeof(int)},
+        {(void **)&D.colslab, (size_t)std::max(s->n_segments, 1) * 2 * GL_TB * 8}};
+    size_t total = 0;
+    for (const Part &q : parts) total += (q.bytes + 255) / 256 * 256;
+    hipError_t e = hipMalloc(&s->arena, total);
+    if (e != hipSuccess) {
+        delete s;
+        return gl_set_error(ctx, GL_E_NOMEM, "hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
+    }
+    {
+        char *at = (char *)s->arena;
+        for (const Part &q : parts) {
+            *q.p = at;
+            at += (q.bytes + 255) / 256 * 256;
+        }
     }
     D.z = zbuf;
-    if ((rc = build_column_index(s)) != GL_OK || (rc = gl_resident_prepare(s)) != GL_OK) {
+    D.col_ptr = s->col_ptr;
+    D.seg_dest = s->seg_dest;
+    if ((rc = gl_h2d(ctx, s->col_ptr, ptr.data(), ptr.size() * sizeof(int))) != GL_OK ||
+        (rc = gl_h2d(ctx, s->seg_dest, dest.data(), dest.size() * sizeof(int))) != GL_OK ||
+        (rc = gl_resident_prepare(s)) != GL_OK) {
         gl_logdeg_destroy(s);
         return rc;
     }
+    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // ptr / dest are locals: the staged uploads have left them
     *out = s;
     return GL_OK;
 }
@@ -877,10 +892,7 @@ GL_API int gl_logdeg_destroy(gl_logdeg *s) {
     }
     drop_graph(s);
     gl_resident_free(s);
-    LogdegDev &D = s->dev;
-    void *ptrs[] = {D.w[0], D.w[1], const_cast<double *>(D.z), D.dvar, D.dprev, D.ybar, D.pbar, D.rowslab_p, D.rowslab_w,
-                    D.colslab, D.tnorm, D.bnorm, D.dstat, D.ctr, s->stage, s->zsq, s->xdev, s->theta_terms,
-                    s->col_ptr, s->seg_dest};
+    void *ptrs[] = {s->arena, s->zsq, s->xdev, s->theta_terms};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete s;
