@@ -760,27 +760,40 @@ GL_API int gl_graphdict_create(gl_ctx *ctx, int64_t n_nodes, int64_t n_samples, 
     if (const char *e = getenv("GRAPHLEARN_AMD_GD_TS")) P.TS = std::max(1, std::min(64, atoi(e)));  // tuning aid
     if (const char *e = getenv("GRAPHLEARN_AMD_GD_NG")) P.NG = std::max(1, std::min(nstrips, atoi(e)));
     P.MS = std::max(1, std::min(128, P.T / 32));
-    int rc = GL_OK;
     const size_t np2 = (size_t)P.n_pad * P.n_pad;
-    if ((rc = gd_alloc(s, &P.X, (size_t)P.Tp * P.n_pad)) || (rc = gd_alloc(s, &P.XT, (size_t)P.n_pad * P.Tp)) ||
-        (rc = gd_alloc(s, &P.WS, np2 * P.KP)) || (rc = gd_alloc(s, &P.C, (size_t)P.K * P.T)) ||
-        (rc = gd_alloc(s, &P.CT, (size_t)P.Tp * P.KP)) || (rc = gd_alloc(s, &P.Cw, (size_t)P.KP * P.Tw)) ||
-        (rc = gd_alloc(s, &P.dual, (size_t)P.Tw * P.n)) || (rc = gd_alloc(s, &P.deg, (size_t)P.KP * P.n_pad)) ||
-        (rc = gd_alloc(s, &P.deg_new, (size_t)P.KP * P.n_pad)) || (rc = gd_alloc(s, &P.SC, (size_t)P.NG * P.KP * P.Tp)) ||
-        (rc = gd_alloc(s, &P.SCR, (size_t)P.KP * P.Tp)) || (rc = gd_alloc(s, &P.wtasks, tasks.size())) || (rc = gd_alloc(s, &P.cnorm, 256 * 3)) ||
-        (rc = gd_alloc(s, &P.GS, (size_t)P.TS * np2 * P.KP)) || (rc = gd_alloc(s, &P.MSL, (size_t)P.MS * P.KP * P.n_pad)) ||
-        (rc = gd_alloc(s, &P.M, (size_t)P.KP * P.n_pad)) || (rc = gd_alloc(s, &P.cpart, (size_t)P.Tw)) ||
-        (rc = gd_alloc(s, &P.wpart, (size_t)P.n * (P.n_pad / 64) * 3)) || (rc = gd_alloc(s, &P.stat, GD_NORM_SLOTS))) {
-        for (void *p : s->allocs) (void)hipFree(p);
-        delete s;
-        return rc;
-    }
+    // every buffer of the session in ONE zeroed allocation (21 hipMalloc + memset pairs cost more than a
+    // hundred steps of the small engine)
     s->stage_elems = std::max((size_t)P.K * ((size_t)P.n * (P.n - 1) / 2), (size_t)P.T * P.n);
-    if ((rc = gd_alloc(s, &s->stage, s->stage_elems))) {
-        for (void *p : s->allocs) (void)hipFree(p);
+    struct Part {
+        void **p;
+        size_t bytes;
+    };
+    const Part parts[] = {
+        {(void **)&P.X, (size_t)P.Tp * P.n_pad * 8}, {(void **)&P.XT, (size_t)P.n_pad * P.Tp * 8}, {(void **)&P.WS, np2 * P.KP * 8},
+        {(void **)&P.C, (size_t)P.K * P.T * 8}, {(void **)&P.CT, (size_t)P.Tp * P.KP * 8}, {(void **)&P.Cw, (size_t)P.KP * P.Tw * 8},
+        {(void **)&P.dual, (size_t)P.Tw * P.n * 8}, {(void **)&P.deg, (size_t)P.KP * P.n_pad * 8},
+        {(void **)&P.deg_new, (size_t)P.KP * P.n_pad * 8}, {(void **)&P.SC, (size_t)P.NG * P.KP * P.Tp * 8},
+        {(void **)&P.SCR, (size_t)P.KP * P.Tp * 8}, {(void **)&P.wtasks, tasks.size() * sizeof(int2)}, {(void **)&P.cnorm, 256 * 3 * 8},
+        {(void **)&P.GS, (size_t)P.TS * np2 * P.KP * 8}, {(void **)&P.MSL, (size_t)P.MS * P.KP * P.n_pad * 8},
+        {(void **)&P.M, (size_t)P.KP * P.n_pad * 8}, {(void **)&P.cpart, (size_t)P.Tw * 8},
+        {(void **)&P.wpart, (size_t)P.n * (P.n_pad / 64) * 3 * 8}, {(void **)&P.stat, GD_NORM_SLOTS * 8},
+        {(void **)&s->stage, s->stage_elems * 8}};
+    size_t total = 0;
+    for (const Part &q : parts) total += (std::max<size_t>(q.bytes, 8) + 255) / 256 * 256;
+    void *arena = nullptr;
+    if (hipMalloc(&arena, total) != hipSuccess) {
         delete s;
-        return rc;
+        return gl_set_error(ctx, GL_E_NOMEM, "hipMalloc(%zu) failed", total);
     }
+    s->allocs.push_back(arena);
+    {
+        char *at = (char *)arena;
+        for (const Part &q : parts) {
+            *q.p = at;
+            at += (std::max<size_t>(q.bytes, 8) + 255) / 256 * 256;
+        }
+    }
+    GL_HIP(ctx, hipMemsetAsync(arena, 0, total, ctx->stream));
     GL_TRY(gl_h2d(ctx, P.wtasks, tasks.data(), tasks.size() * sizeof(int2)));
     if (getenv("GRAPHLEARN_AMD_GD_PROBE"))
         (void)gd_alloc(s, &s->dbgbuf, (size_t)16 * P.nwtasks * P.TS);
