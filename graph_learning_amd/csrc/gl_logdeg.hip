@@ -444,6 +444,11 @@ __device__ __forceinline__ void node_body(const LogdegDev &P, const int64_t B) {
         double dnew, dq2 = 0, d2 = 0;
         if (INIT) {
             dnew = sw;  // :144  dvar = S w
+            if (B == 0 && lane == 0) {  // no relative change yet, no tolerance yet
+                P.dstat[0] = INFINITY;
+                P.dstat[1] = INFINITY;
+                P.dstat[2] = 0.0;
+            }
         } else {
             const double qb = pb_old + P.gamma * sp;  // :154
             const double dq = qb - yb_old;            // == -ybar + qbar (:159)
@@ -848,12 +853,14 @@ GL_API int gl_logdeg_create(gl_ctx *ctx, int64_t n_nodes, gl_logdeg **out) {
         size_t bytes;
     };
     const Part parts[] = {
-        {(void **)&D.w[0], tiled_bytes}, {(void **)&D.w[1], tiled_bytes}, {(void **)&zbuf, tiled_bytes},
-        {(void **)&D.dvar, (size_t)D.n_pad * 8}, {(void **)&D.dprev, (size_t)D.n_pad * 8},
+        // w[0], w[1], bnorm, dprev, ctr in this order: init() zeroes them with one memset
+        {(void **)&D.w[0], tiled_bytes}, {(void **)&D.w[1], tiled_bytes}, {(void **)&D.bnorm, (size_t)2 * D.nb * 4 * 8},
+        {(void **)&D.dprev, (size_t)D.n_pad * 8}, {(void **)&D.ctr, 8 * 8},
+        {(void **)&zbuf, tiled_bytes}, {(void **)&D.dvar, (size_t)D.n_pad * 8},
         {(void **)&D.ybar, (size_t)D.n_pad * 8}, {(void **)&D.pbar, (size_t)D.n_pad * 8},
         {(void **)&D.rowslab_p, (size_t)D.nb * D.n_pad * 8}, {(void **)&D.rowslab_w, (size_t)D.nb * D.n_pad * 8},
-        {(void **)&D.tnorm, (size_t)D.G * 2 * 8}, {(void **)&D.bnorm, (size_t)2 * D.nb * 4 * 8},
-        {(void **)&D.dstat, 8 * 8}, {(void **)&D.ctr, 8 * 8}, {(void **)&s->stage, (size_t)s->n_edges * 8},
+        {(void **)&D.tnorm, (size_t)D.G * 2 * 8},
+        {(void **)&D.dstat, 8 * 8}, {(void **)&s->stage, (size_t)s->n_edges * 8},
         {(void **)&s->col_ptr, ptr.size() * sizeof(int)}, {(void **)&s->seg_dest, dest.size() * sizeof(int)},
         {(void **)&D.colslab, (size_t)std::max(s->n_segments, 1) * 2 * GL_TB * 8}};
     size_t total = 0;
@@ -908,7 +915,7 @@ GL_API int gl_logdeg_set_distances(gl_logdeg *s, const double *z_condensed) {
     k_to_tiled<0><<<dim3((unsigned)s->dev.ntiles), dim3(256), 0, ctx->stream>>>(
         s->stage, const_cast<double *>(s->dev.z), s->n, s->dev.nb, 1.0);
     GL_HIP(ctx, hipGetLastError());
-    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((size_t)s->n_edges * 8 > GL_STAGE_BYTES) GL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pageable source still in use
     s->have_z = true;
     s->have_zsq = false;
     s->theta = 1.0;
@@ -979,30 +986,25 @@ GL_API int gl_logdeg_init(gl_logdeg *s, double alpha, double beta, double step_s
     D.c = 1 - D.gamma * 2 * beta;
     D.g2 = 2 * D.gamma;
     D.a4g = 4 * alpha * D.gamma;
-    const size_t tiled_bytes = (size_t)D.ntiles * GL_TILE_ELEMS * sizeof(double);
+    const size_t edge_bytes = (size_t)s->n_edges * 8;
     if (edge_init) {
-        GL_TRY(gl_h2d(ctx, s->stage, edge_init, (size_t)s->n_edges * 8));
+        GL_TRY(gl_h2d(ctx, s->stage, edge_init, edge_bytes));
         k_to_tiled<0><<<dim3((unsigned)D.ntiles), dim3(256), 0, ctx->stream>>>(s->stage, D.w[0], s->n, D.nb, 1.0);
         GL_HIP(ctx, hipGetLastError());
-    } else {
-        GL_HIP(ctx, hipMemsetAsync(D.w[0], 0, tiled_bytes, ctx->stream));
     }
-    GL_HIP(ctx, hipMemsetAsync(D.w[1], 0, tiled_bytes, ctx->stream));
-    GL_HIP(ctx, hipMemsetAsync(D.bnorm, 0, (size_t)2 * D.nb * 4 * 8, ctx->stream));
-    GL_HIP(ctx, hipMemsetAsync(D.dprev, 0, (size_t)D.n_pad * 8, ctx->stream));
-    GL_HIP(ctx, hipMemsetAsync(D.ctr, 0, 8 * 8, ctx->stream));
-    const double inf = std::numeric_limits<double>::infinity();
-    double *st = (double *)ctx->pinned;
-    st[0] = inf;  // rel_primal
-    st[1] = inf;  // rel_dual
-    st[2] = 0.0;  // tol
-    GL_HIP(ctx, hipMemcpyAsync(D.dstat, st, 3 * 8, hipMemcpyHostToDevice, ctx->stream));
+    // w[1], bnorm, dprev, ctr (and w[0] without a start) are adjacent in the session's allocation: one memset
+    {
+        char *from = (char *)(edge_init ? D.w[1] : D.w[0]);
+        GL_HIP(ctx, hipMemsetAsync(from, 0, (size_t)((char *)D.ctr + 8 * 8 - from), ctx->stream));
+    }
     s->it = 0;
     k_edge<true><<<dim3((unsigned)D.G), dim3(64), 0, ctx->stream>>>(D, D.dvar, D.pbar);
     GL_HIP(ctx, hipGetLastError());
-    k_node<true><<<dim3((unsigned)D.nb), dim3(NODE_WAVES * 64), 0, ctx->stream>>>(D);
+    k_node<true><<<dim3((unsigned)D.nb), dim3(NODE_WAVES * 64), 0, ctx->stream>>>(D);  // also dstat = {inf, inf, tol 0}
     GL_HIP(ctx, hipGetLastError());
-    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // stream-ordered from here on; only a start handed over in pageable memory too large for the staging
+    // area is still being read by the copy engine
+    if (edge_init && edge_bytes > GL_STAGE_BYTES) GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     s->inited = true;
     return GL_OK;
 }
