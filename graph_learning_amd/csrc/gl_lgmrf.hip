@@ -734,6 +734,100 @@ __global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, unsigned *err, lg_
 }
 
 // ------------------------------------------------------------------------------------------
+// The ADMM of small problems (n <= 64) in ONE WAVE: lane i keeps row i of the explicit inverse in
+// registers, the right-hand side lives one entry per lane and is broadcast entry by entry through the
+// scalar file (v_readlane), the norms are DPP reductions, the stopping rule (lgmrf.py:66-69) is evaluated
+// in place after every step -- no LDS, no barrier, no memory traffic inside the loop: ~0.5 us per step
+// against 1.7 us for the multi-workgroup forms at this size.  NP = n rounded up to 16 / 32 / 64 (zero
+// padding).  u_fast >= 0: rows of inv(I + rho M) straight from G (the formula of k_lg_build_winv).
+__device__ __forceinline__ double lg_bcast(double x, int j) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), j), hi = __builtin_amdgcn_readlane(__double2hiint(x), j);
+    return __hiloint2double(hi, lo);
+}
+
+template <int NP>
+__global__ __launch_bounds__(64) void k_lg_admm_wave(LgDev D, int max_iter, int64_t u_fast) {
+    const int n = (int)D.n, lane = threadIdx.x;
+    const bool rowon = lane < n;
+    double w[NP];
+    if (u_fast >= 0) {
+        const int u = (int)u_fast;
+        const double guu = D.G[(int64_t)u * n + u];
+        const double gi = rowon ? D.gcol[lane] : 0.0;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            double t = 0.0;
+            if (rowon && j < n) {
+                t = (lane == j) ? 1.0 : 0.0;
+                if (lane != u && j != u) t -= D.rho * (D.G[(int64_t)lane * n + j] - (gi * D.gcol[j]) / guu);
+            }
+            w[j] = t;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) w[j] = (rowon && j < n) ? D.W[(int64_t)lane * n + j] : 0.0;
+    }
+    double xo = 0, zo = 0, uo = 0, pi = 0, on = 0, v = 0;
+    if (rowon) {
+        xo = D.x[lane];
+        zo = D.z[lane];
+        uo = D.uu[lane];
+        pi = D.p[lane];
+        on = D.act[lane];
+        v = D.v[lane];
+    }
+    const bool active = on != 0.0;
+    int steps = 0;
+    bool stopped = false;
+    for (int it = 0; it < max_iter; ++it) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) acc += w[j] * lg_bcast(v, j);
+        const double xn = active ? acc : 0.0;
+        double zn = xn + uo;
+        zn = zn < 0 ? 0.0 : zn;
+        const double un = uo + (xn - zn);
+        double dx2 = 0, x2 = 0, xm = 0, dz2 = 0, z2 = 0, zm = 0;
+        if (active) {
+            dx2 = (xn - xo) * (xn - xo);
+            x2 = xo * xo;
+            xm = fabs(xo);
+            dz2 = (zn - zo) * (zn - zo);
+            z2 = zo * zo;
+            zm = fabs(zo);
+        }
+        xo = xn;
+        zo = active ? zn : 0.0;
+        uo = active ? un : 0.0;
+        v = active ? (zn - un) + D.rho * pi : 0.0;
+        steps = it + 1;
+        if (it > 0) {  // `if it > 0 and ...`; relative_error's plain-norm branch when prev ~ 0
+            dx2 = wsum(dx2);
+            x2 = wsum(x2);
+            xm = wmax(xm);
+            dz2 = wsum(dz2);
+            z2 = wsum(z2);
+            zm = wmax(zm);
+            const double rx = (xm <= 1e-8) ? sqrt(dx2) : sqrt(dx2) / sqrt(x2);
+            const double rz = (zm <= 1e-8) ? sqrt(dz2) : sqrt(dz2) / sqrt(z2);
+            if (rx < D.qp_tol && rz < D.qp_tol) {
+                stopped = true;
+                break;
+            }
+        }
+    }
+    if (rowon) {
+        D.x[lane] = xo;
+        D.z[lane] = zo;
+        D.uu[lane] = uo;
+    }
+    if (lane == 0) {
+        D.scal[1] = (double)steps;
+        D.scal[0] = stopped ? 1.0 : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // The same ADMM for small problems (n <= 64) in ONE launch of ONE workgroup: the whole explicit inverse
 // (<= 128 KiB) in LDS (transposed, so a wave's lanes read consecutive addresses), v double-buffered in
 // LDS, 8 threads per row, row sums combined by DPP, the
@@ -840,8 +934,258 @@ __global__ __launch_bounds__(1024) void k_lg_admm_one(LgDev D, int max_iter) {
 // The QP's ADMM loop: launches in chunks and polls the device-side stop flag in between, so a
 // QP that stops after ~30 steps does not pay for 100 launches.
 // Persistent form: rows per workgroup R = ceil(n / #CU) <= 8 and R * n * 8 bytes of LDS.
+// ------------------------------------------------------------------------------------------
+// The whole block-coordinate descent of a small problem (n <= 64, full mask: the "fast" path) in ONE launch
+// of ONE workgroup.  lgmrf.py:169-226: K', Theta, C = Theta^-1 and G = (Theta + rho I)^-1 live in LDS (row
+// stride n + 1), a cycle inverts Theta + rho I by Gauss-Jordan in place, and per node: the QP's set-up, its
+// ADMM in wave 0 (rows of inv(I + rho M) in registers, right-hand side broadcast through the scalar file,
+// as k_lg_admm_wave), beta, C beta, the rank-one updates of Theta and C and the rank-two Woodbury
+// correction of G -- the same element-wise formulas as the kernels of the launch path (k_lg_qp_setup,
+// k_lg_build_winv, k_lg_node_update, k_lg_update_c, k_lg_wood_scal, k_lg_update_g), separated by workgroup
+// barriers instead of eleven launches.  The cycle rule (:221-224) is evaluated in place.
+// At n = 32 a node update costs ~50 us here against 96 us with eleven launches around a one-wave ADMM.
+template <int NP>
+__global__ __launch_bounds__(256) void k_lg_fit_small(LgDev D, int max_cycle, double prob_tol, int max_qp_iter, double *out) {
+    extern __shared__ double sm[];
+    __shared__ double s_red[3][4];
+    __shared__ double s_sc[8];
+    const int n = (int)D.n, S = n + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *sKT = sm, *sTh = sKT + n * S, *sC = sTh + n * S, *sG = sC + n * S;
+    double *s_beta = sG + n * S, *s_t = s_beta + n, *s_a = s_t + n, *s_h = s_a + n, *s_g = s_h + n;
+    double *s_prow = s_g + n, *s_pcol = s_prow + n;
+    const bool col = lane < n;
+    const double rho = D.rho;
+
+    for (int i = wave; i < n; i += 4)
+        if (col) {
+            sKT[lane * S + i] = D.K[(int64_t)i * n + lane];  // transposed: column u of K is row u here
+            sTh[i * S + lane] = D.Th[(int64_t)i * n + lane];
+            sC[i * S + lane] = D.C[(int64_t)i * n + lane];
+        }
+    __syncthreads();
+
+    int converged = -1, cycles = 0;
+    for (int cycle = 0; cycle < max_cycle; ++cycle) {
+        // l_pre (:173) to memory (only the cycle rule reads it back); G0 = Theta + rho I
+        for (int i = wave; i < n; i += 4)
+            if (col) {
+                D.ThPrev[(int64_t)i * n + lane] = sTh[i * S + lane];
+                sG[i * S + lane] = sTh[i * S + lane] + (i == lane ? rho : 0.0);
+            }
+        __syncthreads();
+        for (int k = 0; k < n; ++k) {  // Gauss-Jordan, no pivoting (SPD), as k_gj_pivot / k_gj_eliminate
+            if (tid < n) {
+                const double piv = sG[k * S + k];
+                s_prow[tid] = (tid == k) ? 1.0 / piv : sG[k * S + tid] / piv;
+                s_pcol[tid] = sG[tid * S + k];
+            }
+            __syncthreads();
+            for (int i = wave; i < n; i += 4)
+                if (col) {
+                    if (i == k) {
+                        sG[i * S + lane] = s_prow[lane];
+                    } else {
+                        const double cur = (lane == k) ? 0.0 : sG[i * S + lane];
+                        sG[i * S + lane] = cur - s_pcol[i] * s_prow[lane];
+                    }
+                }
+            __syncthreads();
+        }
+
+        for (int u = 0; u < n; ++u) {
+            // ---- the QP of node u in wave 0 (k_lg_qp_setup + k_lg_build_winv + the ADMM of k_lg_admm_wave)
+            if (wave == 0) {
+                const double kuu = sKT[u * S + u], guu = sG[u * S + u];
+                const bool active = col && lane != u;
+                const double pi = active ? sKT[u * S + lane] / kuu : 0.0;
+                const double gi = col ? sG[lane * S + u] : 0.0;
+                double w[NP];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    double t = 0.0;
+                    if (col && j < n) {
+                        t = (lane == j) ? 1.0 : 0.0;
+                        if (lane != u && j != u) t -= rho * (sG[lane * S + j] - (gi * sG[j * S + u]) / guu);
+                    }
+                    w[j] = t;
+                }
+                double xo = 0, zo = 0, uo = 0;
+                double v = active ? (0.0 - 0.0) + rho * pi : 0.0;
+                for (int it = 0; it < max_qp_iter; ++it) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) acc += w[j] * lg_bcast(v, j);
+                    const double xn = active ? acc : 0.0;
+                    double zn = xn + uo;
+                    zn = zn < 0 ? 0.0 : zn;
+                    const double un = uo + (xn - zn);
+                    double dx2 = 0, x2 = 0, xm = 0, dz2 = 0, z2 = 0, zm = 0;
+                    if (active) {
+                        dx2 = (xn - xo) * (xn - xo);
+                        x2 = xo * xo;
+                        xm = fabs(xo);
+                        dz2 = (zn - zo) * (zn - zo);
+                        z2 = zo * zo;
+                        zm = fabs(zo);
+                    }
+                    xo = xn;
+                    zo = active ? zn : 0.0;
+                    uo = active ? un : 0.0;
+                    v = active ? (zn - un) + rho * pi : 0.0;
+                    if (it > 0) {
+                        dx2 = wsum(dx2);
+                        x2 = wsum(x2);
+                        xm = wmax(xm);
+                        dz2 = wsum(dz2);
+                        z2 = wsum(z2);
+                        zm = wmax(zm);
+                        const double rx = (xm <= 1e-8) ? sqrt(dx2) : sqrt(dx2) / sqrt(x2);
+                        const double rz = (zm <= 1e-8) ? sqrt(dz2) : sqrt(dz2) / sqrt(z2);
+                        if (rx < D.qp_tol && rz < D.qp_tol) break;
+                    }
+                }
+                if (col) {
+                    s_beta[lane] = active ? -zo : 0.0;  // k_lg_beta
+                    s_h[lane] = sC[lane * S + u];       // k_lg_snap_col: the old column of C
+                }
+            }
+            __syncthreads();
+            // ---- t = C beta: one wave per row, the order of k_matvec
+            for (int i = wave; i < n; i += 4) {
+                double acc = col ? sC[i * S + lane] * s_beta[lane] : 0.0;
+                acc = wsum(acc);
+                if (lane == 0) s_t[i] = acc;
+            }
+            __syncthreads();
+            // ---- k_lg_node_update in wave 0: M beta, the new row / column of Theta, the change vector a
+            if (wave == 0) {
+                const double cuu = sC[u * S + u], kuu = sKT[u * S + u];
+                const double ciu = col ? s_h[lane] : 0.0;
+                const double bi = col ? s_beta[lane] : 0.0;
+                const double cb = wsum((col && lane != u) ? ciu * bi : 0.0);
+                double ti = 0.0;
+                if (col && lane != u) ti = s_t[lane] - ciu * cb / cuu;
+                const double quad = wsum(bi * ti);
+                const double th_uu_old = sTh[u * S + u];
+                const double th_uu_new = 1.0 / kuu + quad;
+                if (col) {
+                    s_t[lane] = ti;
+                    if (lane == u) {
+                        s_a[lane] = 0.5 * (th_uu_new - th_uu_old);
+                    } else {
+                        s_a[lane] = bi - sTh[lane * S + u];
+                        sTh[lane * S + u] = bi;
+                        sTh[u * S + lane] = bi;
+                    }
+                }
+                if (lane == 0) {
+                    sTh[u * S + u] = th_uu_new;
+                    s_sc[0] = kuu;
+                    s_sc[1] = cuu;
+                }
+            }
+            __syncthreads();
+            // ---- k_lg_update_c (element-wise) and h = G a (one wave per row)
+            {
+                const double kuu = s_sc[0], cuu = s_sc[1];
+                for (int i = wave; i < n; i += 4)
+                    if (col) {
+                        const int j = lane;
+                        const double gi = s_t[i] * kuu, gj = s_t[j] * kuu;
+                        double o;
+                        if (i == u && j == u)
+                            o = kuu;
+                        else if (i == u)
+                            o = -gj;
+                        else if (j == u)
+                            o = -gi;
+                        else {
+                            const double m = sC[i * S + j] - (s_h[i] * s_h[j]) / cuu;
+                            o = m + (gi * gj) / kuu;
+                        }
+                        sC[i * S + j] = o;
+                    }
+            }
+            __syncthreads();  // every reader of the snapshot h is done: h becomes G a (one wave per row)
+            for (int i = wave; i < n; i += 4) {
+                double acc = col ? sG[i * S + lane] * s_a[lane] : 0.0;
+                acc = wsum(acc);
+                if (lane == 0) s_h[i] = acc;
+            }
+            __syncthreads();
+            // ---- k_lg_wood_scal in wave 0, then k_lg_update_g (element-wise)
+            if (wave == 0) {
+                const double gci = col ? sG[lane * S + u] : 0.0;  // g = G e_u
+                const double ai = col ? s_a[lane] : 0.0, hi = col ? s_h[lane] : 0.0;
+                const double ag = wsum(ai * gci), ah = wsum(ai * hi);
+                if (col) s_g[lane] = gci;
+                if (lane == 0) {
+                    const double s11 = 1.0 + ag, s12 = ah, s21 = sG[u * S + u], s22 = 1.0 + s_h[u];
+                    const double det = s11 * s22 - s12 * s21;
+                    s_sc[4] = s22 / det;  // inverse of S
+                    s_sc[5] = -s12 / det;
+                    s_sc[6] = -s21 / det;
+                    s_sc[7] = s11 / det;
+                }
+            }
+            __syncthreads();
+            {
+                const double i11 = s_sc[4], i12 = s_sc[5], i21 = s_sc[6], i22 = s_sc[7];
+                for (int i = wave; i < n; i += 4)
+                    if (col) {
+                        const int j = lane;
+                        const double gi = s_g[i], hi = s_h[i], gj = s_g[j], hj = s_h[j];
+                        const double corr = gi * (i11 * hj + i12 * gj) + hi * (i21 * hj + i22 * gj);
+                        sG[i * S + j] -= corr;
+                    }
+            }
+            __syncthreads();
+        }
+        cycles = cycle + 1;
+        if (cycle > 4) {  // :221  relative_error(l_pre, Theta) (evaluation.py:21-25)
+            double d2 = 0, a2 = 0, am = 0;
+            for (int i = wave; i < n; i += 4)
+                if (col) {
+                    const double a = D.ThPrev[(int64_t)i * n + lane], b = sTh[i * S + lane];
+                    d2 += (b - a) * (b - a);
+                    a2 += a * a;
+                    am = fmax(am, fabs(a));
+                }
+            d2 = wsum(d2);
+            a2 = wsum(a2);
+            am = wmax(am);
+            if (lane == 0) {
+                s_red[0][wave] = d2;
+                s_red[1][wave] = a2;
+                s_red[2][wave] = am;
+            }
+            __syncthreads();
+            d2 = ((s_red[0][0] + s_red[0][1]) + s_red[0][2]) + s_red[0][3];
+            a2 = ((s_red[1][0] + s_red[1][1]) + s_red[1][2]) + s_red[1][3];
+            am = fmax(fmax(s_red[2][0], s_red[2][1]), fmax(s_red[2][2], s_red[2][3]));
+            const double rel = (am <= 1e-8) ? sqrt(d2) : sqrt(d2) / sqrt(a2);
+            __syncthreads();
+            if (rel < prob_tol) {
+                converged = cycle;
+                break;
+            }
+        }
+    }
+    for (int i = wave; i < n; i += 4)
+        if (col) {
+            D.Th[(int64_t)i * n + lane] = sTh[i * S + lane];
+            D.C[(int64_t)i * n + lane] = sC[i * S + lane];
+        }
+    if (tid == 0) {
+        out[0] = (double)converged;
+        out[1] = (double)cycles;
+    }
+}
+
 struct AdmmRes {
-    bool one = false;  // n <= 128: single-workgroup form (k_lg_admm_one)
+    bool one = false;  // n <= 64: single-workgroup form (k_lg_admm_one)
+    bool wave = false;  // n <= 64: single-wave form (k_lg_admm_wave), the default there
     bool on = false;
     int R = 0, nwg = 0;
     size_t lds = 0;
@@ -852,19 +1196,22 @@ struct AdmmRes {
     unsigned next_tag = 0;  // first tag of the next launch (a launch uses max_iter + 1 consecutive ones)
 };
 
-// Which form the QP's ADMM loop takes.  GRAPHLEARN_AMD_LGMRF_ADMM = launch | one | resident | tagged forces
+// Which form the QP's ADMM loop takes.  GRAPHLEARN_AMD_LGMRF_ADMM = launch | wave | one | resident | tagged forces
 // one (where it applies).  Measured per node-update, one cycle of the config-3 input (every QP runs its
 // 100 steps), launch / grid-barrier / tagged:  n = 128: 0.66 / 0.61 / 0.38 ms,  256: 0.67 / 0.72 / 0.39,
 // 500: 0.90 / 0.81 / 0.46,  1024: 0.96 / 0.89 / 0.56,  2048: 1.62 / 1.20 / 0.80;  single workgroup
-// against tagged at n = 32: 0.26 / 0.20, n = 64: 0.48 / 0.30.
-constexpr int ADMM_ONE_AUTO = 16;  // below this the single-workgroup form is the default
+// against tagged at n = 32: 0.26 / 0.20, n = 64: 0.48 / 0.30.  To n = 64 the default is the single-wave form.
 
 int admm_res_plan(gl_ctx *ctx, int64_t n, AdmmRes &A) {
-    A.on = A.one = A.tagged = false;
+    A.on = A.one = A.wave = A.tagged = false;
     const char *force = getenv("GRAPHLEARN_AMD_LGMRF_ADMM");
     auto is = [&](const char *v) { return force && !strcmp(force, v); };
     if (is("launch")) return GL_OK;
-    if (n <= ADMM_ONE_MAXN && (is("one") || (!force && n <= ADMM_ONE_AUTO))) {
+    if (n <= ADMM_ONE_MAXN && (is("wave") || !force)) {  // one wave, rows in registers
+        A.wave = true;
+        return GL_OK;
+    }
+    if (n <= ADMM_ONE_MAXN && is("one")) {
         A.lds = ((size_t)n * n + 2 * n + 6 * 16) * 8;
         GL_HIP(ctx, hipFuncSetAttribute((const void *)k_lg_admm_one, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A.lds));
         A.one = true;
@@ -885,6 +1232,17 @@ int admm_res_plan(gl_ctx *ctx, int64_t n, AdmmRes &A) {
     GL_HIP(ctx, hipFuncSetAttribute(A.tagged ? (const void *)k_lg_admm_tag : (const void *)k_lg_admm_res,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     A.on = true;
+    return GL_OK;
+}
+
+int run_admm_wave(gl_ctx *ctx, const LgDev &D, int max_iter, int64_t u_fast = -1) {
+    if (D.n <= 16)
+        k_lg_admm_wave<16><<<1, 64, 0, ctx->stream>>>(D, max_iter, u_fast);
+    else if (D.n <= 32)
+        k_lg_admm_wave<32><<<1, 64, 0, ctx->stream>>>(D, max_iter, u_fast);
+    else
+        k_lg_admm_wave<64><<<1, 64, 0, ctx->stream>>>(D, max_iter, u_fast);
+    GL_HIP(ctx, hipGetLastError());
     return GL_OK;
 }
 
@@ -1195,8 +1553,9 @@ GL_API int gl_nonneg_qp_solve(gl_ctx *ctx, const double *mat, const double *vec,
     GL_TRY(gl_h2d(ctx, V, hv.data(), hv.size() * 8));
     GL_HIP(ctx, hipMemsetAsync(D.scal, 0, 16 * 8, ctx->stream));
     GL_TRY(invert_spd_inplace(ctx, D.W, m, pivrow));
-    GL_TRY(ares.one ? run_admm_one(ctx, D, ares, max_iter)
-                    : (ares.on ? run_admm_res(ctx, D, ares, max_iter) : run_admm(ctx, D, max_iter)));
+    GL_TRY(ares.wave ? run_admm_wave(ctx, D, max_iter)
+                     : (ares.one ? run_admm_one(ctx, D, ares, max_iter)
+                                 : (ares.on ? run_admm_res(ctx, D, ares, max_iter) : run_admm(ctx, D, max_iter))));
     double sc[9];
     GL_HIP(ctx, hipMemcpyAsync(sc, D.scal, 9 * 8, hipMemcpyDeviceToHost, ctx->stream));
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1300,6 +1659,32 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
     const unsigned mvb = (unsigned)((n + 3) / 4);
     const int max_qp_iter = 100;  // default of nonnegative_qp_solver (lgmrf.py:24)
     int converged = -1, cycles = 0;
+    // small problems on the fast path: the whole descent in one launch of one workgroup (k_lg_fit_small).
+    // A forced ADMM form (GRAPHLEARN_AMD_LGMRF_ADMM) or GRAPHLEARN_AMD_LGMRF_FUSED=0 keeps the launch path.
+    {
+        const char *fz = getenv("GRAPHLEARN_AMD_LGMRF_FUSED");
+        if (fast && n <= 64 && !getenv("GRAPHLEARN_AMD_LGMRF_ADMM") && !(fz && !strcmp(fz, "0"))) {
+            const size_t lds = ((size_t)4 * n * (n + 1) + 9 * n) * 8;
+            const void *fn = n <= 16 ? (const void *)k_lg_fit_small<16> : (n <= 32 ? (const void *)k_lg_fit_small<32> : (const void *)k_lg_fit_small<64>);
+            GL_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            double *res = D.scal + 12;
+            if (n <= 16)
+                k_lg_fit_small<16><<<1, 256, lds, ctx->stream>>>(D, max_cycle, prob_tol, max_qp_iter, res);
+            else if (n <= 32)
+                k_lg_fit_small<32><<<1, 256, lds, ctx->stream>>>(D, max_cycle, prob_tol, max_qp_iter, res);
+            else
+                k_lg_fit_small<64><<<1, 256, lds, ctx->stream>>>(D, max_cycle, prob_tol, max_qp_iter, res);
+            GL_HIP(ctx, hipGetLastError());
+            double r2[2];
+            GL_TRY(gl_d2h(ctx, laplacian_out, D.Th, nn));
+            GL_TRY(gl_d2h(ctx, inv_laplacian_out, D.C, nn));
+            GL_TRY(gl_d2h(ctx, r2, res, 2 * 8));
+            GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (converged_out) *converged_out = (int)r2[0];
+            if (cycles_out) *cycles_out = (int)r2[1];
+            return GL_OK;
+        }
+    }
     for (int cycle = 0; cycle < max_cycle; ++cycle) {
         GL_HIP(ctx, hipMemcpyAsync(D.ThPrev, D.Th, nn, hipMemcpyDeviceToDevice, ctx->stream));  // l_pre (:173)
         if (ares.on) GL_HIP(ctx, hipMemcpyAsync(bCprev.p, D.C, nn, hipMemcpyDeviceToDevice, ctx->stream));  // to redo the cycle
@@ -1309,7 +1694,7 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
         }
         for (int64_t u = 0; u < n; ++u) {
             k_lg_qp_setup<<<1, VT, 0, ctx->stream>>>(D, u);
-            const bool fused_winv = fast && ares.on && ares.tagged;  // the ADMM kernel forms its rows of the inverse itself
+            const bool fused_winv = fast && (ares.wave || (ares.on && ares.tagged));  // the ADMM kernel forms its rows of the inverse itself
             if (fused_winv) {
             } else if (fast) {
                 k_lg_build_winv<<<g2, 256, 0, ctx->stream>>>(D, u);
@@ -1317,8 +1702,10 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
                 k_lg_build_w<<<g2, 256, 0, ctx->stream>>>(D, u);
                 GL_TRY(invert_spd_inplace(ctx, D.W, n, pivrow));
             }
-            GL_TRY(ares.one ? run_admm_one(ctx, D, ares, max_qp_iter)
-                            : (ares.on ? run_admm_res(ctx, D, ares, max_qp_iter, fused_winv ? u : -1) : run_admm(ctx, D, max_qp_iter)));
+            GL_TRY(ares.wave ? run_admm_wave(ctx, D, max_qp_iter, fused_winv ? u : -1)
+                             : (ares.one ? run_admm_one(ctx, D, ares, max_qp_iter)
+                                         : (ares.on ? run_admm_res(ctx, D, ares, max_qp_iter, fused_winv ? u : -1)
+                                                    : run_admm(ctx, D, max_qp_iter))));
             k_lg_beta<<<1, VT, 0, ctx->stream>>>(D, u);
             k_matvec<<<mvb, 256, 0, ctx->stream>>>(D.C, D.beta, D.t, n, D.scal, 0);
             k_lg_snap_col<<<1, VT, 0, ctx->stream>>>(D, u);

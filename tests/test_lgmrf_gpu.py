@@ -16,12 +16,13 @@ from oracle import lgmrf as olg
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["launch", "one", "resident", "tagged", "auto"])
+@pytest.fixture(autouse=True, params=["launch", "wave", "one", "resident", "tagged", "auto"])
 def admm_form(request, monkeypatch):
-    """Every test runs with every form of the QP's ADMM loop: one launch per step, the single-workgroup
-    kernel (n <= 64, whole inverse in LDS), the persistent multi-workgroup kernels (matrix rows resident
-    in LDS; steps separated by grid barriers, or the right-hand side handed over as self-validating
-    tagged records) and the automatic choice (single workgroup to n = 16, tagged above)."""
+    """Every test runs with every form of the QP's ADMM loop: one launch per step, the single-wave kernel
+    (n <= 64, rows of the inverse in registers), the single-workgroup kernel (n <= 64, whole inverse in
+    LDS), the persistent multi-workgroup kernels (matrix rows resident in LDS; steps separated by grid
+    barriers, or the right-hand side handed over as self-validating tagged records) and the automatic
+    choice (single wave to n = 64, tagged above)."""
     if request.param == "auto":
         monkeypatch.delenv("GRAPHLEARN_AMD_LGMRF_ADMM", raising=False)
     else:

@@ -67,7 +67,7 @@ while time.time() < t_end:
         n = int(rng.choice([3, 6, 12, 17, 33, 48]))
         x = rng.standard_normal((int(rng.integers(2, 6)) * n, n)) @ (np.eye(n) + 0.3 * rng.standard_normal((n, n)))
         cov = x.T @ x / x.shape[0]
-        form = rng.choice(["auto", "launch", "one", "resident", "tagged"])
+        form = rng.choice(["auto", "launch", "wave", "one", "resident", "tagged"])
         if form == "auto":
             os.environ.pop("GRAPHLEARN_AMD_LGMRF_ADMM", None)
         else:
@@ -88,7 +88,7 @@ while time.time() < t_end:
         n = int(rng.choice([2, 5, 16, 40, 64, 65, 130, 300]))
         a = rng.standard_normal((n, n + 3))
         q, p = a @ a.T / n + rng.uniform(0.01, 1.0) * np.eye(n), rng.standard_normal(n)
-        form = rng.choice(["auto", "launch", "one", "resident", "tagged"])
+        form = rng.choice(["auto", "launch", "wave", "one", "resident", "tagged"])
         if form == "auto":
             os.environ.pop("GRAPHLEARN_AMD_LGMRF_ADMM", None)
         else:
