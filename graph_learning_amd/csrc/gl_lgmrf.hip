@@ -726,6 +726,10 @@ __global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, unsigned *err, lg_
         D.x[i] = xo;
         D.z[i] = zo;
         D.uu[i] = uo;
+        if (u_fast >= 0) {  // fast path of the fit: k_lg_beta and k_lg_snap_col ride along
+            D.beta[i] = (on != 0.0) ? -zo : 0.0;
+            D.h[i] = D.C[i * n + u_fast];
+        }
     }
     if (blockIdx.x == 0 && tid == 0) {
         D.scal[1] = (double)steps;
@@ -820,6 +824,10 @@ __global__ __launch_bounds__(64) void k_lg_admm_wave(LgDev D, int max_iter, int6
         D.x[lane] = xo;
         D.z[lane] = zo;
         D.uu[lane] = uo;
+        if (u_fast >= 0) {  // fast path of the fit: k_lg_beta and k_lg_snap_col ride along
+            D.beta[lane] = active ? -zo : 0.0;
+            D.h[lane] = D.C[(int64_t)lane * n + u_fast];
+        }
     }
     if (lane == 0) {
         D.scal[1] = (double)steps;
@@ -1706,9 +1714,9 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
                              : (ares.one ? run_admm_one(ctx, D, ares, max_qp_iter)
                                          : (ares.on ? run_admm_res(ctx, D, ares, max_qp_iter, fused_winv ? u : -1)
                                                     : run_admm(ctx, D, max_qp_iter))));
-            k_lg_beta<<<1, VT, 0, ctx->stream>>>(D, u);
+            if (!fused_winv) k_lg_beta<<<1, VT, 0, ctx->stream>>>(D, u);  // else written by the ADMM kernel, with the snapshot
             k_matvec<<<mvb, 256, 0, ctx->stream>>>(D.C, D.beta, D.t, n, D.scal, 0);
-            k_lg_snap_col<<<1, VT, 0, ctx->stream>>>(D, u);
+            if (!fused_winv) k_lg_snap_col<<<1, VT, 0, ctx->stream>>>(D, u);
             k_lg_node_update<<<1, VT, 0, ctx->stream>>>(D, u);
             k_lg_update_c<<<g2, 256, 0, ctx->stream>>>(D, u);
             if (fast) {
