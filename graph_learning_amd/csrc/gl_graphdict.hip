@@ -237,10 +237,10 @@ __global__ void k_gd_logc_reset(GdDev P) {
 
 // sum of the strip-group partials of k_gd_grad_c, fixed order: 4 interleaved partial sums per
 // element (threadIdx.y), then ((p0 + p1) + p2) + p3
-__global__ __launch_bounds__(256) void k_gd_sc_reduce(GdDev P) {
+__device__ __forceinline__ void gd_sc_reduce_body(const GdDev &P, const int bx) {
     if (P.stat[5] != 0.0) return;
     __shared__ double s_p[4][64];
-    const int64_t q = (int64_t)blockIdx.x * 64 + threadIdx.x;  // (k, t)
+    const int64_t q = (int64_t)bx * 64 + threadIdx.x;  // (k, t)
     const int gy = threadIdx.y;
     double v = 0.0;
     if (q < (int64_t)P.KP * P.Tp) {
@@ -256,9 +256,9 @@ __global__ __launch_bounds__(256) void k_gd_sc_reduce(GdDev P) {
 // ------------------------------------------------------------------------------------------
 // coefficient update (base_model.py:373-401), one wave per window
 template <int KP>
-__global__ __launch_bounds__(64) void k_gd_coef_update(GdDev P) {
+__device__ __forceinline__ void gd_coef_update_body(const GdDev &P, const int bx) {
     if (P.stat[5] != 0.0) return;
-    const int lane = threadIdx.x, tw = blockIdx.x;
+    const int lane = threadIdx.x, tw = bx;
     // adjoint term  W @ (S' dual')  ==  <S W_k, dual_tw>   (log_model.py:33-34)
     double dt[KP];
 #pragma unroll
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64) void k_gd_coef_update(GdDev P) {
 }
 
 // all-zero guard (:406-408); one workgroup
-__global__ __launch_bounds__(256) void k_gd_coef_finish(GdDev P) {
+__device__ __forceinline__ void gd_coef_finish_body(const GdDev &P) {
     if (P.stat[5] != 0.0) return;
     __shared__ double s_a[256];
     const int tid = threadIdx.x;
@@ -333,10 +333,10 @@ __global__ __launch_bounds__(64) void k_gd_m(GdDev P, int tchunk) {
         }
     for (int k = 0; k < P.K; ++k) P.MSL[((int64_t)ms * P.KP + k) * P.n_pad + i] = i < P.n ? acc[k] : 0.0;
 }
-__global__ __launch_bounds__(256) void k_gd_m_reduce(GdDev P) {
+__device__ __forceinline__ void gd_m_reduce_body(const GdDev &P, const int bx) {
     if (P.stat[5] != 0.0) return;
     __shared__ double s_p[4][64];
-    const int64_t q = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t q = (int64_t)bx * 64 + threadIdx.x;
     const int gy = threadIdx.y;
     double v = 0.0;
     if (q < (int64_t)P.KP * P.n_pad) {
@@ -352,10 +352,9 @@ __global__ __launch_bounds__(256) void k_gd_m_reduce(GdDev P) {
 // ------------------------------------------------------------------------------------------
 // weight update (base_model.py:444-461): one wave per (row i, column block); in place
 template <int KP>
-__global__ __launch_bounds__(64) void k_gd_weight_update(GdDev P) {
+__device__ __forceinline__ void gd_weight_update_body(const GdDev &P, const int jb, const int i, const int nbj) {
     if (P.stat[5] != 0.0) return;
-    const int lane = threadIdx.x, jb = blockIdx.x, i = blockIdx.y;
-    const int nbj = gridDim.x;
+    const int lane = threadIdx.x;
     const int j = jb * 64 + lane;
     double num = 0, den = 0, wmax = 0;
     if (jb * 64 + 63 > i && j > i && j < P.n) {
@@ -408,12 +407,13 @@ __global__ __launch_bounds__(64) void k_gd_weight_update(GdDev P) {
     }
 }
 
-__global__ __launch_bounds__(1024) void k_gd_weight_finish(GdDev P, int64_t nparts) {
+template <int NT>
+__device__ __forceinline__ void gd_weight_finish_body(const GdDev &P, const int64_t nparts) {
     if (P.stat[5] != 0.0) return;
-    __shared__ double s_a[1024], s_b[1024], s_c[1024];
+    __shared__ double s_a[NT], s_b[NT], s_c[NT];
     const int tid = threadIdx.x;
     double num = 0, den = 0, mx = 0;
-    for (int64_t q = tid; q < nparts; q += 1024) {
+    for (int64_t q = tid; q < nparts; q += NT) {
         num += P.wpart[3 * q];
         den += P.wpart[3 * q + 1];
         mx = fmax(mx, P.wpart[3 * q + 2]);
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(1024) void k_gd_weight_finish(GdDev P, int64_t npar
     s_b[tid] = den;
     s_c[tid] = mx;
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
+    for (int o = NT / 2; o > 0; o >>= 1) {
         if (tid < o) {
             s_a[tid] += s_a[tid + o];
             s_b[tid] += s_b[tid + o];
@@ -434,9 +434,9 @@ __global__ __launch_bounds__(1024) void k_gd_weight_finish(GdDev P, int64_t npar
 }
 
 // degrees S W_k' of the weights in WS: one wave per node
-__global__ __launch_bounds__(64) void k_gd_degree(GdDev P, double *__restrict__ out, int chk_done) {
+__device__ __forceinline__ void gd_degree_body(const GdDev &P, double *__restrict__ out, const int chk_done, const int v, const int lane) {
     if (chk_done && P.stat[5] != 0.0) return;
-    const int lane = threadIdx.x, v = blockIdx.x;
+    if (v >= P.n_pad) return;  // a wave past the last node (four nodes per block in k_gd_finish3)
     double acc[GD_MAXK];
     for (int k = 0; k < P.K; ++k) acc[k] = 0.0;
     if (v < P.n)
@@ -449,6 +449,47 @@ __global__ __launch_bounds__(64) void k_gd_degree(GdDev P, double *__restrict__ 
         const double s = gd_wave_sum(acc[k]);
         if (lane == 0) out[(int64_t)k * P.n_pad + v] = s;
     }
+}
+
+
+// ---- launch wrappers.  The pieces of a step that do not depend on each other share a launch (the step is
+// launch-bound below ~1e8 pair-sample products: 13 dependent kernels cost 64 us whatever the size):
+// the two partial-sum folds; the coefficient and weight updates; the two finishers and the new degrees.
+__global__ __launch_bounds__(256) void k_gd_sc_reduce(GdDev P) { gd_sc_reduce_body(P, (int)blockIdx.x); }
+__global__ __launch_bounds__(256) void k_gd_reduce2(GdDev P, int nsc) {  // blocks [0, nsc): SC, then M
+    if ((int)blockIdx.x < nsc)
+        gd_sc_reduce_body(P, (int)blockIdx.x);
+    else
+        gd_m_reduce_body(P, (int)blockIdx.x - nsc);
+}
+template <int KP>
+__global__ __launch_bounds__(64) void k_gd_coef_update(GdDev P) {
+    gd_coef_update_body<KP>(P, (int)blockIdx.x);
+}
+template <int KP>
+__global__ __launch_bounds__(64) void k_gd_update2(GdDev P, int nbj) {  // blocks [0, Tw): windows, then (column block, row)
+    const int b = (int)blockIdx.x;
+    if (b < P.Tw) {
+        gd_coef_update_body<KP>(P, b);
+    } else {
+        const int r = b - P.Tw;
+        gd_weight_update_body<KP>(P, r % nbj, r / nbj, nbj);
+    }
+}
+__global__ __launch_bounds__(256) void k_gd_coef_finish(GdDev P) { gd_coef_finish_body(P); }
+__global__ __launch_bounds__(64) void k_gd_degree(GdDev P, double *__restrict__ out, int chk_done) {
+    gd_degree_body(P, out, chk_done, (int)blockIdx.x, (int)threadIdx.x);
+}
+// block 0: all-zero guard of the coefficients; block 1: relative change of the weights; then four nodes'
+// degrees per block
+__global__ __launch_bounds__(256) void k_gd_finish3(GdDev P, int64_t nparts, double *__restrict__ deg_out) {
+    const int b = (int)blockIdx.x;
+    if (b == 0)
+        gd_coef_finish_body(P);
+    else if (b == 1)
+        gd_weight_finish_body<256>(P, nparts);
+    else
+        gd_degree_body(P, deg_out, 1, (b - 2) * 4 + ((int)threadIdx.x >> 6), (int)threadIdx.x & 63);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -663,20 +704,18 @@ int gd_step(gl_graphdict *s, int fit_mode = 0) {
     if (P.log_c > 0) k_gd_logc_reset<<<dim3((unsigned)((P.Tw + 255) / 256)), 256, 0, st>>>(P);
     GL_TRY(gd_launch_grad_c(s));
     GL_TRY(gd_launch_grad_w(s));
-    k_gd_sc_reduce<<<dim3((unsigned)(((int64_t)P.KP * P.Tp + 63) / 64)), dim3(64, 4), 0, st>>>(P);
-    gd_launch_coef_update(P, st);
-    k_gd_coef_finish<<<1, 256, 0, st>>>(P);
     const int mchunk = (P.T + P.MS - 1) / P.MS;
     k_gd_m<<<dim3((unsigned)(P.n_pad / 64), (unsigned)P.MS), 64, 0, st>>>(P, mchunk);
-    k_gd_m_reduce<<<dim3((unsigned)(((int64_t)P.KP * P.n_pad + 63) / 64)), dim3(64, 4), 0, st>>>(P);
+    const int nsc = (int)(((int64_t)P.KP * P.Tp + 63) / 64), nmr = (int)(((int64_t)P.KP * P.n_pad + 63) / 64);
+    k_gd_reduce2<<<dim3((unsigned)(nsc + nmr)), dim3(64, 4), 0, st>>>(P, nsc);
     const int nbj = P.n_pad / 64;
+    const dim3 gu((unsigned)(P.Tw + nbj * P.n));
     switch (P.KP) {
-        case 4: k_gd_weight_update<4><<<dim3((unsigned)nbj, (unsigned)P.n), 64, 0, st>>>(P); break;
-        case 8: k_gd_weight_update<8><<<dim3((unsigned)nbj, (unsigned)P.n), 64, 0, st>>>(P); break;
-        default: k_gd_weight_update<16><<<dim3((unsigned)nbj, (unsigned)P.n), 64, 0, st>>>(P); break;
+        case 4: k_gd_update2<4><<<gu, 64, 0, st>>>(P, nbj); break;
+        case 8: k_gd_update2<8><<<gu, 64, 0, st>>>(P, nbj); break;
+        default: k_gd_update2<16><<<gu, 64, 0, st>>>(P, nbj); break;
     }
-    k_gd_weight_finish<<<1, 1024, 0, st>>>(P, (int64_t)P.n * nbj);
-    GL_TRY(gd_degrees(s, P.deg_new, 1));
+    k_gd_finish3<<<dim3((unsigned)(2 + (P.n + 3) / 4)), 256, 0, st>>>(P, (int64_t)P.n * nbj, P.deg_new);
     gd_launch_dual_update(P, st, 0);
     const int cb = gd_commit_blocks(P);
     k_gd_coef_commit<<<dim3((unsigned)cb), 256, 0, st>>>(P);
