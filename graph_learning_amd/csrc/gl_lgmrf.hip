@@ -943,8 +943,9 @@ __global__ __launch_bounds__(1024) void k_lg_admm_one(LgDev D, int max_iter) {
 // QP that stops after ~30 steps does not pay for 100 launches.
 // Persistent form: rows per workgroup R = ceil(n / #CU) <= 8 and R * n * 8 bytes of LDS.
 // ------------------------------------------------------------------------------------------
-// The whole block-coordinate descent of a small problem (n <= 64, full mask: the "fast" path) in ONE launch
-// of ONE workgroup.  lgmrf.py:169-226: K', Theta, C = Theta^-1 and G = (Theta + rho I)^-1 live in LDS (row
+// The whole block-coordinate descent of a small problem (n <= 64) in ONE launch of ONE workgroup.  Fast path
+// (full mask) as described next; GENERAL (any mask): no G, per node W = I + rho M on the active set is built
+// from C in the same LDS matrix and inverted in place (k_lg_build_w + Gauss-Jordan of the launch path).  lgmrf.py:169-226: K', Theta, C = Theta^-1 and G = (Theta + rho I)^-1 live in LDS (row
 // stride n + 1), a cycle inverts Theta + rho I by Gauss-Jordan in place, and per node: the QP's set-up, its
 // ADMM in wave 0 (rows of inv(I + rho M) in registers, right-hand side broadcast through the scalar file,
 // as k_lg_admm_wave), beta, C beta, the rank-one updates of Theta and C and the rank-two Woodbury
@@ -952,7 +953,7 @@ __global__ __launch_bounds__(1024) void k_lg_admm_one(LgDev D, int max_iter) {
 // k_lg_build_winv, k_lg_node_update, k_lg_update_c, k_lg_wood_scal, k_lg_update_g), separated by workgroup
 // barriers instead of eleven launches.  The cycle rule (:221-224) is evaluated in place.
 // At n = 32 a node update costs ~50 us here against 96 us with eleven launches around a one-wave ADMM.
-template <int NP>
+template <int NP, bool GENERAL>
 __global__ __launch_bounds__(256) void k_lg_fit_small(LgDev D, int max_cycle, double prob_tol, int max_qp_iter, double *out) {
     extern __shared__ double sm[];
     __shared__ double s_red[3][4];
@@ -979,42 +980,66 @@ __global__ __launch_bounds__(256) void k_lg_fit_small(LgDev D, int max_cycle, do
         for (int i = wave; i < n; i += 4)
             if (col) {
                 D.ThPrev[(int64_t)i * n + lane] = sTh[i * S + lane];
-                sG[i * S + lane] = sTh[i * S + lane] + (i == lane ? rho : 0.0);
+                if (!GENERAL) sG[i * S + lane] = sTh[i * S + lane] + (i == lane ? rho : 0.0);
             }
         __syncthreads();
-        for (int k = 0; k < n; ++k) {  // Gauss-Jordan, no pivoting (SPD), as k_gj_pivot / k_gj_eliminate
-            if (tid < n) {
-                const double piv = sG[k * S + k];
-                s_prow[tid] = (tid == k) ? 1.0 / piv : sG[k * S + tid] / piv;
-                s_pcol[tid] = sG[tid * S + k];
-            }
-            __syncthreads();
-            for (int i = wave; i < n; i += 4)
-                if (col) {
-                    if (i == k) {
-                        sG[i * S + lane] = s_prow[lane];
-                    } else {
-                        const double cur = (lane == k) ? 0.0 : sG[i * S + lane];
-                        sG[i * S + lane] = cur - s_pcol[i] * s_prow[lane];
-                    }
+        // Gauss-Jordan in place, no pivoting (SPD), as k_gj_pivot / k_gj_eliminate
+        auto invert_sG = [&]() {
+            for (int k = 0; k < n; ++k) {
+                if (tid < n) {
+                    const double piv = sG[k * S + k];
+                    s_prow[tid] = (tid == k) ? 1.0 / piv : sG[k * S + tid] / piv;
+                    s_pcol[tid] = sG[tid * S + k];
                 }
-            __syncthreads();
-        }
+                __syncthreads();
+                for (int i = wave; i < n; i += 4)
+                    if (col) {
+                        if (i == k) {
+                            sG[i * S + lane] = s_prow[lane];
+                        } else {
+                            const double cur = (lane == k) ? 0.0 : sG[i * S + lane];
+                            sG[i * S + lane] = cur - s_pcol[i] * s_prow[lane];
+                        }
+                    }
+                __syncthreads();
+            }
+        };
+        if (!GENERAL) invert_sG();  // fast path: G = (Theta + rho I)^-1 once per cycle
 
         for (int u = 0; u < n; ++u) {
+            if (GENERAL) {  // k_lg_build_w: W = I + rho M on the active set (identity elsewhere), M = C - c c'/c_uu; inverted in place
+                if (tid < n) s_a[tid] = (tid != u && D.mask[(int64_t)tid * n + u] == 1.0) ? 1.0 : 0.0;  // the active set (s_a is free here)
+                __syncthreads();
+                const double cuu = sC[u * S + u];
+                for (int i = wave; i < n; i += 4)
+                    if (col) {
+                        double t = (i == lane) ? 1.0 : 0.0;
+                        if (s_a[i] != 0.0 && s_a[lane] != 0.0) {
+                            const double m = sC[i * S + lane] - (sC[i * S + u] * sC[lane * S + u]) / cuu;
+                            t += rho * m;
+                        }
+                        sG[i * S + lane] = t;
+                    }
+                __syncthreads();
+                invert_sG();
+            }
             // ---- the QP of node u in wave 0 (k_lg_qp_setup + k_lg_build_winv + the ADMM of k_lg_admm_wave)
             if (wave == 0) {
-                const double kuu = sKT[u * S + u], guu = sG[u * S + u];
-                const bool active = col && lane != u;
+                const double kuu = sKT[u * S + u], guu = GENERAL ? 1.0 : sG[u * S + u];
+                const bool active = col && lane != u && (!GENERAL || s_a[col ? lane : 0] != 0.0);
                 const double pi = active ? sKT[u * S + lane] / kuu : 0.0;
-                const double gi = col ? sG[lane * S + u] : 0.0;
+                const double gi = (col && !GENERAL) ? sG[lane * S + u] : 0.0;
                 double w[NP];
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
                     double t = 0.0;
                     if (col && j < n) {
-                        t = (lane == j) ? 1.0 : 0.0;
-                        if (lane != u && j != u) t -= rho * (sG[lane * S + j] - (gi * sG[j * S + u]) / guu);
+                        if (GENERAL) {
+                            t = sG[lane * S + j];
+                        } else {
+                            t = (lane == j) ? 1.0 : 0.0;
+                            if (lane != u && j != u) t -= rho * (sG[lane * S + j] - (gi * sG[j * S + u]) / guu);
+                        }
                     }
                     w[j] = t;
                 }
@@ -1116,6 +1141,7 @@ __global__ __launch_bounds__(256) void k_lg_fit_small(LgDev D, int max_cycle, do
                     }
             }
             __syncthreads();  // every reader of the snapshot h is done: h becomes G a (one wave per row)
+            if (GENERAL) continue;  // no G to maintain: W is rebuilt from C for the next node
             for (int i = wave; i < n; i += 4) {
                 double acc = col ? sG[i * S + lane] * s_a[lane] : 0.0;
                 acc = wsum(acc);
@@ -1671,17 +1697,31 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
     // A forced ADMM form (GRAPHLEARN_AMD_LGMRF_ADMM) or GRAPHLEARN_AMD_LGMRF_FUSED=0 keeps the launch path.
     {
         const char *fz = getenv("GRAPHLEARN_AMD_LGMRF_FUSED");
-        if (fast && n <= 64 && !getenv("GRAPHLEARN_AMD_LGMRF_ADMM") && !(fz && !strcmp(fz, "0"))) {
+        if (n <= 64 && !getenv("GRAPHLEARN_AMD_LGMRF_ADMM") && !(fz && !strcmp(fz, "0"))) {
             const size_t lds = ((size_t)4 * n * (n + 1) + 9 * n) * 8;
-            const void *fn = n <= 16 ? (const void *)k_lg_fit_small<16> : (n <= 32 ? (const void *)k_lg_fit_small<32> : (const void *)k_lg_fit_small<64>);
-            GL_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             double *res = D.scal + 12;
-            if (n <= 16)
-                k_lg_fit_small<16><<<1, 256, lds, ctx->stream>>>(D, max_cycle, prob_tol, max_qp_iter, res);
-            else if (n <= 32)
-                k_lg_fit_small<32><<<1, 256, lds, ctx->stream>>>(D, max_cycle, prob_tol, max_qp_iter, res);
-            else
-                k_lg_fit_small<64><<<1, 256, lds, ctx->stream>>>(D, max_cycle, prob_tol, max_qp_iter, res);
+            const int np = n <= 16 ? 16 : (n <= 32 ? 32 : 64);
+            const bool general = !fast;
+            if (general && !D.mask) {  // forced general path with a full mask: the kernel reads the mask
+                GL_HIP(ctx, hipMalloc(&bMask.p, nn));
+                std::vector<double> ones((size_t)n * n, 1.0);
+                GL_TRY(gl_h2d(ctx, bMask.p, ones.data(), nn));
+                GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                D.mask = (const double *)bMask.p;
+            }
+#define GL_FIT_SMALL(NPV, GEN)                                                                                              \
+    do {                                                                                                                    \
+        GL_HIP(ctx, hipFuncSetAttribute((const void *)k_lg_fit_small<NPV, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        (int)lds));                                                                         \
+        k_lg_fit_small<NPV, GEN><<<1, 256, lds, ctx->stream>>>(D, max_cycle, prob_tol, max_qp_iter, res);                   \
+    } while (0)
+            if (np == 16 && !general) GL_FIT_SMALL(16, false);
+            else if (np == 16) GL_FIT_SMALL(16, true);
+            else if (np == 32 && !general) GL_FIT_SMALL(32, false);
+            else if (np == 32) GL_FIT_SMALL(32, true);
+            else if (!general) GL_FIT_SMALL(64, false);
+            else GL_FIT_SMALL(64, true);
+#undef GL_FIT_SMALL
             GL_HIP(ctx, hipGetLastError());
             double r2[2];
             GL_TRY(gl_d2h(ctx, laplacian_out, D.Th, nn));
