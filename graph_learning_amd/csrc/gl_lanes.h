@@ -53,6 +53,27 @@ __device__ __forceinline__ double half_sum(double v) {
 // sum over all 64 lanes (result in every lane)
 __device__ __forceinline__ double wave_sum(double v) { return add_xor32(half_sum(v)); }
 
+// maximum over all 64 lanes (result in every lane): the butterfly of wave_sum with fmax
+__device__ __forceinline__ double wave_max(double v) {
+    v = fmax(v, dpp_mov<DPP_QUAD_XOR1>(v));
+    v = fmax(v, dpp_mov<DPP_QUAD_XOR2>(v));
+    v = fmax(v, dpp_mov<DPP_HALF_MIRROR>(v));
+    v = fmax(v, dpp_mov<DPP_ROW_ROR8>(v));
+    {
+        const long long b = __double_as_longlong(v);
+        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+        v = fmax(__longlong_as_double(((long long)hi[0] << 32) | lo[0]), __longlong_as_double(((long long)hi[1] << 32) | lo[1]));
+    }
+    {
+        const long long b = __double_as_longlong(v);
+        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+        v = fmax(__longlong_as_double(((long long)hi[0] << 32) | lo[0]), __longlong_as_double(((long long)hi[1] << 32) | lo[1]));
+    }
+    return v;
+}
+
 // Sums of 8 per-lane values over the 32 lanes of a half-wave, "halving" butterfly: every step
 // exchanges half of what is left, so 4 + 2 + 1 + 1 + 1 = 9 exchanges instead of 8 x 5.  Afterwards
 // lane l holds the total of value ((l >> 2) & 7) of its half-wave.

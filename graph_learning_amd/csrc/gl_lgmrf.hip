@@ -37,10 +37,18 @@ namespace {
 constexpr int VT = 1024;  // threads of the single-workgroup vector kernels
 
 __device__ __forceinline__ double wsum(double v) { return wave_sum(v); }  // gl_lanes.h: DPP / permlane swaps
-__device__ __forceinline__ double wmax(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
-    return v;
+__device__ __forceinline__ double wmax(double v) { return wave_max(v); }  // DPP butterfly (a ds_bpermute one cost 0.25 us)
+
+// The ADMM's stopping rule (lgmrf.py:66-69 with relative_error, evaluation.py:21-25: plain norm when the
+// previous iterate is allclose to 0) from the squared norms.  Four square roots and two divisions in fp64
+// are ~0.35 us for a lone wave; they are only taken when the squares do not already say "not yet".
+__device__ __forceinline__ bool lg_rule_met(double dx2, double x2, double xm, double dz2, double z2, double zm, double tol) {
+    const bool xs = xm <= 1e-8, zs = zm <= 1e-8;
+    const double t2 = tol * tol * (1 + 1e-12);
+    if (dx2 > t2 * (xs ? 1.0 : x2) || dz2 > t2 * (zs ? 1.0 : z2)) return false;  // sqrt(a) / sqrt(b) > tol for sure
+    const double rx = xs ? sqrt(dx2) : sqrt(dx2) / sqrt(x2);
+    const double rz = zs ? sqrt(dz2) : sqrt(dz2) / sqrt(z2);
+    return rx < tol && rz < tol;
 }
 
 // block-wide sum / max over VT threads (deterministic order); result in every thread
@@ -252,10 +260,7 @@ __global__ __launch_bounds__(256) void k_lg_admm(LgDev D, int it) {
         a4 = wsum(a4);
         m2 = wmax(m2);
         m5 = wmax(m5);
-        // relative_error(prev, new): plain norm when prev is allclose to 0 (atol 1e-8)
-        const double rx = (m2 <= 1e-8) ? sqrt(a0) : sqrt(a0) / sqrt(a1);
-        const double rz = (m5 <= 1e-8) ? sqrt(a3) : sqrt(a3) / sqrt(a4);
-        if (lane == 0 && rx < D.qp_tol && rz < D.qp_tol) {
+        if (lane == 0 && lg_rule_met(a0, a1, m2, a3, a4, m5, D.qp_tol)) {
             s_stop = 1;
             if (blockIdx.x == 0) {
                 D.scal[1] = (double)it;  // steps run
@@ -410,10 +415,7 @@ __global__ __launch_bounds__(256) void k_lg_admm_res(LgDev D, GlGridBar gb, int 
             a4 = wsum(a4);
             m2 = wmax(m2);
             m5 = wmax(m5);
-            // relative_error(prev, new): plain norm when prev is allclose to 0 (atol 1e-8)
-            const double rx = (m2 <= 1e-8) ? sqrt(a0) : sqrt(a0) / sqrt(a1);
-            const double rz = (m5 <= 1e-8) ? sqrt(a3) : sqrt(a3) / sqrt(a4);
-            if (lane == 0 && rx < D.qp_tol && rz < D.qp_tol) s_stop = 1;
+            if (lane == 0 && lg_rule_met(a0, a1, m2, a3, a4, m5, D.qp_tol)) s_stop = 1;
         }
         __syncthreads();
         if (s_stop) {  // step it-1 met the rule: its z is the result, nothing of step `it` is applied
@@ -607,10 +609,7 @@ __global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, unsigned *err, lg_
                 a4 = wsum(a4);
                 m2 = wmax(m2);
                 m5 = wmax(m5);
-                // relative_error(prev, new): plain norm when prev is allclose to 0 (atol 1e-8)
-                const double rx = (m2 <= 1e-8) ? sqrt(a0) : sqrt(a0) / sqrt(a1);
-                const double rz = (m5 <= 1e-8) ? sqrt(a3) : sqrt(a3) / sqrt(a4);
-                stop = (rx < D.qp_tol && rz < D.qp_tol) ? 1 : 0;
+                stop = lg_rule_met(a0, a1, m2, a3, a4, m5, D.qp_tol) ? 1 : 0;
             }
             if (lane == 0) s_stop[it & 1] = stop;
         }
@@ -749,6 +748,32 @@ __device__ __forceinline__ double lg_bcast(double x, int j) {
     return __hiloint2double(hi, lo);
 }
 
+// sums of four per-lane values over the wave, all four in every lane: the halving butterfly of gl_lanes.h
+// (7 exchanges instead of 4 x 6) and four scalar broadcasts
+__device__ __forceinline__ void lg_wsum4(double (&v)[4], int lane) {
+    const double c = add_xor32(halfwave_rows4(v, lane));
+    v[0] = lg_bcast(c, 0);
+    v[1] = lg_bcast(c, 8);
+    v[2] = lg_bcast(c, 16);
+    v[3] = lg_bcast(c, 24);
+}
+// "the previous iterate is allclose to 0" (max |prev| <= 1e-8, evaluation.py:21-23) from the sum of squares
+// wherever that decides (max^2 <= sum <= m max^2 over m entries); the max reduction only in between
+template <typename F>
+__device__ __forceinline__ bool lg_prev_is_zero(double sum2, double m, F &&max_abs) {
+    if (sum2 > m * 1e-16) return false;
+    if (sum2 <= 1e-16) return true;
+    return max_abs() <= 1e-8;
+}
+// the rule with the two "previous iterate ~ 0" flags already known
+__device__ __forceinline__ bool lg_rule_met2(double dx2, double x2, bool xs, double dz2, double z2, bool zs, double tol) {
+    const double t2 = tol * tol * (1 + 1e-12);
+    if (dx2 > t2 * (xs ? 1.0 : x2) || dz2 > t2 * (zs ? 1.0 : z2)) return false;
+    const double rx = xs ? sqrt(dx2) : sqrt(dx2) / sqrt(x2);
+    const double rz = zs ? sqrt(dz2) : sqrt(dz2) / sqrt(z2);
+    return rx < tol && rz < tol;
+}
+
 template <int NP>
 __global__ __launch_bounds__(64) void k_lg_admm_wave(LgDev D, int max_iter, int64_t u_fast) {
     const int n = (int)D.n, lane = threadIdx.x;
@@ -784,9 +809,16 @@ __global__ __launch_bounds__(64) void k_lg_admm_wave(LgDev D, int max_iter, int6
     int steps = 0;
     bool stopped = false;
     for (int it = 0; it < max_iter; ++it) {
-        double acc = 0.0;
+        // four independent fused chains: a lone wave is bound by the latency of a dependent fp64 add per column
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-        for (int j = 0; j < NP; ++j) acc += w[j] * lg_bcast(v, j);
+        for (int j = 0; j < NP; j += 4) {
+            a0 = __builtin_fma(w[j], lg_bcast(v, j), a0);
+            a1 = __builtin_fma(w[j + 1], lg_bcast(v, j + 1), a1);
+            a2 = __builtin_fma(w[j + 2], lg_bcast(v, j + 2), a2);
+            a3 = __builtin_fma(w[j + 3], lg_bcast(v, j + 3), a3);
+        }
+        const double acc = (a0 + a1) + (a2 + a3);
         const double xn = active ? acc : 0.0;
         double zn = xn + uo;
         zn = zn < 0 ? 0.0 : zn;
@@ -806,15 +838,11 @@ __global__ __launch_bounds__(64) void k_lg_admm_wave(LgDev D, int max_iter, int6
         v = active ? (zn - un) + D.rho * pi : 0.0;
         steps = it + 1;
         if (it > 0) {  // `if it > 0 and ...`; relative_error's plain-norm branch when prev ~ 0
-            dx2 = wsum(dx2);
-            x2 = wsum(x2);
-            xm = wmax(xm);
-            dz2 = wsum(dz2);
-            z2 = wsum(z2);
-            zm = wmax(zm);
-            const double rx = (xm <= 1e-8) ? sqrt(dx2) : sqrt(dx2) / sqrt(x2);
-            const double rz = (zm <= 1e-8) ? sqrt(dz2) : sqrt(dz2) / sqrt(z2);
-            if (rx < D.qp_tol && rz < D.qp_tol) {
+            double sq[4] = {dx2, x2, dz2, z2};
+            lg_wsum4(sq, lane);
+            const bool xs = lg_prev_is_zero(sq[1], 64.0, [&] { return wmax(xm); });
+            const bool zs = lg_prev_is_zero(sq[3], 64.0, [&] { return wmax(zm); });
+            if (lg_rule_met2(sq[0], sq[1], xs, sq[2], sq[3], zs, D.qp_tol)) {
                 stopped = true;
                 break;
             }
@@ -830,6 +858,148 @@ __global__ __launch_bounds__(64) void k_lg_admm_wave(LgDev D, int max_iter, int6
         }
     }
     if (lane == 0) {
+        D.scal[1] = (double)steps;
+        D.scal[0] = stopped ? 1.0 : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The ADMM of mid-size problems (64 < n <= 160) in ONE workgroup with the explicit inverse in REGISTERS:
+// four lanes per row, lane h of row r keeps the entries W[r][4c + h], c < CPL (CPL = 32: n <= 128, 512
+// threads; CPL = 40: n <= 160, 640 threads -- 80 of the 170 registers a thread has there; 48 spills), the right-hand
+// side sits in LDS (double-buffered, broadcast reads), the four partial dot products of a row meet by two
+// DPP adds, lane 0 of the quad updates the row.  One workgroup barrier per step (norm partials and the next
+// right-hand side are double-buffered), no traffic outside the CU: ~0.6-0.9 us per step against 3.3 us for
+// the multi-workgroup form at these sizes.  u_fast >= 0: rows of inv(I + rho M) straight from G.
+constexpr int ADMM_QUAD_MAXN = 160;
+
+template <int CPL>
+__global__ __launch_bounds__(16 * CPL) void k_lg_admm_quad(LgDev D, int max_iter, int64_t u_fast) {
+    constexpr int NR = 4 * CPL, NT = 4 * NR, NW = NT / 64;
+    __shared__ double s_v[2][NR];
+    __shared__ double s_red[2][6][NW];
+    const int n = (int)D.n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = tid >> 2, h = tid & 3;
+    const bool rowon = row < n;
+    double w[CPL];
+    if (u_fast >= 0) {
+        const int u = (int)u_fast;
+        const double guu = D.G[(int64_t)u * n + u];
+        const double gi = rowon ? D.gcol[row] : 0.0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int j = 4 * c + h;
+            double t = 0.0;
+            if (rowon && j < n) {
+                t = (row == j) ? 1.0 : 0.0;
+                if (row != u && j != u) t -= D.rho * (D.G[(int64_t)row * n + j] - (gi * D.gcol[j]) / guu);
+            }
+            w[c] = t;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int j = 4 * c + h;
+            w[c] = (rowon && j < n) ? D.W[(int64_t)row * n + j] : 0.0;
+        }
+    }
+    double xo = 0, zo = 0, uo = 0, pi = 0, on = 0;
+    if (rowon && h == 0) {
+        xo = D.x[row];
+        zo = D.z[row];
+        uo = D.uu[row];
+        pi = D.p[row];
+        on = D.act[row];
+    }
+    if (h == 0) s_v[0][row] = rowon ? D.v[row] : 0.0;
+    const bool active = on != 0.0;  // false on lanes h != 0 and on padded rows
+    __syncthreads();
+    int steps = 0;
+    bool stopped = false;
+    for (int it = 0; it < max_iter; ++it) {
+        const double *vin = s_v[it & 1];
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;  // four independent fused chains
+#pragma unroll
+        for (int c = 0; c < CPL; c += 4) {
+            a0 = __builtin_fma(w[c], vin[4 * c + h], a0);
+            a1 = __builtin_fma(w[c + 1], vin[4 * c + 4 + h], a1);
+            a2 = __builtin_fma(w[c + 2], vin[4 * c + 8 + h], a2);
+            a3 = __builtin_fma(w[c + 3], vin[4 * c + 12 + h], a3);
+            if (CPL > 32 && (c & 7) == 4) __builtin_amdgcn_sched_barrier(0);  // 640 threads: eight LDS reads in flight are enough
+        }
+        double acc = (a0 + a1) + (a2 + a3);
+        acc += dpp_mov<DPP_QUAD_XOR1>(acc);
+        acc += dpp_mov<DPP_QUAD_XOR2>(acc);
+        double dx2 = 0, x2 = 0, xm = 0, dz2 = 0, z2 = 0, zm = 0;
+        {
+            const double xn = active ? acc : 0.0;
+            double zn = xn + uo;
+            zn = zn < 0 ? 0.0 : zn;
+            const double un = uo + (xn - zn);
+            if (active) {
+                dx2 = (xn - xo) * (xn - xo);
+                x2 = xo * xo;
+                xm = fabs(xo);
+                dz2 = (zn - zo) * (zn - zo);
+                z2 = zo * zo;
+                zm = fabs(zo);
+            }
+            xo = xn;
+            zo = active ? zn : 0.0;
+            uo = active ? un : 0.0;
+            if (h == 0) s_v[(it + 1) & 1][row] = active ? (zn - un) + D.rho * pi : 0.0;
+        }
+        double sq[4] = {dx2, x2, dz2, z2};
+        lg_wsum4(sq, lane);  // per-wave sums, all four in every lane
+        if (lane == 0) {
+            double *r = &s_red[it & 1][0][0];
+            r[0 * NW + wave] = sq[0];
+            r[1 * NW + wave] = sq[1];
+            r[2 * NW + wave] = sq[2];
+            r[3 * NW + wave] = sq[3];
+        }
+        __syncthreads();  // the next right-hand side and this step's norm partials are out
+        steps = it + 1;
+        if (it > 0) {  // `if it > 0 and ...`; relative_error's plain-norm branch when prev ~ 0
+            const double *r = &s_red[it & 1][0][0];
+            double t[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double a = r[q * NW];
+#pragma unroll
+                for (int v = 1; v < NW; ++v) a += r[q * NW + v];
+                t[q] = a;
+            }
+            // max |prev| over the workgroup, only when the sums of squares do not already tell (same branch everywhere)
+            auto block_max = [&](double m) {
+                m = wmax(m);
+                double *mx = &s_red[it & 1][4][0];
+                if (lane == 0) mx[wave] = m;
+                __syncthreads();
+                double a = mx[0];
+                for (int v = 1; v < NW; ++v) a = fmax(a, mx[v]);
+                __syncthreads();
+                return a;
+            };
+            const bool xs = lg_prev_is_zero(t[1], (double)n, [&] { return block_max(xm); });
+            const bool zs = lg_prev_is_zero(t[3], (double)n, [&] { return block_max(zm); });
+            if (lg_rule_met2(t[0], t[1], xs, t[2], t[3], zs, D.qp_tol)) {
+                stopped = true;
+                break;
+            }
+        }
+    }
+    if (rowon && h == 0) {
+        D.x[row] = xo;
+        D.z[row] = zo;
+        D.uu[row] = uo;
+        if (u_fast >= 0) {  // fast path of the fit: k_lg_beta and k_lg_snap_col ride along
+            D.beta[row] = active ? -zo : 0.0;
+            D.h[row] = D.C[(int64_t)row * n + u_fast];
+        }
+    }
+    if (tid == 0) {
         D.scal[1] = (double)steps;
         D.scal[0] = stopped ? 1.0 : 0.0;
     }
@@ -919,9 +1089,7 @@ __global__ __launch_bounds__(1024) void k_lg_admm_one(LgDev D, int max_iter) {
         }
         steps = it + 1;
         if (it > 0) {  // lgmrf.py:68 `if it > 0 and ...`; relative_error's plain-norm branch when prev ~ 0
-            const double rx = (t[2] <= 1e-8) ? sqrt(t[0]) : sqrt(t[0]) / sqrt(t[1]);
-            const double rz = (t[5] <= 1e-8) ? sqrt(t[3]) : sqrt(t[3]) / sqrt(t[4]);
-            if (rx < D.qp_tol && rz < D.qp_tol) {
+            if (lg_rule_met(t[0], t[1], t[2], t[3], t[4], t[5], D.qp_tol)) {
                 stopped = true;
                 break;
             }
@@ -1046,9 +1214,15 @@ __global__ __launch_bounds__(256) void k_lg_fit_small(LgDev D, int max_cycle, do
                 double xo = 0, zo = 0, uo = 0;
                 double v = active ? (0.0 - 0.0) + rho * pi : 0.0;
                 for (int it = 0; it < max_qp_iter; ++it) {
-                    double acc = 0.0;
+                    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;  // four independent fused chains (see k_lg_admm_wave)
 #pragma unroll
-                    for (int j = 0; j < NP; ++j) acc += w[j] * lg_bcast(v, j);
+                    for (int j = 0; j < NP; j += 4) {
+                        a0 = __builtin_fma(w[j], lg_bcast(v, j), a0);
+                        a1 = __builtin_fma(w[j + 1], lg_bcast(v, j + 1), a1);
+                        a2 = __builtin_fma(w[j + 2], lg_bcast(v, j + 2), a2);
+                        a3 = __builtin_fma(w[j + 3], lg_bcast(v, j + 3), a3);
+                    }
+                    const double acc = (a0 + a1) + (a2 + a3);
                     const double xn = active ? acc : 0.0;
                     double zn = xn + uo;
                     zn = zn < 0 ? 0.0 : zn;
@@ -1067,15 +1241,11 @@ __global__ __launch_bounds__(256) void k_lg_fit_small(LgDev D, int max_cycle, do
                     uo = active ? un : 0.0;
                     v = active ? (zn - un) + rho * pi : 0.0;
                     if (it > 0) {
-                        dx2 = wsum(dx2);
-                        x2 = wsum(x2);
-                        xm = wmax(xm);
-                        dz2 = wsum(dz2);
-                        z2 = wsum(z2);
-                        zm = wmax(zm);
-                        const double rx = (xm <= 1e-8) ? sqrt(dx2) : sqrt(dx2) / sqrt(x2);
-                        const double rz = (zm <= 1e-8) ? sqrt(dz2) : sqrt(dz2) / sqrt(z2);
-                        if (rx < D.qp_tol && rz < D.qp_tol) break;
+                        double sq[4] = {dx2, x2, dz2, z2};
+                        lg_wsum4(sq, lane);
+                        const bool xs = lg_prev_is_zero(sq[1], 64.0, [&] { return wmax(xm); });
+                        const bool zs = lg_prev_is_zero(sq[3], 64.0, [&] { return wmax(zm); });
+                        if (lg_rule_met2(sq[0], sq[1], xs, sq[2], sq[3], zs, D.qp_tol)) break;
                     }
                 }
                 if (col) {
@@ -1220,6 +1390,7 @@ __global__ __launch_bounds__(256) void k_lg_fit_small(LgDev D, int max_cycle, do
 struct AdmmRes {
     bool one = false;  // n <= 64: single-workgroup form (k_lg_admm_one)
     bool wave = false;  // n <= 64: single-wave form (k_lg_admm_wave), the default there
+    bool quad = false;  // 64 < n <= 160: one workgroup, four lanes per row, rows in registers (k_lg_admm_quad), the default there
     bool on = false;
     int R = 0, nwg = 0;
     size_t lds = 0;
@@ -1230,19 +1401,23 @@ struct AdmmRes {
     unsigned next_tag = 0;  // first tag of the next launch (a launch uses max_iter + 1 consecutive ones)
 };
 
-// Which form the QP's ADMM loop takes.  GRAPHLEARN_AMD_LGMRF_ADMM = launch | wave | one | resident | tagged forces
+// Which form the QP's ADMM loop takes.  GRAPHLEARN_AMD_LGMRF_ADMM = launch | wave | quad | one | resident | tagged forces
 // one (where it applies).  Measured per node-update, one cycle of the config-3 input (every QP runs its
 // 100 steps), launch / grid-barrier / tagged:  n = 128: 0.66 / 0.61 / 0.38 ms,  256: 0.67 / 0.72 / 0.39,
 // 500: 0.90 / 0.81 / 0.46,  1024: 0.96 / 0.89 / 0.56,  2048: 1.62 / 1.20 / 0.80;  single workgroup
 // against tagged at n = 32: 0.26 / 0.20, n = 64: 0.48 / 0.30.  To n = 64 the default is the single-wave form.
 
 int admm_res_plan(gl_ctx *ctx, int64_t n, AdmmRes &A) {
-    A.on = A.one = A.wave = A.tagged = false;
+    A.on = A.one = A.wave = A.quad = A.tagged = false;
     const char *force = getenv("GRAPHLEARN_AMD_LGMRF_ADMM");
     auto is = [&](const char *v) { return force && !strcmp(force, v); };
     if (is("launch")) return GL_OK;
     if (n <= ADMM_ONE_MAXN && (is("wave") || !force)) {  // one wave, rows in registers
         A.wave = true;
+        return GL_OK;
+    }
+    if (n > ADMM_ONE_MAXN && n <= ADMM_QUAD_MAXN && (is("quad") || is("wave") || !force)) {  // one workgroup, rows in registers
+        A.quad = true;
         return GL_OK;
     }
     if (n <= ADMM_ONE_MAXN && is("one")) {
@@ -1276,6 +1451,15 @@ int run_admm_wave(gl_ctx *ctx, const LgDev &D, int max_iter, int64_t u_fast = -1
         k_lg_admm_wave<32><<<1, 64, 0, ctx->stream>>>(D, max_iter, u_fast);
     else
         k_lg_admm_wave<64><<<1, 64, 0, ctx->stream>>>(D, max_iter, u_fast);
+    GL_HIP(ctx, hipGetLastError());
+    return GL_OK;
+}
+
+int run_admm_quad(gl_ctx *ctx, const LgDev &D, int max_iter, int64_t u_fast = -1) {
+    if (D.n <= 128)
+        k_lg_admm_quad<32><<<1, 512, 0, ctx->stream>>>(D, max_iter, u_fast);
+    else
+        k_lg_admm_quad<40><<<1, 640, 0, ctx->stream>>>(D, max_iter, u_fast);
     GL_HIP(ctx, hipGetLastError());
     return GL_OK;
 }
@@ -1588,6 +1772,7 @@ GL_API int gl_nonneg_qp_solve(gl_ctx *ctx, const double *mat, const double *vec,
     GL_HIP(ctx, hipMemsetAsync(D.scal, 0, 16 * 8, ctx->stream));
     GL_TRY(invert_spd_inplace(ctx, D.W, m, pivrow));
     GL_TRY(ares.wave ? run_admm_wave(ctx, D, max_iter)
+           : ares.quad ? run_admm_quad(ctx, D, max_iter)
                      : (ares.one ? run_admm_one(ctx, D, ares, max_iter)
                                  : (ares.on ? run_admm_res(ctx, D, ares, max_iter) : run_admm(ctx, D, max_iter))));
     double sc[9];
@@ -1742,7 +1927,7 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
         }
         for (int64_t u = 0; u < n; ++u) {
             k_lg_qp_setup<<<1, VT, 0, ctx->stream>>>(D, u);
-            const bool fused_winv = fast && (ares.wave || (ares.on && ares.tagged));  // the ADMM kernel forms its rows of the inverse itself
+            const bool fused_winv = fast && (ares.wave || ares.quad || (ares.on && ares.tagged));  // the ADMM kernel forms its rows of the inverse itself
             if (fused_winv) {
             } else if (fast) {
                 k_lg_build_winv<<<g2, 256, 0, ctx->stream>>>(D, u);
@@ -1751,6 +1936,7 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
                 GL_TRY(invert_spd_inplace(ctx, D.W, n, pivrow));
             }
             GL_TRY(ares.wave ? run_admm_wave(ctx, D, max_qp_iter, fused_winv ? u : -1)
+                   : ares.quad ? run_admm_quad(ctx, D, max_qp_iter, fused_winv ? u : -1)
                              : (ares.one ? run_admm_one(ctx, D, ares, max_qp_iter)
                                          : (ares.on ? run_admm_res(ctx, D, ares, max_qp_iter, fused_winv ? u : -1)
                                                     : run_admm(ctx, D, max_qp_iter))));

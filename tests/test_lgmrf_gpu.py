@@ -16,13 +16,14 @@ from oracle import lgmrf as olg
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["launch", "wave", "one", "resident", "tagged", "auto"])
+@pytest.fixture(autouse=True, params=["launch", "wave", "quad", "one", "resident", "tagged", "auto"])
 def admm_form(request, monkeypatch):
     """Every test runs with every form of the QP's ADMM loop: one launch per step, the single-wave kernel
-    (n <= 64, rows of the inverse in registers), the single-workgroup kernel (n <= 64, whole inverse in
-    LDS), the persistent multi-workgroup kernels (matrix rows resident in LDS; steps separated by grid
-    barriers, or the right-hand side handed over as self-validating tagged records) and the automatic
-    choice (single wave to n = 64, tagged above)."""
+    (n <= 64, rows of the inverse in registers), the single-workgroup kernel with four lanes per row
+    (64 < n <= 160, rows in registers), the single-workgroup kernel with the inverse in LDS (n <= 64), the
+    persistent multi-workgroup kernels (matrix rows resident in LDS; steps separated by grid barriers, or
+    the right-hand side handed over as self-validating tagged records) and the automatic choice (wave to
+    n = 64, quad to n = 160, tagged above)."""
     if request.param == "auto":
         monkeypatch.delenv("GRAPHLEARN_AMD_LGMRF_ADMM", raising=False)
     else:
@@ -139,3 +140,17 @@ def test_qp_solver_many_iterations():
     zr, ref_iters = olg.nonneg_qp_admm(q, p, step=0.1, tol=1e-13, max_iter=400, return_iters=True)
     assert abs(iters - ref_iters) <= 1 and iters > 120
     np.testing.assert_allclose(z, zr, rtol=0, atol=1e-10)
+
+
+@pytest.mark.parametrize("n", [65, 100, 128, 129, 160, 161])
+def test_qp_solver_mid_sizes(n):
+    """Both sides of the limits of the register-resident single-workgroup form (64 < n <= 160) against the oracle."""
+    rng = np.random.default_rng(n)
+    a = rng.standard_normal((n, n + 5))
+    q, p = a @ a.T / n + 0.05 * np.eye(n), rng.standard_normal(n)
+    for tol, mi in ((1e-6, 100), (1e-3, 100), (0.0, 7)):
+        z, iters = nonnegative_qp_solver(q, p, step=0.1, tol=tol, max_iter=mi, return_iters=True)
+        zr, ref_iters = olg.nonneg_qp_admm(q, p, step=0.1, tol=tol, max_iter=mi, return_iters=True)
+        assert abs(iters - ref_iters) <= 1
+        if iters == ref_iters:
+            np.testing.assert_allclose(z, zr, rtol=0, atol=1e-10)

@@ -64,10 +64,10 @@ while time.time() < t_end:
         if not np.allclose(out, ref, rtol=0, atol=1e-9):
             fail(kind, desc, f"max diff {np.abs(out - ref).max():.2e}")
     elif kind == "lgmrf":
-        n = int(rng.choice([3, 6, 12, 17, 33, 48]))
+        n = int(rng.choice([3, 6, 12, 17, 33, 48, 70]))
         x = rng.standard_normal((int(rng.integers(2, 6)) * n, n)) @ (np.eye(n) + 0.3 * rng.standard_normal((n, n)))
         cov = x.T @ x / x.shape[0]
-        form = rng.choice(["auto", "launch", "wave", "one", "resident", "tagged"])
+        form = rng.choice(["auto", "launch", "wave", "quad", "one", "resident", "tagged"])
         if form == "auto":
             os.environ.pop("GRAPHLEARN_AMD_LGMRF_ADMM", None)
         else:
@@ -85,10 +85,10 @@ while time.time() < t_end:
         if err > 1e-6:
             fail(kind, desc, f"relative error {err:.2e}")
     elif kind == "qp":
-        n = int(rng.choice([2, 5, 16, 40, 64, 65, 130, 300]))
+        n = int(rng.choice([2, 5, 16, 40, 64, 65, 100, 130, 160, 161, 300]))
         a = rng.standard_normal((n, n + 3))
         q, p = a @ a.T / n + rng.uniform(0.01, 1.0) * np.eye(n), rng.standard_normal(n)
-        form = rng.choice(["auto", "launch", "wave", "one", "resident", "tagged"])
+        form = rng.choice(["auto", "launch", "wave", "quad", "one", "resident", "tagged"])
         if form == "auto":
             os.environ.pop("GRAPHLEARN_AMD_LGMRF_ADMM", None)
         else:
