@@ -51,6 +51,38 @@ __device__ __forceinline__ bool lg_rule_met(double dx2, double x2, double xm, do
     return rx < tol && rz < tol;
 }
 
+// lane j's value in every lane, through the scalar file
+__device__ __forceinline__ double lg_bcast(double x, int j) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), j), hi = __builtin_amdgcn_readlane(__double2hiint(x), j);
+    return __hiloint2double(hi, lo);
+}
+
+// sums of four per-lane values over the wave, all four in every lane: the halving butterfly of gl_lanes.h
+// (7 exchanges instead of 4 x 6) and four scalar broadcasts
+__device__ __forceinline__ void lg_wsum4(double (&v)[4], int lane) {
+    const double c = add_xor32(halfwave_rows4(v, lane));
+    v[0] = lg_bcast(c, 0);
+    v[1] = lg_bcast(c, 8);
+    v[2] = lg_bcast(c, 16);
+    v[3] = lg_bcast(c, 24);
+}
+// "the previous iterate is allclose to 0" (max |prev| <= 1e-8, evaluation.py:21-23) from the sum of squares
+// wherever that decides (max^2 <= sum <= m max^2 over m entries); the max reduction only in between
+template <typename F>
+__device__ __forceinline__ bool lg_prev_is_zero(double sum2, double m, F &&max_abs) {
+    if (sum2 > m * 1e-16) return false;
+    if (sum2 <= 1e-16) return true;
+    return max_abs() <= 1e-8;
+}
+// the rule with the two "previous iterate ~ 0" flags already known
+__device__ __forceinline__ bool lg_rule_met2(double dx2, double x2, bool xs, double dz2, double z2, bool zs, double tol) {
+    const double t2 = tol * tol * (1 + 1e-12);
+    if (dx2 > t2 * (xs ? 1.0 : x2) || dz2 > t2 * (zs ? 1.0 : z2)) return false;
+    const double rx = xs ? sqrt(dx2) : sqrt(dx2) / sqrt(x2);
+    const double rz = zs ? sqrt(dz2) : sqrt(dz2) / sqrt(z2);
+    return rx < tol && rz < tol;
+}
+
 // block-wide sum / max over VT threads (deterministic order); result in every thread
 __device__ double block_sum(double v, double *sh) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -627,12 +659,10 @@ __global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, unsigned *err, lg_
                         if (r < nrows) acc[r] += s_W[(int64_t)r * n + j] * vj[c];
                 }
             }
-#pragma unroll
-            for (int r = 0; r < ADMM_RES_MAXR; ++r) acc[r] = wsum(acc[r]);
-            if (lane == 0) {
-#pragma unroll
-                for (int r = 0; r < ADMM_RES_MAXR; ++r) s_acc[it & 1][wave][r] = acc[r];
-            }
+            // the eight row sums of the wave in ONE halving butterfly (10 exchanges instead of 8 x 6): afterwards
+            // lane 4 r holds row r
+            const double rs = add_xor32(halfwave_rows8(acc, lane));
+            if (lane < 32 && (lane & 3) == 0) s_acc[it & 1][wave][lane >> 2] = rs;
         }
         __syncthreads();
         if (s_fail) {
@@ -674,11 +704,10 @@ __global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, unsigned *err, lg_
                 publish((it + 1) & 1, r0 + tid, active ? (zn - un) + D.rho * pi : 0.0, tag + 1u);
             }
             if (wave == 0) {  // rows live in lanes 0..R-1 of wave 0: fixed-order sums over those lanes
-                dx2 = wsum(dx2);
-                x2 = wsum(x2);
+                double sq[4] = {dx2, x2, dz2, z2};
+                lg_wsum4(sq, lane);
+                dx2 = sq[0], x2 = sq[1], dz2 = sq[2], z2 = sq[3];
                 xm = wmax(xm);
-                dz2 = wsum(dz2);
-                z2 = wsum(z2);
                 zm = wmax(zm);
                 if (lane == 0) {
                     const int off = ((it & 3) * nblk + (int)blockIdx.x) * 48;
@@ -743,36 +772,6 @@ __global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, unsigned *err, lg_
 // in place after every step -- no LDS, no barrier, no memory traffic inside the loop: ~0.5 us per step
 // against 1.7 us for the multi-workgroup forms at this size.  NP = n rounded up to 16 / 32 / 64 (zero
 // padding).  u_fast >= 0: rows of inv(I + rho M) straight from G (the formula of k_lg_build_winv).
-__device__ __forceinline__ double lg_bcast(double x, int j) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), j), hi = __builtin_amdgcn_readlane(__double2hiint(x), j);
-    return __hiloint2double(hi, lo);
-}
-
-// sums of four per-lane values over the wave, all four in every lane: the halving butterfly of gl_lanes.h
-// (7 exchanges instead of 4 x 6) and four scalar broadcasts
-__device__ __forceinline__ void lg_wsum4(double (&v)[4], int lane) {
-    const double c = add_xor32(halfwave_rows4(v, lane));
-    v[0] = lg_bcast(c, 0);
-    v[1] = lg_bcast(c, 8);
-    v[2] = lg_bcast(c, 16);
-    v[3] = lg_bcast(c, 24);
-}
-// "the previous iterate is allclose to 0" (max |prev| <= 1e-8, evaluation.py:21-23) from the sum of squares
-// wherever that decides (max^2 <= sum <= m max^2 over m entries); the max reduction only in between
-template <typename F>
-__device__ __forceinline__ bool lg_prev_is_zero(double sum2, double m, F &&max_abs) {
-    if (sum2 > m * 1e-16) return false;
-    if (sum2 <= 1e-16) return true;
-    return max_abs() <= 1e-8;
-}
-// the rule with the two "previous iterate ~ 0" flags already known
-__device__ __forceinline__ bool lg_rule_met2(double dx2, double x2, bool xs, double dz2, double z2, bool zs, double tol) {
-    const double t2 = tol * tol * (1 + 1e-12);
-    if (dx2 > t2 * (xs ? 1.0 : x2) || dz2 > t2 * (zs ? 1.0 : z2)) return false;
-    const double rx = xs ? sqrt(dx2) : sqrt(dx2) / sqrt(x2);
-    const double rz = zs ? sqrt(dz2) : sqrt(dz2) / sqrt(z2);
-    return rx < tol && rz < tol;
-}
 
 template <int NP>
 __global__ __launch_bounds__(64) void k_lg_admm_wave(LgDev D, int max_iter, int64_t u_fast) {
