@@ -33,11 +33,7 @@
 namespace {
 
 __device__ __forceinline__ double gd_wave_sum(double v) { return wave_sum(v); }  // gl_lanes.h
-__device__ __forceinline__ double gd_wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
-}
+__device__ __forceinline__ double gd_wave_max(double v) { return wave_max(v); }  // gl_lanes.h (DPP)
 
 // ------------------------------------------------------------------------------------------
 // coefficient gradient: SC[g][k][t] = sum over the pairs of strip group g of W[k,(i,j)] (x_ti - x_tj)^2

@@ -41,11 +41,7 @@ struct GdSmallArgs {
     int oX, oW, oC, oCw, oDual, oDeg, oDegN, oPc, oPw, oPm, oPair;  // LDS offsets, in doubles
 };
 
-__device__ __forceinline__ double gs_wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
-}
+__device__ __forceinline__ double gs_wave_max(double v) { return wave_max(v); }  // gl_lanes.h (DPP)
 
 template <int KP>
 __global__ __launch_bounds__(GS_NT) void k_gd_small(GdDev P, GdSmallArgs A) {
@@ -92,12 +88,18 @@ __global__ __launch_bounds__(GS_NT) void k_gd_small(GdDev P, GdSmallArgs A) {
     // sums (slots 0, 1, 3, 4) and maxima (slots 2, 5) over the workgroup, fixed order; the first barrier
     // also publishes what the phase before wrote to LDS
     auto reduce6 = [&](double(&v)[6]) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) v[c] = (c % 3 == 2) ? gs_wave_max(v[c]) : wave_sum(v[c]);
+        // the four sums in one halving butterfly (lane 8 q of the lower half holds sum q), the maxima by DPP
+        const double four[4] = {v[0], v[1], v[3], v[4]};
+        const double sums = add_xor32(halfwave_rows4(four, lane));
+        const double m2 = gs_wave_max(v[2]), m5 = gs_wave_max(v[5]);
         __syncthreads();
+        if (lane < 32 && (lane & 7) == 0) {
+            const int q = lane >> 3;
+            s_red[q < 2 ? q : q + 1][wave] = sums;
+        }
         if (lane == 0) {
-#pragma unroll
-            for (int c = 0; c < 6; ++c) s_red[c][wave] = v[c];
+            s_red[2][wave] = m2;
+            s_red[5][wave] = m5;
         }
         __syncthreads();
 #pragma unroll
