@@ -43,6 +43,22 @@ struct GdSmallArgs {
 
 __device__ __forceinline__ double gs_wave_max(double v) { return wave_max(v); }  // gl_lanes.h (DPP)
 
+// q = tid, tid + NT, ... split as (q / d, q % d) without a division inside the step loop: a runtime integer
+// division is ~40 dependent instructions, and a lone workgroup is bound by exactly such chains
+struct GsIdx {
+    int a0, b0, sa, sb;  // first item of this thread and the step of (quotient, remainder)
+};
+__device__ __forceinline__ GsIdx gs_idx(int tid, int nt, int d) {
+    GsIdx r;
+    r.a0 = tid / d;
+    r.b0 = tid - r.a0 * d;
+    r.sa = nt / d;
+    r.sb = nt - r.sa * d;
+    return r;
+}
+#define GS_FOR2(IT, D, COUNT, A_, B_) \
+    for (int q = tid, A_ = (IT).a0, B_ = (IT).b0; q < (COUNT); q += NT, A_ += (IT).sa, B_ += (IT).sb, A_ += (B_ >= (D)) ? 1 : 0, B_ -= (B_ >= (D)) ? (D) : 0)
+
 template <int KP>
 __global__ __launch_bounds__(GS_NT) void k_gd_small(GdDev P, GdSmallArgs A) {
     extern __shared__ double smem[];
@@ -110,6 +126,8 @@ __global__ __launch_bounds__(GS_NT) void k_gd_small(GdDev P, GdSmallArgs A) {
         }
     };
 
+    const GsIdx ixT = gs_idx(tid, NT, T), ixE = gs_idx(tid, NT, E > 0 ? E : 1), ixN = gs_idx(tid, NT, n),
+                ixTw = gs_idx(tid, NT, Tw);
     double step_c = P.step_c, step_w = P.step_w, step_dual = P.step_dual;
     int flags = 0;
     long long converged = -1, it = 0;
@@ -126,8 +144,7 @@ __global__ __launch_bounds__(GS_NT) void k_gd_small(GdDev P, GdSmallArgs A) {
         }
         // ---- the three products, chunk partials ---------------------------------------------------
         if (fit || it == 0) {  // W @ sq_pdiffs' (:375); predict: the weights never change
-            for (int q = tid; q < T * A.PC; q += NT) {
-                const int pc = q / T, t = q - pc * T;
+            GS_FOR2(ixT, T, T * A.PC, pc, t) {
                 double acc[KP];
 #pragma unroll
                 for (int k = 0; k < KP; ++k) acc[k] = 0.0;
@@ -142,8 +159,7 @@ __global__ __launch_bounds__(GS_NT) void k_gd_small(GdDev P, GdSmallArgs A) {
             }
         }
         if (fit) {
-            for (int q = tid; q < E * A.TC; q += NT) {  // C @ sq_pdiffs (:447)
-                const int tc = q / E, e = q - tc * E;
+            GS_FOR2(ixE, E, E * A.TC, tc, e) {  // C @ sq_pdiffs (:447)
                 const double *xi = sX + sI[e] * XS, *xj = sX + sJ[e] * XS;
                 double acc[KP];
 #pragma unroll
@@ -158,8 +174,7 @@ __global__ __launch_bounds__(GS_NT) void k_gd_small(GdDev P, GdSmallArgs A) {
 #pragma unroll
                 for (int k = 0; k < KP; ++k) sPw[(tc * E + e) * KP + k] = acc[k];
             }
-            for (int q = tid; q < n * A.MC; q += NT) {  // C @ dual_rep (log_model.py:36-37)
-                const int mc = q / n, i = q - mc * n;
+            GS_FOR2(ixN, n, n * A.MC, mc, i) {  // C @ dual_rep (log_model.py:36-37)
                 double acc[KP];
 #pragma unroll
                 for (int k = 0; k < KP; ++k) acc[k] = 0.0;
@@ -196,8 +211,7 @@ __global__ __launch_bounds__(GS_NT) void k_gd_small(GdDev P, GdSmallArgs A) {
         __syncthreads();
         // ---- coefficient update (:373-401) and weight update (:444-461) ----------------------------
         double r[6] = {0, 0, 0, 0, 0, 0};  // [2] max |c_new|; [3..5] sum (w_new - w)^2, sum w^2, max |w|
-        for (int q = tid; q < K * Tw; q += NT) {
-            const int k = q / Tw, tw = q - k * Tw;
+        GS_FOR2(ixTw, Tw, K * Tw, k, tw) {
             double dterm = 0.0;  // W @ (S' dual') == <S W_k, dual_tw>  (log_model.py:33-34)
             for (int i = 0; i < n; ++i) dterm += sDeg[k * n + i] * sDual[tw * n + i];
             double tot = 0.0;
@@ -247,8 +261,7 @@ __global__ __launch_bounds__(GS_NT) void k_gd_small(GdDev P, GdSmallArgs A) {
             flags |= 1;
         }
         if (fit)  // degrees of the new weights
-            for (int q = tid; q < K * n; q += NT) {
-                const int k = q / n, i = q - k * n;
+            GS_FOR2(ixN, n, K * n, k, i) {
                 double s = 0.0;
                 for (int u = 0; u < n; ++u) {
                     if (u == i) continue;
@@ -259,8 +272,7 @@ __global__ __launch_bounds__(GS_NT) void k_gd_small(GdDev P, GdSmallArgs A) {
             }
         __syncthreads();
         // ---- dual update with the overshoot 2 new - old (log_model.py:39-50, base_model.py:509-514) ----
-        for (int q = tid; q < Tw * n; q += NT) {
-            const int tw = q / n, i = q - tw * n;
+        GS_FOR2(ixN, n, Tw * n, tw, i) {
             double stp = 0.0;
             for (int k = 0; k < K; ++k) {
                 const double dold = sDeg[k * n + i];
@@ -273,9 +285,8 @@ __global__ __launch_bounds__(GS_NT) void k_gd_small(GdDev P, GdSmallArgs A) {
         __syncthreads();
         // ---- commit the coefficients, relative changes (:516-519) ------------------------------------
         double c6[6] = {0, 0, 0, 0, 0, 0};
-        for (int q = tid; q < K * T; q += NT) {
-            const int k = q / T, t = q - k * T;
-            const double nw = sCw[k * Tw + t / W], o = sC[q];
+        GS_FOR2(ixT, T, K * T, k, t) {
+            const double nw = sCw[k * Tw + (W == 1 ? t : t / W)], o = sC[q];
             c6[0] += (nw - o) * (nw - o);
             c6[1] += o * o;
             c6[2] = fmax(c6[2], fabs(o));
