@@ -28,7 +28,6 @@ struct gl_ctx {
     size_t pinned_bytes = 0;  // status area only (the staging area follows it)
     bool stage_busy = false;  // an asynchronous staged upload may still be reading the staging area
     bool small_attrs_set = false;  // dynamic-LDS limit of the small-engine kernels raised on this device
-    bool gj_attr_set = false;     // k_gj_lds' dynamic LDS attribute (gl_lgmrf.hip)
 };
 
 int gl_set_error(gl_ctx *ctx, int code, const char *fmt, ...);

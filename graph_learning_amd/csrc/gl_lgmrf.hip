@@ -1673,50 +1673,85 @@ struct Buf {
     }
 };
 
-// The same Gauss-Jordan for n <= 128 in ONE launch of ONE workgroup: the matrix in LDS (row stride n + 1), a
-// workgroup barrier per half-step instead of two launches per pivot (n = 64: 128 launches = 0.6 ms -> 40 us).
-// Element-wise the arithmetic of k_gj_pivot / k_gj_eliminate, so the result is bit-identical.
+// The same Gauss-Jordan for n <= 128 in ONE launch of ONE workgroup, the matrix in REGISTERS: thread (wave w,
+// lane l) owns the entries (w + 16 r, l + 64 c), r < 8, c < 2; per pivot the scaled pivot row and the pivot
+// column go through LDS (double-buffered: one workgroup barrier per pivot) and every thread updates its 16
+// entries from 10 LDS reads.  n = 64: 128 launches = 0.6 ms -> ~30 us.  Element-wise the arithmetic of
+// k_gj_pivot / k_gj_eliminate, so the result is bit-identical.
 constexpr int GJ_LDS_MAXN = 128;
 __global__ __launch_bounds__(1024) void k_gj_lds(double *__restrict__ A, int n) {
-    extern __shared__ double sA[];
-    const int S = n + 1;
-    double *s_prow = sA + n * S, *s_pcol = s_prow + n;
+    __shared__ double s_prow[2][GJ_LDS_MAXN], s_pcol[2][GJ_LDS_MAXN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = wave; i < n; i += 16)
-        for (int j = lane; j < n; j += 64) sA[i * S + j] = A[(int64_t)i * n + j];
-    __syncthreads();
+    double a[8][2];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int i = wave + 16 * r, j = lane + 64 * c;
+            a[r][c] = (i < n && j < n) ? A[(int64_t)i * n + j] : 0.0;
+        }
     for (int k = 0; k < n; ++k) {
-        if (tid < n) {
-            const double piv = sA[k * S + k];
-            s_prow[tid] = (tid == k) ? 1.0 / piv : sA[k * S + tid] / piv;
-            s_pcol[tid] = sA[tid * S + k];
+        double *prow = s_prow[k & 1], *pcol = s_pcol[k & 1];
+        const int kr = k >> 4, kw = k & 15, kc = k >> 6, kl = k & 63;  // owner of row k: wave kw, slot kr; of column k: lane kl, slot kc
+        if (wave == kw) {  // scaled pivot row
+            double rowv[2] = {0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (r == kr) {
+                    rowv[0] = a[r][0];
+                    rowv[1] = a[r][1];
+                }
+            const double mine = kc ? rowv[1] : rowv[0];
+            const long long pb = __double_as_longlong(mine);
+            const double piv = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(pb >> 32), kl) << 32) |
+                                                    (unsigned)__builtin_amdgcn_readlane((int)pb, kl));
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int j = lane + 64 * c;
+                if (j < n) prow[j] = (j == k) ? 1.0 / piv : rowv[c] / piv;
+            }
+        }
+        if (lane == kl) {  // pivot column before it is overwritten
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = wave + 16 * r;
+                if (i < n) pcol[i] = kc ? a[r][1] : a[r][0];
+            }
         }
         __syncthreads();
-        for (int i = wave; i < n; i += 16)
-            for (int j = lane; j < n; j += 64) {
+        double pr[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) pr[c] = (lane + 64 * c < n) ? prow[lane + 64 * c] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = wave + 16 * r;
+            if (i >= n) continue;
+            const double pc = pcol[i];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int j = lane + 64 * c;
                 if (i == k) {
-                    sA[i * S + j] = s_prow[j];
+                    a[r][c] = pr[c];
                 } else {
-                    const double cur = (j == k) ? 0.0 : sA[i * S + j];
-                    sA[i * S + j] = cur - s_pcol[i] * s_prow[j];
+                    const double cur = (j == k) ? 0.0 : a[r][c];
+                    a[r][c] = cur - pc * pr[c];
                 }
             }
-        __syncthreads();
+        }
     }
-    for (int i = wave; i < n; i += 16)
-        for (int j = lane; j < n; j += 64) A[(int64_t)i * n + j] = sA[i * S + j];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int i = wave + 16 * r, j = lane + 64 * c;
+            if (i < n && j < n) A[(int64_t)i * n + j] = a[r][c];
+        }
 }
 
 // pivrow: 2 n doubles of scratch (scaled pivot row, then the pivot column)
 int invert_spd_inplace(gl_ctx *ctx, double *A, int64_t n, double *pivrow) {
     if (n <= GJ_LDS_MAXN && !getenv("GRAPHLEARN_AMD_LGMRF_GJ_LAUNCH")) {
-        const size_t lds = ((size_t)n * (n + 1) + 2 * n) * 8;
-        if (!ctx->gj_attr_set) {
-            GL_HIP(ctx, hipFuncSetAttribute((const void *)k_gj_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)(((size_t)GJ_LDS_MAXN * (GJ_LDS_MAXN + 1) + 2 * GJ_LDS_MAXN) * 8)));
-            ctx->gj_attr_set = true;
-        }
-        k_gj_lds<<<1, 1024, lds, ctx->stream>>>(A, (int)n);
+        k_gj_lds<<<1, 1024, 0, ctx->stream>>>(A, (int)n);
         GL_HIP(ctx, hipGetLastError());
         return GL_OK;
     }
@@ -1771,20 +1806,29 @@ GL_API int gl_nonneg_qp_solve(gl_ctx *ctx, const double *mat, const double *vec,
     if (!ctx) return GL_E_INVALID;
     if (!mat || !vec || !z_out || m < 1 || max_iter < 0) return gl_set_error(ctx, GL_E_INVALID, "bad argument");
     GL_HIP(ctx, hipSetDevice(ctx->device));
-    Buf W, vecs, scal, part, bar;
-    GL_HIP(ctx, hipMalloc(&W.p, (size_t)m * m * 8));
-    Buf gran;
-    GL_HIP(ctx, hipMalloc(&part.p, (size_t)4 * m * 6 * 8));  // one entry per workgroup and ring slot, any ADMM form
-    GL_HIP(ctx, hipMalloc(&bar.p, GL_BAR_WORDS * 4));
-    GL_HIP(ctx, hipMemsetAsync(bar.p, 0, GL_BAR_WORDS * 4, ctx->stream));
-    GL_HIP(ctx, hipMalloc(&gran.p, (size_t)2 * m * 16));
-    GL_HIP(ctx, hipMemsetAsync(gran.p, 0, (size_t)2 * m * 16, ctx->stream));
+    // one allocation for everything (seven hipMalloc / hipFree pairs were half of a small call's time)
+    Buf arena;
+    struct View {
+        void *p = nullptr;
+    } W, vecs, scal, part, bar, gran;
+    {
+        auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+        const size_t bW = up((size_t)m * m * 8), bPart = up((size_t)4 * m * 6 * 8), bBar = up(GL_BAR_WORDS * 4),
+                     bGran = up((size_t)2 * m * 16), bVec = up((size_t)16 * m * 8), bScal = up(16 * 8);
+        GL_HIP(ctx, hipMalloc(&arena.p, bW + bPart + bBar + bGran + bVec + bScal));
+        char *at = (char *)arena.p;
+        W.p = at, at += bW;
+        part.p = at, at += bPart;
+        bar.p = at, at += bBar;       // bar, gran: zeroed together
+        gran.p = at, at += bGran;
+        vecs.p = at, at += bVec;
+        scal.p = at;
+        GL_HIP(ctx, hipMemsetAsync(bar.p, 0, bBar + bGran, ctx->stream));
+    }
     AdmmRes ares;
     GL_TRY(admm_res_plan(ctx, m, ares));
     ares.bar = (unsigned *)bar.p;
     ares.gran = (lg_u4 *)gran.p;
-    GL_HIP(ctx, hipMalloc(&vecs.p, (size_t)16 * m * 8));
-    GL_HIP(ctx, hipMalloc(&scal.p, 16 * 8));
     double *V = (double *)vecs.p;
     LgDev D{};
     D.n = m;
