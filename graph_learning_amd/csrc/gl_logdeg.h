@@ -39,6 +39,7 @@ struct gl_logdeg {
     LogdegDev dev{};
     int64_t n = 0, n_edges = 0;
     void *arena = nullptr;        // the one allocation every fixed-size buffer of the session is carved from
+    void *sig_arena = nullptr;    // zsq, theta_terms and xdev (set_signals only), one allocation too
     double *zsq = nullptr;        // n x n squared distances (set_signals only)
     double *stage = nullptr;      // device staging for condensed host transfers (E doubles)
     double *xdev = nullptr;       // signals (d x n) on device

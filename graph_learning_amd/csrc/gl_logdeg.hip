@@ -899,7 +899,7 @@ GL_API int gl_logdeg_destroy(gl_logdeg *s) {
     }
     drop_graph(s);
     gl_resident_free(s);
-    void *ptrs[] = {s->arena, s->zsq, s->xdev, s->theta_terms};
+    void *ptrs[] = {s->arena, s->sig_arena};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete s;
@@ -935,15 +935,21 @@ GL_API int gl_logdeg_set_signals(gl_logdeg *s, const double *x, int64_t d, int64
         return gl_set_error(ctx, GL_E_INVALID, "avg_degree %d must be < n_nodes %lld", avg_degree, (long long)s->n);
     GL_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t xe = d * s->n;
-    if (s->xdev_elems < xe) {
-        if (s->xdev) (void)hipFree(s->xdev);
-        s->xdev = nullptr;
+    if (s->xdev_elems < xe || !s->zsq) {  // signals, squared distances and the theta terms in one allocation
+        if (s->sig_arena) {
+            GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(s->sig_arena);
+        }
+        s->sig_arena = nullptr;
+        s->xdev = s->zsq = s->theta_terms = nullptr;
         s->xdev_elems = 0;
-        GL_HIP(ctx, hipMalloc((void **)&s->xdev, (size_t)xe * 8));
+        const size_t bz = ((size_t)s->n * s->n * 8 + 255) / 256 * 256, bt = ((size_t)2 * s->n * 8 + 255) / 256 * 256;
+        GL_HIP(ctx, hipMalloc(&s->sig_arena, bz + bt + (size_t)xe * 8));
+        s->zsq = (double *)s->sig_arena;
+        s->theta_terms = (double *)((char *)s->sig_arena + bz);
+        s->xdev = (double *)((char *)s->sig_arena + bz + bt);
         s->xdev_elems = xe;
     }
-    if (!s->zsq) GL_HIP(ctx, hipMalloc((void **)&s->zsq, (size_t)s->n * s->n * 8));
-    if (!s->theta_terms) GL_HIP(ctx, hipMalloc((void **)&s->theta_terms, (size_t)2 * s->n * 8));
     GL_TRY(gl_h2d(ctx, s->xdev, x, (size_t)xe * 8));
     GL_TRY(gl_gram_distances(ctx, s->xdev, d, s->n, s->zsq));
     double theta = 1.0;
@@ -951,7 +957,7 @@ GL_API int gl_logdeg_set_signals(gl_logdeg *s, const double *x, int64_t d, int64
     k_to_tiled<1><<<dim3((unsigned)s->dev.ntiles), dim3(256), 0, ctx->stream>>>(
         s->zsq, const_cast<double *>(s->dev.z), s->n, s->dev.nb, theta);
     GL_HIP(ctx, hipGetLastError());
-    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((size_t)xe * 8 > GL_STAGE_BYTES) GL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pageable source still in use
     s->theta = theta;
     s->have_z = true;
     s->have_zsq = true;
