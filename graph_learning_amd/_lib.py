@@ -49,6 +49,7 @@ SIGNATURES = {
     "gl_logdeg_create": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
     "gl_logdeg_destroy": (C.c_int, [C.c_void_p]),
     "gl_logdeg_set_signals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _c_double_p]),
+    "gl_logdeg_theta": (C.c_int, [C.c_void_p, _c_double_p]),
     "gl_logdeg_set_distances": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gl_logdeg_get_distances": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gl_logdeg_init": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]),
@@ -238,15 +239,21 @@ class LogDegreeSession:
         self.ctx.check(self._lib.gl_logdeg_create(self.ctx.handle, self.n, C.byref(h)), "logdeg_create")
         self._h = h
 
-    def set_signals(self, x, avg_degree=None) -> float:
+    def set_signals(self, x, avg_degree=None, deferred=False):
+        """-> theta; with deferred=True nothing comes back (no host round trip): ask ``theta()`` later."""
         x = as_f64(x)
         if x.ndim != 2 or x.shape[1] != self.n:
             raise ValueError(f"x must be (n_samples, {self.n}), got {x.shape}")
         theta = C.c_double(1.0)
         k = -1 if avg_degree is None else int(avg_degree)
-        self.ctx.check(self._lib.gl_logdeg_set_signals(self._h, ptr(x), x.shape[0], x.shape[1], k, C.byref(theta)),
-                       "set_signals")
-        return theta.value
+        self.ctx.check(self._lib.gl_logdeg_set_signals(self._h, ptr(x), x.shape[0], x.shape[1], k,
+                                                       None if deferred else C.byref(theta)), "set_signals")
+        return None if deferred else theta.value
+
+    def theta(self) -> float:
+        out = C.c_double(1.0)
+        self.ctx.check(self._lib.gl_logdeg_theta(self._h, C.byref(out)), "theta")
+        return out.value
 
     def set_distances(self, z):
         z = as_f64(z)

@@ -58,11 +58,11 @@ def learn_log_degrees_from_signals(signal_blocks, avg_degree, alpha, beta, edge_
     ctx = ctx or _lib.default_context()
     sessions = [_lib.LogDegreeSession(n, ctx) for _ in range(n_batch)]
     try:
-        thetas = []
         for b, s in enumerate(sessions):
-            thetas.append(s.set_signals(blocks[b], avg_degree))  # distances scaled by theta, resident
+            s.set_signals(blocks[b], avg_degree, deferred=True)  # distances scaled by theta, resident; nothing comes back
             s.init(alpha, beta, step_size, None if edge_init is None else np.ascontiguousarray(edge_init[:, b]))
         out, info = _run_sessions(sessions, ctx, maxit, tol, edge_tol)
+        thetas = [s.theta() for s in sessions]
     finally:
         for s in sessions:
             s.close()

@@ -51,6 +51,7 @@ struct gl_logdeg {
     bool have_zsq = false;
     int64_t it = 0;               // iterations completed (iterate lives in w[it & 1])
     double theta = 1.0;
+    bool theta_pending = false;   // set_signals left theta on the device (dstat[4]): gl_logdeg_theta fetches it
     // captured batch of iterations (launch-bound inner loop -> one graph launch)
     hipGraphExec_t graph = nullptr;
     int graph_iters = 0;
@@ -65,6 +66,7 @@ int gl_gram_distances(gl_ctx *ctx, const double *x_dev, int64_t d, int64_t n, do
 // gl_theta.hip
 int gl_theta_from_square(gl_ctx *ctx, const double *zsq_dev, int64_t n, int k, double *terms_dev,
                          double *theta_out);
+int gl_theta_from_square_dev(gl_ctx *ctx, const double *zsq_dev, int64_t n, int k, double *terms_dev, double *theta_dev);
 int gl_theta_from_rows(gl_ctx *ctx, const double *zsq_dev, int64_t rows, int64_t cols, int k, double *terms_dev,
                        double *theta_out);
 // gl_resident.hip

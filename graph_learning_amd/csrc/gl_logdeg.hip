@@ -527,7 +527,9 @@ __global__ void k_status(LogdegDev P) {
 // Layout conversion kernels (one workgroup per tile, same lane map as k_edge).
 template <int MODE>  // 0: from condensed, 1: from square (upper triangle)
 __global__ __launch_bounds__(256) void k_to_tiled(const double *__restrict__ src, double *__restrict__ dst,
-                                                  int64_t n, int64_t nb, double scale) {
+                                                  int64_t n, int64_t nb, double scale_arg,
+                                                  const double *__restrict__ scale_dev = nullptr) {
+    const double scale = scale_dev ? scale_dev[0] : scale_arg;  // theta left on the device by set_signals
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int I, J;
     gl_tile_decode((int64_t)blockIdx.x, nb, I, J);
@@ -953,9 +955,20 @@ GL_API int gl_logdeg_set_signals(gl_logdeg *s, const double *x, int64_t d, int64
     GL_TRY(gl_h2d(ctx, s->xdev, x, (size_t)xe * 8));
     GL_TRY(gl_gram_distances(ctx, s->xdev, d, s->n, s->zsq));
     double theta = 1.0;
-    if (avg_degree > 0) GL_TRY(gl_theta_from_square(ctx, s->zsq, s->n, avg_degree, s->theta_terms, &theta));
-    k_to_tiled<1><<<dim3((unsigned)s->dev.ntiles), dim3(256), 0, ctx->stream>>>(
-        s->zsq, const_cast<double *>(s->dev.z), s->n, s->dev.nb, theta);
+    // theta_out == NULL: the caller fetches theta later (gl_logdeg_theta); for n <= 128 it then never leaves the
+    // device before the distances are scaled, and a batch of windows goes through without a round trip each
+    const bool deferred = !theta_out && avg_degree > 0 && s->n <= 128;
+    s->theta_pending = deferred;
+    if (deferred) {
+        double *theta_dev = s->dev.dstat + 4;
+        GL_TRY(gl_theta_from_square_dev(ctx, s->zsq, s->n, avg_degree, s->theta_terms, theta_dev));
+        k_to_tiled<1><<<dim3((unsigned)s->dev.ntiles), dim3(256), 0, ctx->stream>>>(
+            s->zsq, const_cast<double *>(s->dev.z), s->n, s->dev.nb, 1.0, theta_dev);
+    } else {
+        if (avg_degree > 0) GL_TRY(gl_theta_from_square(ctx, s->zsq, s->n, avg_degree, s->theta_terms, &theta));
+        k_to_tiled<1><<<dim3((unsigned)s->dev.ntiles), dim3(256), 0, ctx->stream>>>(
+            s->zsq, const_cast<double *>(s->dev.z), s->n, s->dev.nb, theta);
+    }
     GL_HIP(ctx, hipGetLastError());
     if ((size_t)xe * 8 > GL_STAGE_BYTES) GL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pageable source still in use
     s->theta = theta;
@@ -963,6 +976,18 @@ GL_API int gl_logdeg_set_signals(gl_logdeg *s, const double *x, int64_t d, int64
     s->have_zsq = true;
     s->inited = false;
     if (theta_out) *theta_out = theta;
+    return GL_OK;
+}
+
+GL_API int gl_logdeg_theta(gl_logdeg *s, double *theta_out) {
+    GL_TRY(check(s));
+    if (!theta_out) return gl_set_error(s->ctx, GL_E_INVALID, "theta_out is NULL");
+    if (s->theta_pending) {
+        GL_HIP(s->ctx, hipSetDevice(s->ctx->device));
+        GL_TRY(gl_d2h(s->ctx, &s->theta, s->dev.dstat + 4, 8));
+        s->theta_pending = false;
+    }
+    *theta_out = s->theta;
     return GL_OK;
 }
 

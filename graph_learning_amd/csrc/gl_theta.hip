@@ -107,7 +107,26 @@ double pairwise_sum(const double *a, int64_t n) {
     return pairwise_sum(a, h) + pairwise_sum(a + h, n - h);
 }
 
+// the host's finish of theta on the device, for rows <= 128 (there pairwise_sum is the plain ordered sum):
+// one thread, so that nothing has to come back before the distances are scaled
+__global__ void k_theta_finish(const double *__restrict__ terms, int rows, double *__restrict__ theta_dev) {
+    double lo = 0, hi = 0;
+    for (int i = 0; i < rows; ++i) lo += terms[i];
+    for (int i = 0; i < rows; ++i) hi += terms[rows + i];
+    theta_dev[0] = sqrt((lo / (double)rows) * (hi / (double)rows));
+}
+
 }  // namespace
+
+// theta of a square matrix left in device memory (n <= 128); no synchronisation
+int gl_theta_from_square_dev(gl_ctx *ctx, const double *zsq_dev, int64_t n, int k, double *terms_dev, double *theta_dev) {
+    if (k < 1 || k >= n) return gl_set_error(ctx, GL_E_INVALID, "avg_degree must be in [1, %lld], got %d", (long long)n - 1, k);
+    if (n > 128) return gl_set_error(ctx, GL_E_INVALID, "internal: device-side theta is for n <= 128");
+    k_theta_rows<<<dim3((unsigned)n), dim3(256), 0, ctx->stream>>>(zsq_dev, n, k, terms_dev, n);
+    k_theta_finish<<<1, 1, 0, ctx->stream>>>(terms_dev, (int)n, theta_dev);
+    GL_HIP(ctx, hipGetLastError());
+    return GL_OK;
+}
 
 // rows x cols matrix (the square n x n case of LogModel, or a block of it: get_theta's blocks branch,
 // smooth_learning.py:220-235, calls the plain branch on rectangular sub-matrices)

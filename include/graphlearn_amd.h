@@ -71,9 +71,13 @@ int gl_logdeg_destroy(gl_logdeg *s);
  * row-major) via an fp64 MFMA Gram contraction, then theta for `avg_degree`
  * (get_theta, smooth_learning.py:201-219; avg_degree <= 0 means theta = 1,
  * :279-280), then z*theta is laid out in the solver's tiled HBM layout.
- * theta_out may be NULL. */
+ * theta_out may be NULL: theta is then fetched later with gl_logdeg_theta (for n <= 128 it never
+ * leaves the device before the distances are scaled, so a batch of windows is set up without a
+ * host round trip each). */
 int gl_logdeg_set_signals(gl_logdeg *s, const double *x, int64_t d, int64_t n_nodes,
                           int avg_degree, double *theta_out);
+/* theta of the last set_signals (1 after set_distances). */
+int gl_logdeg_theta(gl_logdeg *s, double *theta_out);
 /* Distances given directly (condensed, already scaled), as the free function
  * of the reference takes them (smooth_learning.py:48). */
 int gl_logdeg_set_distances(gl_logdeg *s, const double *z_condensed);

@@ -280,3 +280,21 @@ def test_resident_matches_streaming_at_ragged_large_sizes(n, engine, monkeypatch
     np.testing.assert_allclose(out["resident"][1], out["stream"][1], rtol=0, atol=1e-12)
     assert out["resident"][2][0] == pytest.approx(out["stream"][2][0], rel=1e-9)
     assert out["resident"][2][1] == pytest.approx(out["stream"][2][1], rel=1e-9)
+
+
+@pytest.mark.parametrize("n", [12, 128, 150])
+def test_deferred_theta_is_the_same_theta(n):
+    """set_signals(..., deferred=True) leaves theta on the device (n <= 128: also its computation) and
+    theta() fetches it later: same value, same scaled distances as the immediate form."""
+    x = np.random.default_rng(n).standard_normal((3 * n, n))
+    with _lib.LogDegreeSession(n) as s:
+        t1 = s.set_signals(x, 5)
+        s.init(1, 1, 0.5, None)
+        s.iterate(20, 0.0)
+        w1 = s.weights_condensed(-np.inf)
+        assert s.set_signals(x, 5, deferred=True) is None
+        s.init(1, 1, 0.5, None)
+        s.iterate(20, 0.0)
+        w2 = s.weights_condensed(-np.inf)
+        assert s.theta() == t1
+        assert np.array_equal(w1, w2)
