@@ -56,6 +56,7 @@ SIGNATURES = {
     "gl_logdeg_iterate": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, _c_int64_p, _c_int_p, _c_double_p]),
     "gl_logdeg_iterate_async": (C.c_int, [C.c_void_p, C.c_int64]),
     "gl_logdeg_get_weights_condensed": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p]),
+    "gl_logdeg_batch_get_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
     "gl_logdeg_get_weights_square": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p]),
     "gl_logdeg_get_dual": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gl_logdeg_total_iterations": (C.c_int64, [C.c_void_p]),

@@ -37,7 +37,8 @@ def _run_sessions(sessions, ctx, maxit, tol, edge_tol):
     n_it, conv, rel = C.c_int64(0), C.c_int(0), (C.c_double * 2)(np.inf, np.inf)
     ctx.check(ctx._lib.gl_logdeg_batch_iterate(handles, n_batch, int(maxit), float(tol), C.byref(n_it), C.byref(conv), rel),
               "batch_iterate")
-    out = np.stack([s.weights_condensed(edge_tol) for s in sessions])  # (B, E) == edge_w.T (:174)
+    out = np.empty((n_batch, sessions[0].n_edges))  # (B, E) == edge_w.T (:174): one copy, one synchronisation
+    ctx.check(ctx._lib.gl_logdeg_batch_get_weights(handles, n_batch, float(edge_tol), _lib.ptr(out)), "batch_get_weights")
     return out, {"n_iter": n_it.value, "rel_primal": float(rel[0]), "rel_dual": float(rel[1]),
                  "converged": bool(conv.value)}
 

@@ -1205,6 +1205,37 @@ GL_API int gl_logdeg_get_weights_condensed(gl_logdeg *s, double edge_tol, double
     return GL_OK;
 }
 
+// The thresholded iterates of B sessions (same context, same n) in one go: B conversions into one device
+// buffer, ONE copy, ONE synchronisation (a batch of windows otherwise pays a round trip per graph).
+// w_out is B x E, row b = session b (the layout of the reference's edge_w.T, smooth_learning.py:174).
+GL_API int gl_logdeg_batch_get_weights(gl_logdeg **sessions, int B, double edge_tol, double *w_out) {
+    if (!sessions || B < 1 || !w_out) return GL_E_INVALID;
+    for (int a = 0; a < B; ++a) GL_TRY(check(sessions[a]));
+    gl_ctx *ctx = sessions[0]->ctx;
+    const int64_t E = sessions[0]->n_edges;
+    for (int a = 0; a < B; ++a) {
+        if (sessions[a]->ctx != ctx || sessions[a]->n != sessions[0]->n)
+            return gl_set_error(ctx, GL_E_INVALID, "batched sessions must share the context and n_nodes");
+        if (!sessions[a]->inited) return gl_set_error(ctx, GL_E_STATE, "no iterate yet: call init first");
+    }
+    GL_HIP(ctx, hipSetDevice(ctx->device));
+    double *buf = nullptr;
+    GL_HIP(ctx, hipMalloc((void **)&buf, (size_t)B * E * 8));
+    int rc = GL_OK;
+    for (int a = 0; a < B && rc == GL_OK; ++a) {
+        gl_logdeg *s = sessions[a];
+        rc = resident_check(s);
+        if (rc != GL_OK) break;
+        k_to_condensed<<<dim3((unsigned)s->dev.ntiles), dim3(256), 0, ctx->stream>>>(s->dev.w[s->it & 1], buf + (size_t)a * E, s->n,
+                                                                                  s->dev.nb, edge_tol);
+    }
+    if (rc == GL_OK && hipGetLastError() != hipSuccess) rc = gl_set_error(ctx, GL_E_HIP, "k_to_condensed launch failed");
+    if (rc == GL_OK) rc = gl_d2h(ctx, w_out, buf, (size_t)B * E * 8);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(buf);
+    return rc;
+}
+
 GL_API int gl_logdeg_get_weights_square(gl_logdeg *s, double edge_tol, double *w_out) {
     GL_TRY(check(s));
     gl_ctx *ctx = s->ctx;
