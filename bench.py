@@ -36,6 +36,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PROFILE_JSON = "r02_rocprof_summary.json"   # falls back to nothing when absent
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md), the roofline the edge pass is bound by
 
 
@@ -95,7 +96,11 @@ def main():
     if world > 1:
         from graph_learning_amd.batch import make_comm
 
-        comm = make_comm(rank, world, local_rank, ctx)  # RCCL over xGMI; bootstrap via /tmp file
+        # RCCL over xGMI (bootstrap via a /tmp file); a run that cannot bring RCCL up fails instead of
+        # quietly timing a gloo gather
+        comm = make_comm(rank, world, local_rank, ctx, allow_fallback=os.environ.get("GRAPHLEARN_AMD_COMM") == "gloo")
+        if getattr(comm, "kind", None) != "rccl" and os.environ.get("GRAPHLEARN_AMD_COMM") != "gloo":
+            sys.exit(f"bench.py --gpus {world}: RCCL communicator not available (got {getattr(comm, 'kind', None)})")
     x, _ = logmodel_problem(n, d, seed=rank)
 
     sess = _lib.LogDegreeSession(n, ctx)
@@ -104,10 +109,18 @@ def main():
     setup_s = time.perf_counter() - t0
     sess.init(1.0, 1.0, 0.5, None)
 
-    sess.iterate_async(args.warmup)
+    # ---- warm-up: W untimed steps as asked, then -- whatever W says -- one untimed call of the SAME length as
+    # the timed one, so that the timed call runs the same engine with its code object loaded (a process's first
+    # launch of a kernel costs hundreds of microseconds; the driver's `--steps 20 --warmup 5` used to time that)
+    if args.warmup > 0:
+        sess.iterate_async(args.warmup)
     ctx.sync()
+    ctx.timer_start()
+    sess.iterate_async(args.steps)
+    first_call_us = ctx.timer_stop() * 1e3                # the process's first call of this length (cold), HIP events
     if comm is not None:
         comm.barrier()
+    ctx.sync()
     ctx.timer_start()
     t0 = time.perf_counter()
     sess.iterate_async(args.steps)
@@ -121,6 +134,15 @@ def main():
     engine = sess.engine                                 # "resident" (n=4096 default) or "stream"
     if engine == "resident" and args.steps < 16:         # calls shorter than 16 iterations run on the streaming engine
         engine = "stream"
+    # steady state and fixed cost per call: a long call (2000 steps, or the timed one if it is longer) gives the
+    # per-iteration rate; what the timed call took beyond steps x that rate is the call's fixed cost
+    # (launch, loading the iterate into registers / LDS, storing it back)
+    long_steps = max(args.steps, 2000)
+    ctx.timer_start()
+    sess.iterate_async(long_steps)
+    long_us = ctx.timer_stop() * 1e3
+    steady_us = long_us / long_steps
+    fixed_call_us = max(gpu_ms * 1e3 - args.steps * steady_us, 0.0) if long_steps > args.steps else None
     edge_us = sess.time_edge_pass(200)                   # streaming edge pass alone, HIP events on its stream
     if comm is not None:
         edge_us = comm.max_over_ranks(edge_us)
@@ -128,9 +150,11 @@ def main():
     gather_s = None
     if comm is not None and not args.no_gather:
         t0 = time.perf_counter()
-        gathered = comm.allgather_condensed(sess, edge_tol=1e-3)
+        gathered = comm.allgather_records(sess, 1e-3, problem_id=rank, n_iter=sess.total_iterations, theta=theta)
         gather_s = comm.max_over_ranks(time.perf_counter() - t0)
-        assert gathered.shape == (world, n * (n - 1) // 2)
+        assert gathered.shape == (world, 8 + n * (n - 1) // 2)
+        from graph_learning_amd import wire
+        assert [wire.unpack(r)["problem_id"] for r in gathered] == list(range(world))
 
     # time-to-converge (the second half of BASELINE's metric): fresh start, reference stopping rule
     converge = None
@@ -155,15 +179,23 @@ def main():
             kernel, kprefix = "k_edge<false> (edge pass: prox update of all edges + degree sums)", "k_edge"
             launch_us, launch_bytes, its_per_launch = edge_us, bytes_it, 1
         achieved = launch_bytes / (launch_us * 1e-6) / 1e9
-        traffic = None
-        try:  # PMC FETCH_SIZE / WRITE_SIZE, collected with rocprofv3 in separate passes, per iteration
-            with open(os.path.join(ROOT, "profiles", "r01_rocprof_summary.json")) as f:
+        # HBM traffic: PMC counters cannot be read from inside this process; the figure below is the per-iteration
+        # constant of the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md) of
+        # a 2000-iteration launch -- "profile-derived", and left out when this run's launch is not comparable
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", PROFILE_JSON)) as f:
                 prof = json.load(f)
-            if n == 4096:
+            if n == 4096 and (engine != "resident" or its_per_launch >= 1000):
                 per_it = next(v["total_bytes_per_iteration"] for k, v in prof["traffic"].items() if k.startswith(kprefix))
                 traffic = per_it * its_per_launch
+                traffic_src = (f"profile-derived: profiles/{PROFILE_JSON} (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE per "
+                               f"iteration of a {prof.get('iterations_per_launch', 2000)}-iteration launch) x {its_per_launch}")
         except Exception:
             traffic = None
+        # the resident engine keeps w on chip: its real stream is z (8 E) + the degree partials, so the honest
+        # bound for THIS kernel is that stream at the HBM rate; both fractions are reported
+        z_stream_bytes = 4 * n * (n - 1)
         out = {
             "metric": "primal-dual iterations/sec, LogModel n=4096 d=1024",
             "value": its_per_s,
@@ -182,21 +214,23 @@ def main():
                        "edges": n * (n - 1) // 2, "theta": theta, "setup_s_distances_theta": setup_s,
                        "gather_s": gather_s, "comm": getattr(comm, "kind", None), "gpu_us_per_iteration": iter_us,
                        "engine": engine, "streaming_edge_pass_us": edge_us,
-                       "iteration_level_frac_of_hbm_peak": bytes_it / (iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                       "first_call_us": first_call_us, "fixed_call_us": fixed_call_us,
+                       "steady_state": {"steps": long_steps, "us_per_iteration": steady_us,
+                                        "iterations_per_s": 1e6 / steady_us,
+                                        "frac_of_hbm_peak_algorithmic": bytes_it / (steady_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
                        "time_to_converge": converge},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kernel, "iterations_per_launch": its_per_launch,
                          "algorithmic_bytes_per_launch": launch_bytes, "avg_launch_us": launch_us,
-                         "traffic_source": "profiles/r01_rocprof_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                           "FETCH x2 per MI355X_MICROARCH.md)" if traffic else None,
-                         # the resident engine does not stream the iterate: its real fabric traffic is below the
-                         # algorithmic 24 E bytes, so `frac` (algorithmic bytes / time / peak) can exceed 1
-                         "measured_traffic_rate": (traffic / (launch_us * 1e-6) / 1e9) if traffic else None,
-                         "note": ("achieved = ALGORITHMIC bytes (24 E per iteration, SURVEY 8d) / time.  The resident engine "
-                                  "keeps the iterate in registers / LDS and streams only z, so its real fabric traffic "
-                                  "(`traffic`, PMC) is ~0.45 of the algorithmic figure and `frac` may exceed 1: the kernel is "
-                                  "fp64-issue / barrier bound, not HBM bound (DESIGN.md 3a)") if engine == "resident" else None},
+                         "traffic_source": traffic_src,
+                         "z_stream_frac": (z_stream_bytes * its_per_launch / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS)
+                         if engine == "resident" else None,
+                         "note": ("achieved = ALGORITHMIC bytes (24 E per iteration: read w, read z, write w; SURVEY 8d) / "
+                                  "launch time.  This engine keeps w in registers / LDS, so the bytes it really streams per "
+                                  "iteration are z (8 E) + degree partials: `z_stream_frac` prices that stream against the "
+                                  "same 8 TB/s and is the fraction to read as 'how close to the memory system's limit'; "
+                                  "`frac` can exceed 1") if engine == "resident" else None},
         }
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
             z = sess.get_distances() * theta

@@ -100,6 +100,9 @@ SIGNATURES = {
     "gl_comm_barrier": (C.c_int, [C.c_void_p]),
     "gl_comm_allreduce_max": (C.c_int, [C.c_void_p, _c_double_p]),
     "gl_comm_allgather_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
+    "gl_comm_allgather_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gl_comm_allgather_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int64, C.c_int64, C.c_double,
+                                            C.c_int, C.c_void_p]),
 }
 
 _lib = None

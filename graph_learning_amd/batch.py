@@ -27,6 +27,14 @@ import numpy as np
 from . import _lib
 
 
+def _host_record(session, edge_tol, problem_id, n_iter, theta, converged):
+    """One gather record (wire.py: 64-byte header + condensed weights) built on the host."""
+    from . import wire
+
+    return wire.pack(session.weights_condensed(edge_tol), problem_id=problem_id, n_iter=n_iter, theta=theta,
+                     edge_tol=edge_tol, converged=converged)
+
+
 class SingleComm:
     """World of one: the same interface, nothing to exchange."""
 
@@ -43,6 +51,9 @@ class SingleComm:
 
     def allgather_condensed(self, session, edge_tol=1e-3) -> np.ndarray:
         return session.weights_condensed(edge_tol)[None]
+
+    def allgather_records(self, session, edge_tol, problem_id, n_iter, theta, converged=False) -> np.ndarray:
+        return _host_record(session, edge_tol, problem_id, n_iter, theta, converged)[None]
 
     def close(self):
         pass
@@ -111,6 +122,23 @@ class RcclComm:
                        "comm_allgather_weights")
         return out
 
+    def allgather_arrays(self, arr: np.ndarray) -> np.ndarray:
+        """(world, ...) stack of every rank's small float64 array (same shape everywhere)."""
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        out = np.empty((self.world,) + a.shape)
+        self.ctx.check(self._lib.gl_comm_allgather_f64(self._h, _lib.ptr(a.reshape(-1)), a.size, _lib.ptr(out)),
+                       "comm_allgather_f64")
+        return out
+
+    def allgather_records(self, session, edge_tol, problem_id, n_iter, theta, converged=False) -> np.ndarray:
+        """(world, 8 + E): every rank's self-describing record (wire.py) -- header and weights travel
+        together through ONE RCCL all-gather, straight from device memory."""
+        out = np.empty((self.world, 8 + session.n_edges))
+        self.ctx.check(self._lib.gl_comm_allgather_records(self._h, session._h, float(edge_tol), int(problem_id),
+                                                           int(n_iter), float(theta), int(bool(converged)),
+                                                           _lib.ptr(out)), "comm_allgather_records")
+        return out
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.gl_comm_destroy(self._h)
@@ -163,16 +191,21 @@ class GlooComm:
     def allgather_condensed(self, session, edge_tol=1e-3) -> np.ndarray:
         return self.allgather_arrays(session.weights_condensed(edge_tol))
 
+    def allgather_records(self, session, edge_tol, problem_id, n_iter, theta, converged=False) -> np.ndarray:
+        return self.allgather_arrays(_host_record(session, edge_tol, problem_id, n_iter, theta, converged))
+
     def close(self):
         if self._own and self._dist.is_initialized():
             self._dist.destroy_process_group()
 
 
-def make_comm(rank: int, world: int, local_rank: int = 0, ctx: _lib.Context | None = None, backend: str | None = None):
+def make_comm(rank: int, world: int, local_rank: int = 0, ctx: _lib.Context | None = None, backend: str | None = None,
+              allow_fallback: bool = True):
     """RCCL by default; ``GRAPHLEARN_AMD_COMM=gloo`` (or backend="gloo") selects the host-staged
     torch.distributed/gloo communicator.  If RCCL cannot be brought up at all (library missing,
     communicator init error on every rank) the gloo communicator is used instead and says so
-    (``comm.kind``) -- a slower gather, never a silent change of the solver."""
+    (``comm.kind == "gloo-fallback"``) -- a slower gather, never a silent change of the solver; with
+    ``allow_fallback=False`` (bench.py) the RCCL error is raised instead."""
     if world <= 1:
         return SingleComm()
     backend = backend or os.environ.get("GRAPHLEARN_AMD_COMM", "rccl")
@@ -185,6 +218,8 @@ def make_comm(rank: int, world: int, local_rank: int = 0, ctx: _lib.Context | No
         c.kind = "rccl"
         return c
     except (_lib.GraphLearnError, TimeoutError, OSError) as exc:
+        if not allow_fallback:
+            raise
         print(f"[graph_learning_amd] rank {rank}: RCCL communicator unavailable ({exc}); falling back to gloo",
               flush=True)
         c = GlooComm(rank, world)
@@ -231,16 +266,23 @@ class LogModelBatch:
     """``LogModel`` over a batch of signal matrices, one problem per GPU at a time.
 
     Every rank passes the same list ``xs`` (each (n_samples, n_nodes), same n_nodes); rank r fits
-    xs[r], xs[r + W], ...; after each round the condensed weights are all-gathered with RCCL
-    straight from device memory.  ``weights_`` is the (len(xs), E) array on every rank.
+    xs[r], xs[r + W], ...; after each round every rank's result is all-gathered as ONE self-describing
+    record (``wire``: 64-byte header with problem id, theta, iteration count and flags, then the condensed
+    thresholded weights) -- with RCCL straight from device memory -- so ``weights_``, ``theta_``, ``n_iter_``
+    and ``converged_`` of EVERY problem are right on every rank, whoever solved it.
+
+    ``session_factory(n_nodes, ctx)`` defaults to the device session (``_lib.LogDegreeSession``); the CPU
+    tests of the distribution logic pass an oracle-backed stand-in with the same methods.
     """
 
-    def __init__(self, avg_degree=None, *, maxit=1000, tol=1e-5, step_size=0.5, edge_tol=1e-3):
+    def __init__(self, avg_degree=None, *, maxit=1000, tol=1e-5, step_size=0.5, edge_tol=1e-3, session_factory=None):
         self.avg_degree, self.maxit, self.tol, self.step_size, self.edge_tol = avg_degree, maxit, tol, step_size, edge_tol
+        self.session_factory = session_factory
 
     def fit(self, xs, comm=None, ctx: _lib.Context | None = None):
+        from . import wire
+
         comm = comm or SingleComm()
-        ctx = ctx or getattr(comm, "ctx", None) or _lib.default_context()
         n_items = len(xs)
         n_nodes = np.asarray(xs[0]).shape[1]
         n_edges = n_nodes * (n_nodes - 1) // 2
@@ -248,28 +290,34 @@ class LogModelBatch:
         self.weights_ = np.zeros((n_items, n_edges))
         self.theta_ = np.ones(n_items)
         self.n_iter_ = np.zeros(n_items, dtype=np.int64)
-        with _lib.LogDegreeSession(n_nodes, ctx) as s:
+        self.converged_ = np.zeros(n_items, dtype=bool)
+        if self.session_factory is not None:
+            session = self.session_factory(n_nodes, ctx)
+        else:
+            session = _lib.LogDegreeSession(n_nodes, ctx or getattr(comm, "ctx", None) or _lib.default_context())
+        with session as s:
             for r in range(rounds):
                 idx = r * comm.world + comm.rank
                 if idx < n_items:
                     theta = s.set_signals(xs[idx], self.avg_degree)
                     s.init(1, 1, self.step_size, None)
-                    n_it, _, _ = s.iterate(self.maxit, self.tol)
-                else:  # idle rank in the last round: contribute the zero iterate
-                    theta, n_it = 1.0, 0
+                    n_it, conv, _ = s.iterate(self.maxit, self.tol)
+                    pid = idx
+                else:  # idle rank in the last round: contribute the zero iterate under problem id -1
+                    theta, n_it, conv, pid = 1.0, 0, False, -1
                     s.set_distances(np.zeros(n_edges))
                     s.init(1, 1, self.step_size, None)
-                gathered = comm.allgather_condensed(s, self.edge_tol)
-                meta = np.array([theta, float(n_it)])
-                metas = comm.allgather_arrays(meta) if hasattr(comm, "allgather_arrays") else None
+                gathered = comm.allgather_records(s, self.edge_tol, pid, n_it, theta, conv)
                 for src in range(comm.world):
                     j = r * comm.world + src
-                    if j < n_items:
-                        self.weights_[j] = gathered[src]
-                        if metas is not None:
-                            self.theta_[j], self.n_iter_[j] = metas[src][0], int(metas[src][1])
-                        elif src == comm.rank:
-                            self.theta_[j], self.n_iter_[j] = theta, n_it
+                    if j >= n_items:
+                        continue
+                    rec = wire.unpack(gathered[src])
+                    if rec["problem_id"] != j or rec["n_nodes"] != n_nodes:
+                        raise RuntimeError(f"gathered record of rank {src} is for problem {rec['problem_id']} "
+                                           f"({rec['n_nodes']} nodes), expected problem {j} ({n_nodes} nodes)")
+                    self.weights_[j] = rec["weights"]
+                    self.theta_[j], self.n_iter_[j], self.converged_[j] = rec["theta"], rec["n_iter"], rec["converged"]
         return self
 
     def records(self):
@@ -277,4 +325,4 @@ class LogModelBatch:
         from . import wire
 
         return [wire.pack(self.weights_[j], problem_id=j, n_iter=int(self.n_iter_[j]), theta=float(self.theta_[j]),
-                          edge_tol=self.edge_tol) for j in range(len(self.weights_))]
+                          edge_tol=self.edge_tol, converged=bool(self.converged_[j])) for j in range(len(self.weights_))]

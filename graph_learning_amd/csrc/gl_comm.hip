@@ -174,3 +174,69 @@ GL_API int gl_comm_allgather_weights(gl_comm *c, gl_logdeg *s, double edge_tol, 
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GL_OK;
 }
+
+// All-gather of a small fp64 vector given in host memory (count doubles per rank -> nranks x count on
+// every rank): per-problem scalars of a batch, e.g. theta and the iteration count.
+GL_API int gl_comm_allgather_f64(gl_comm *c, const double *host_in, int64_t count, double *host_out) {
+    if (!c || !host_in || !host_out || count < 1) return GL_E_INVALID;
+    gl_ctx *ctx = c->ctx;
+    GL_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)(c->nranks + 1) * (size_t)count * 8;  // [send | recv]
+    if (c->gather_bytes < bytes) {
+        if (c->gather) (void)hipFree(c->gather);
+        c->gather = nullptr;
+        c->gather_bytes = 0;
+        GL_HIP(ctx, hipMalloc((void **)&c->gather, bytes));
+        c->gather_bytes = bytes;
+    }
+    GL_HIP(ctx, hipMemcpyAsync(c->gather, host_in, (size_t)count * 8, hipMemcpyHostToDevice, ctx->stream));
+    GL_NCCL(ctx, rccl()->AllGather(c->gather, c->gather + count, (size_t)count, ncclFloat64, c->comm, ctx->stream));
+    GL_HIP(ctx, hipMemcpyAsync(host_out, c->gather + count, (size_t)c->nranks * (size_t)count * 8, hipMemcpyDeviceToHost,
+                               ctx->stream));
+    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GL_OK;
+}
+
+// The gather payload of SURVEY.md section 8 row f-4: every rank contributes ONE self-describing record --
+// the 64-byte header of graph_learning_amd/wire.py (magic "GLAM", version 1, n_nodes, n_edges, problem id,
+// iterations run, theta, edge_tol, flags) followed by its condensed, thresholded weights -- so the header
+// travels THROUGH the collective with the data it describes.  host_out is nranks x (8 + E) doubles.
+GL_API int gl_comm_allgather_records(gl_comm *c, gl_logdeg *s, double edge_tol, int64_t problem_id, int64_t n_iter,
+                                     double theta, int converged, double *host_out) {
+    if (!c || !s) return GL_E_INVALID;
+    gl_ctx *ctx = c->ctx;
+    if (s->ctx != ctx) return gl_set_error(ctx, GL_E_INVALID, "session and communicator live on different contexts");
+    GL_HIP(ctx, hipSetDevice(ctx->device));
+    GL_TRY(gl_logdeg_get_weights_condensed(s, edge_tol, nullptr));  // condensed weights -> s->stage (device only)
+    struct Header {  // little-endian, 64 bytes: the layout of wire.HEADER ("<4sIqqqqddQ")
+        char magic[4];
+        uint32_t version;
+        int64_t n_nodes, n_edges, problem_id, n_iter;
+        double theta, edge_tol;
+        uint64_t flags;
+    } h;
+    static_assert(sizeof(Header) == 64, "record header must be 64 bytes");
+    memcpy(h.magic, "GLAM", 4);
+    h.version = 1;
+    h.n_nodes = s->n;
+    h.n_edges = s->n_edges;
+    h.problem_id = problem_id;
+    h.n_iter = n_iter;
+    h.theta = theta;
+    h.edge_tol = edge_tol;
+    h.flags = converged ? 1u : 0u;
+    GL_TRY(gl_h2d(ctx, s->stage_rec, &h, sizeof h));
+    const size_t rec = (size_t)s->n_edges + 8;
+    const size_t bytes = (size_t)c->nranks * rec * 8;
+    if (c->gather_bytes < bytes) {
+        if (c->gather) (void)hipFree(c->gather);
+        c->gather = nullptr;
+        c->gather_bytes = 0;
+        GL_HIP(ctx, hipMalloc((void **)&c->gather, bytes));
+        c->gather_bytes = bytes;
+    }
+    GL_NCCL(ctx, rccl()->AllGather(s->stage_rec, c->gather, rec, ncclFloat64, c->comm, ctx->stream));
+    if (host_out) GL_HIP(ctx, hipMemcpyAsync(host_out, c->gather, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GL_OK;
+}

@@ -19,11 +19,12 @@ constexpr int GT = 64;   // output tile edge
 constexpr int GK = 16;   // samples per LDS stage
 constexpr int GLD = 80;  // LDS row stride in doubles (64 + 16: ds_read_b64 conflict-free)
 
-// x[t][:] -= mean_j x[t][j]   (one workgroup per sample)
-__global__ __launch_bounds__(256) void k_center_rows(double *__restrict__ x, int64_t d, int64_t n) {
+// xc[t][:] = x[t][:] - mean_j x[t][j]   (one workgroup per sample; x itself is kept for the direct differences)
+__global__ __launch_bounds__(256) void k_center_rows(const double *__restrict__ x, double *__restrict__ xc, int64_t d,
+                                                     int64_t n) {
     __shared__ double s_part[256];
     const int64_t t = blockIdx.x;
-    double *row = x + t * n;
+    const double *row = x + t * n;
     double acc = 0;
     for (int64_t j = threadIdx.x; j < n; j += 256) acc += row[j];
     s_part[threadIdx.x] = acc;
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void k_center_rows(double *__restrict__ x, int
         __syncthreads();
     }
     const double mean = s_part[0] / (double)n;
-    for (int64_t j = threadIdx.x; j < n; j += 256) row[j] -= mean;
+    for (int64_t j = threadIdx.x; j < n; j += 256) xc[t * n + j] = row[j] - mean;
 }
 
 // G[I*64.., J*64..] = sum_t x[t][i] x[t][j].  4 waves in a 2x2 arrangement, each
@@ -99,31 +100,42 @@ __global__ void k_take_diag(const double *__restrict__ G, int64_t n, double *__r
     if (i < n) diag[i] = G[i * n + i];
 }
 
-// in place: G_ij <- max(G_ii + G_jj - 2 G_ij, +0)
-__global__ void k_gram_to_dist(double *__restrict__ G, int64_t n, const double *__restrict__ diag) {
+// in place: G_ij <- max(G_ii + G_jj - 2 G_ij, +0).  The Gram form cancels for near-coincident columns
+// (absolute error ~ eps (G_ii + G_jj)), and those nearest-neighbour distances are exactly the ones theta is
+// built from; the reference takes direct differences (pdist, smooth_learning.py:278).  Where the result is
+// below 2^-10 of G_ii + G_jj it is therefore recomputed as sum_t (x_ti - x_tj)^2 from the ORIGINAL signals, as
+// pdist does (rare: d strided loads per such entry), which restores full relative accuracy.
+__global__ void k_gram_to_dist(double *__restrict__ G, int64_t n, const double *__restrict__ diag,
+                               const double *__restrict__ x, int64_t d) {
     const int64_t i = blockIdx.y;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) {
-        const double z = (diag[i] + diag[j]) - 2 * G[i * n + j];
-        G[i * n + j] = z > 0 ? z : 0.0;
+        const double s = diag[i] + diag[j];
+        double z = s - 2 * G[i * n + j];
+        if (i != j && z < s * 0x1p-10) {
+            double acc = 0;
+            for (int64_t t = 0; t < d; ++t) {
+                const double df = x[t * n + i] - x[t * n + j];
+                acc += df * df;
+            }
+            z = acc;
+        }
+        G[i * n + j] = (i != j && z > 0) ? z : 0.0;
     }
 }
 
 }  // namespace
 
-// x_dev (d x n) is centred IN PLACE; zsq_dev receives the n x n squared distances.
-int gl_gram_distances(gl_ctx *ctx, const double *x_dev, int64_t d, int64_t n, double *zsq_dev) {
-    double *x = const_cast<double *>(x_dev);
-    double *diag = nullptr;
-    GL_HIP(ctx, hipMalloc((void **)&diag, (size_t)n * 8));
-    k_center_rows<<<dim3((unsigned)d), dim3(256), 0, ctx->stream>>>(x, d, n);
+// x_dev (d x n) stays as it is, xc_dev (d x n) receives the centred copy; zsq_dev receives the n x n squared
+// distances; diag_dev is n doubles of scratch.  Stream-ordered: no allocation, no synchronisation.
+int gl_gram_distances(gl_ctx *ctx, const double *x_dev, double *xc_dev, int64_t d, int64_t n, double *zsq_dev,
+                      double *diag_dev) {
+    k_center_rows<<<dim3((unsigned)d), dim3(256), 0, ctx->stream>>>(x_dev, xc_dev, d, n);
     const unsigned nb = (unsigned)((n + GT - 1) / GT);
-    k_gram<<<dim3(nb, nb), dim3(256), 0, ctx->stream>>>(x, d, n, zsq_dev);
-    k_take_diag<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(zsq_dev, n, diag);
-    k_gram_to_dist<<<dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, ctx->stream>>>(zsq_dev, n, diag);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(diag);
-    if (e != hipSuccess) return gl_set_error(ctx, GL_E_HIP, "gram/distance kernels: %s", hipGetErrorString(e));
+    k_gram<<<dim3(nb, nb), dim3(256), 0, ctx->stream>>>(xc_dev, d, n, zsq_dev);
+    k_take_diag<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(zsq_dev, n, diag_dev);
+    k_gram_to_dist<<<dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, ctx->stream>>>(zsq_dev, n, diag_dev, x_dev,
+                                                                                                  d);
+    GL_HIP(ctx, hipGetLastError());
     return GL_OK;
 }

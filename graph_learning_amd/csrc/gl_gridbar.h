@@ -67,9 +67,10 @@ __device__ inline bool gl_grid_barrier(const GlGridBar &G, GlBarState &B, int *s
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned e = ++B.epoch;
-        // level 1 stays inside the XCD: every participant of this counter runs on XCD B.xcc, whose L2
-        // executes the atomic -- no trip to the memory side (workgroup scope = no sc bits)
-        const unsigned a = __hip_atomic_fetch_add(G.bar + 320 + 32 * B.xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
+        // level 1: the counter of my XCD.  Agent scope, as the HSA memory model requires between workgroups
+        // (a workgroup-scope add happens to work -- every participant shares the XCD's L2, which executes it --
+        // and measured 0.3 us faster, but nothing guarantees it across compiler versions)
+        const unsigned a = __hip_atomic_fetch_add(G.bar + 320 + 32 * B.xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
         if (a == B.n_my * e) {  // last of my XCD
             const unsigned t = __hip_atomic_fetch_add(G.bar + 576, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
             if (t == B.nx * e)  // last XCD: release everybody

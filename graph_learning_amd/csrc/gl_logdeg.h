@@ -42,9 +42,12 @@ struct gl_logdeg {
     void *sig_arena = nullptr;    // zsq, theta_terms and xdev (set_signals only), one allocation too
     double *zsq = nullptr;        // n x n squared distances (set_signals only)
     double *stage = nullptr;      // device staging for condensed host transfers (E doubles)
-    double *xdev = nullptr;       // signals (d x n) on device
+    double *stage_rec = nullptr;  // = stage - 8 doubles: room for the 64-byte record header of the gather payload
+    double *xdev = nullptr;       // signals (d x n) on device, followed by their centred copy (another d x n)
     int64_t xdev_elems = 0;
     double *theta_terms = nullptr;  // 2 x n per-row terms of get_theta
+    double *gram_diag = nullptr;    // n Gram diagonal entries (scratch of the distance construction)
+    double *square_out = nullptr;   // n x n scratch of get_weights_square (allocated at its first use, kept)
     int *col_ptr = nullptr, *seg_dest = nullptr;
     int n_segments = 0;
     bool have_z = false, inited = false;
@@ -58,11 +61,14 @@ struct gl_logdeg {
     int wpc = 8;                  // edge waves per CU
     gl_resident *res = nullptr;   // resident engine (register-held iterate), null when not applicable
     bool res_unchecked = false;   // an asynchronous resident launch has not had its error word read yet
-    int64_t res_pending = 0;      // ... and this many iterations were asked of it
+    int64_t res_pending = 0;      // ... and this many iterations were asked of the unchecked launches together
+    double tol_dev = 0.0;         // the tolerance word the streaming kernels see (dstat[2]) ...
+    bool tol_set = false;         // ... once it has been uploaded
 };
 
 // gl_gram.hip
-int gl_gram_distances(gl_ctx *ctx, const double *x_dev, int64_t d, int64_t n, double *zsq_dev);
+int gl_gram_distances(gl_ctx *ctx, const double *x_dev, double *xc_dev, int64_t d, int64_t n, double *zsq_dev,
+                      double *diag_dev);
 // gl_theta.hip
 int gl_theta_from_square(gl_ctx *ctx, const double *zsq_dev, int64_t n, int k, double *terms_dev,
                          double *theta_out);

@@ -862,7 +862,7 @@ GL_API int gl_logdeg_create(gl_ctx *ctx, int64_t n_nodes, gl_logdeg **out) {
         {(void **)&D.ybar, (size_t)D.n_pad * 8}, {(void **)&D.pbar, (size_t)D.n_pad * 8},
         {(void **)&D.rowslab_p, (size_t)D.nb * D.n_pad * 8}, {(void **)&D.rowslab_w, (size_t)D.nb * D.n_pad * 8},
         {(void **)&D.tnorm, (size_t)D.G * 2 * 8},
-        {(void **)&D.dstat, 8 * 8}, {(void **)&s->stage, (size_t)s->n_edges * 8},
+        {(void **)&D.dstat, 8 * 8}, {(void **)&s->stage_rec, (size_t)(s->n_edges + 8) * 8},
         {(void **)&s->col_ptr, ptr.size() * sizeof(int)}, {(void **)&s->seg_dest, dest.size() * sizeof(int)},
         {(void **)&D.colslab, (size_t)std::max(s->n_segments, 1) * 2 * GL_TB * 8}};
     size_t total = 0;
@@ -880,6 +880,7 @@ GL_API int gl_logdeg_create(gl_ctx *ctx, int64_t n_nodes, gl_logdeg **out) {
         }
     }
     D.z = zbuf;
+    s->stage = s->stage_rec + 8;  // the 64-byte record header of the gather payload sits right in front (wire format)
     D.col_ptr = s->col_ptr;
     D.seg_dest = s->seg_dest;
     if ((rc = gl_h2d(ctx, s->col_ptr, ptr.data(), ptr.size() * sizeof(int))) != GL_OK ||
@@ -901,7 +902,7 @@ GL_API int gl_logdeg_destroy(gl_logdeg *s) {
     }
     drop_graph(s);
     gl_resident_free(s);
-    void *ptrs[] = {s->arena, s->sig_arena};
+    void *ptrs[] = {s->arena, s->sig_arena, s->square_out};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete s;
@@ -921,6 +922,7 @@ GL_API int gl_logdeg_set_distances(gl_logdeg *s, const double *z_condensed) {
     s->have_z = true;
     s->have_zsq = false;
     s->theta = 1.0;
+    s->theta_pending = false;  // a theta left on the device by an earlier set_signals belongs to the old distances
     s->inited = false;
     return GL_OK;
 }
@@ -943,17 +945,18 @@ GL_API int gl_logdeg_set_signals(gl_logdeg *s, const double *x, int64_t d, int64
             (void)hipFree(s->sig_arena);
         }
         s->sig_arena = nullptr;
-        s->xdev = s->zsq = s->theta_terms = nullptr;
+        s->xdev = s->zsq = s->theta_terms = s->gram_diag = nullptr;
         s->xdev_elems = 0;
-        const size_t bz = ((size_t)s->n * s->n * 8 + 255) / 256 * 256, bt = ((size_t)2 * s->n * 8 + 255) / 256 * 256;
-        GL_HIP(ctx, hipMalloc(&s->sig_arena, bz + bt + (size_t)xe * 8));
+        const size_t bz = ((size_t)s->n * s->n * 8 + 255) / 256 * 256, bt = ((size_t)3 * s->n * 8 + 255) / 256 * 256;
+        GL_HIP(ctx, hipMalloc(&s->sig_arena, bz + bt + (size_t)2 * xe * 8));  // x and its centred copy
         s->zsq = (double *)s->sig_arena;
         s->theta_terms = (double *)((char *)s->sig_arena + bz);
+        s->gram_diag = s->theta_terms + 2 * s->n;
         s->xdev = (double *)((char *)s->sig_arena + bz + bt);
         s->xdev_elems = xe;
     }
     GL_TRY(gl_h2d(ctx, s->xdev, x, (size_t)xe * 8));
-    GL_TRY(gl_gram_distances(ctx, s->xdev, d, s->n, s->zsq));
+    GL_TRY(gl_gram_distances(ctx, s->xdev, s->xdev + s->xdev_elems, d, s->n, s->zsq, s->gram_diag));
     double theta = 1.0;
     // theta_out == NULL: the caller fetches theta later (gl_logdeg_theta); for n <= 128 it then never leaves the
     // device before the distances are scaled, and a batch of windows goes through without a round trip each
@@ -1036,6 +1039,8 @@ GL_API int gl_logdeg_init(gl_logdeg *s, double alpha, double beta, double step_s
     // stream-ordered from here on; only a start handed over in pageable memory too large for the staging
     // area is still being read by the copy engine
     if (edge_init && edge_bytes > GL_STAGE_BYTES) GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    s->tol_dev = 0.0;  // k_node<true> has just written it
+    s->tol_set = true;
     s->inited = true;
     return GL_OK;
 }
@@ -1045,7 +1050,10 @@ GL_API int gl_logdeg_init(gl_logdeg *s, double alpha, double beta, double step_s
 static bool use_small(const gl_logdeg *s, int64_t iters) { return iters >= 8 && gl_small_applicable(s); }
 static bool use_resident(const gl_logdeg *s, int64_t iters) { return s->res != nullptr && iters >= 16; }
 
-// error word of an earlier asynchronous resident launch (read at the next synchronising call)
+// error word of earlier asynchronous resident launches (read at the next synchronising call).  A launch whose
+// workgroups never met (shared GPU) modifies nothing, records where it stood (ctr[2]) and raises ctr[4] = 1;
+// launches queued behind it see the word and return at once, so everything from ctr[2] on is redone here on
+// the streaming engine.  ctr[4] = 2: a barrier failed after the rendezvous -- an error.
 static int resident_check(gl_logdeg *s) {
     if (!s->res_unchecked) return GL_OK;
     gl_ctx *ctx = s->ctx;
@@ -1054,32 +1062,39 @@ static int resident_check(gl_logdeg *s) {
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     s->res_unchecked = false;
     if (ct[4] == 0) return GL_OK;
-    const int64_t it_before = s->it - s->res_pending;
-    if ((int64_t)ct[2] != it_before)
+    const int64_t stood = (int64_t)ct[2];  // (ctr[1] is re-armed after every launch; ctr[2] = the streaming engine's iteration index)
+    if (ct[4] != 1 || stood < s->it - s->res_pending || stood > s->it)
         return gl_set_error(ctx, GL_E_HIP, "resident engine: grid barrier timed out in mid-run");
-    // the workgroups never met (shared GPU): nothing was modified -- redo the call on the streaming engine
     GL_HIP(ctx, hipMemsetAsync(s->dev.ctr + 4, 0, 8, ctx->stream));
     gl_resident_free(s);
-    s->it = it_before;
-    return launch_iterations(s, s->res_pending);
+    const int64_t redo = s->it - stood;
+    s->it = stood;
+    s->res_pending = 0;
+    return launch_iterations(s, redo);
 }
 
+// tol lives in dstat[2] for the streaming kernels; uploaded only when it changes (the pinned slot is fenced
+// by a stream sync before it is rewritten)
 static int set_tol(gl_logdeg *s, double tol) {
     gl_ctx *ctx = s->ctx;
+    if (s->tol_set && s->tol_dev == tol) return GL_OK;
+    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the slot may still be in flight
     double *slot = (double *)ctx->pinned + 16;
     *slot = tol;
     GL_HIP(ctx, hipMemcpyAsync(s->dev.dstat + 2, slot, 8, hipMemcpyHostToDevice, ctx->stream));
+    s->tol_dev = tol;
+    s->tol_set = true;
     return GL_OK;
 }
 
+// Stream-ordered: nothing here waits for the device (no synchronisation, no read-back) once tol = 0 is in place,
+// so a caller's event bracket around this call contains the kernels only.
 GL_API int gl_logdeg_iterate_async(gl_logdeg *s, int64_t n_iter) {
     GL_TRY(check(s));
     gl_ctx *ctx = s->ctx;
     if (!s->inited) return gl_set_error(ctx, GL_E_STATE, "iterate needs init first");
     if (n_iter < 0) return gl_set_error(ctx, GL_E_INVALID, "n_iter < 0");
     GL_HIP(ctx, hipSetDevice(ctx->device));
-    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the pinned tol slot may still be in flight
-    GL_TRY(resident_check(s));
     GL_TRY(set_tol(s, 0.0));
     if (use_small(s, n_iter)) {  // tol = 0 never stops: the iteration count is known now
         GL_TRY(gl_small_launch(s, n_iter, 0.0));
@@ -1098,10 +1113,11 @@ GL_API int gl_logdeg_iterate_async(gl_logdeg *s, int64_t n_iter) {
         }
         GL_HIP(ctx, hipMemsetAsync(s->dev.ctr, 0, 2 * 8, ctx->stream));
         s->it = itf;
+        s->res_pending = (s->res_unchecked ? s->res_pending : 0) + n_iter;
         s->res_unchecked = true;
-        s->res_pending = n_iter;
         return GL_OK;
     }
+    GL_TRY(resident_check(s));
     return launch_iterations(s, n_iter);
 }
 
@@ -1112,7 +1128,6 @@ GL_API int gl_logdeg_iterate(gl_logdeg *s, int64_t maxit, double tol, int64_t *n
     if (!s->inited) return gl_set_error(ctx, GL_E_STATE, "iterate needs init first");
     if (maxit < 0) return gl_set_error(ctx, GL_E_INVALID, "maxit < 0");
     GL_HIP(ctx, hipSetDevice(ctx->device));
-    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     GL_TRY(resident_check(s));
     LogdegDev &D = s->dev;
     GL_TRY(set_tol(s, tol));
@@ -1243,17 +1258,12 @@ GL_API int gl_logdeg_get_weights_square(gl_logdeg *s, double edge_tol, double *w
     if (!s->inited) return gl_set_error(ctx, GL_E_STATE, "no iterate yet: call init first");
     GL_HIP(ctx, hipSetDevice(ctx->device));
     GL_TRY(resident_check(s));
-    // the square result (n^2) is staged in zsq-sized scratch; allocate on demand
-    double *sq = nullptr;
-    GL_HIP(ctx, hipMalloc((void **)&sq, (size_t)s->n * s->n * 8));
-    k_to_square<<<dim3((unsigned)s->dev.ntiles), dim3(256), 0, ctx->stream>>>(s->dev.w[s->it & 1], sq, s->n,
+    // the square result (n^2) is staged in session-owned scratch (allocated at the first use, then kept)
+    if (!s->square_out) GL_HIP(ctx, hipMalloc((void **)&s->square_out, (size_t)s->n * s->n * 8));
+    k_to_square<<<dim3((unsigned)s->dev.ntiles), dim3(256), 0, ctx->stream>>>(s->dev.w[s->it & 1], s->square_out, s->n,
                                                                            s->dev.nb, edge_tol);
-    hipError_t e = hipGetLastError();
-    int rc = GL_OK;
-    if (e == hipSuccess) rc = gl_d2h(ctx, w_out, sq, (size_t)s->n * s->n * 8);  // returns with the data in place
-    (void)hipFree(sq);
-    if (e != hipSuccess) return gl_set_error(ctx, GL_E_HIP, "get_weights_square: %s", hipGetErrorString(e));
-    return rc;
+    GL_HIP(ctx, hipGetLastError());
+    return gl_d2h(ctx, w_out, s->square_out, (size_t)s->n * s->n * 8);  // returns with the data in place
 }
 
 GL_API int gl_logdeg_get_dual(gl_logdeg *s, double *d_out) {
@@ -1411,7 +1421,6 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
     for (int a = 0; a < B; ++a) {
         GL_TRY(resident_check(sessions[a]));
         GL_TRY(set_tol(sessions[a], 0.0));  // the per-graph rule never fires; the coupled rule is evaluated here
-        GL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // one pinned slot: let the copy land before the next
     }
     const LogdegDev &D0 = sessions[0]->dev;
     const int64_t n_tiled = D0.ntiles * GL_TILE_ELEMS;

@@ -246,9 +246,13 @@ __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
     const int frow1 = fr0 + 1 < fr1 && P.KF > 1 ? P.col_ent[P.F + slot * P.KF + 1] : 0;
     const GlGridBar gb{P.bar, P.rendezvous};
     GlBarState bs{};
+    // an earlier launch of this session failed (workgroups not co-resident) and has not been looked at yet:
+    // stay out of the way, the host redoes everything from where that launch stood
+    if (P.ctr[4] != 0) return;
     if (tid == 0) s_ok = gl_barrier_setup(gb, bs) ? 1 : 0;
     __syncthreads();
     bool ok = s_ok != 0;
+    const bool met = ok;
     int done_iters = 0;
     int stopped = 0;
 
@@ -534,7 +538,7 @@ __global__ __launch_bounds__(RT, 2) void k_resident(ResDev P) {
         P.ctr[1] = itf;
         P.ctr[2] = itf;
         P.ctr[3] = itf > 0 ? itf - 1 : 0;
-        P.ctr[4] = ok ? 0 : 1;  // barrier failure
+        P.ctr[4] = ok ? 0 : (met ? 2 : 1);  // 1: the workgroups never met (nothing modified); 2: a barrier failed in mid-run
     }
 }
 
@@ -717,7 +721,7 @@ int gl_resident_finish(gl_logdeg *s, int64_t *iters_done, bool *stopped, bool *n
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *not_resident = false;
     if (ct[4] != 0) {
-        if ((int64_t)ct[1] != s->it)
+        if (ct[4] != 1 || (int64_t)ct[1] != s->it)
             return gl_set_error(ctx, GL_E_HIP, "resident engine: grid barrier timed out in mid-run");
         *not_resident = true;
         GL_HIP(ctx, hipMemsetAsync(s->dev.ctr, 0, 2 * 8, ctx->stream));

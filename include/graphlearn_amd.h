@@ -188,6 +188,15 @@ int gl_comm_allreduce_max(gl_comm *c, double *value);
 /* All-gather of the condensed, thresholded weights (E doubles per rank) straight
  * from device memory; host_out is (nranks, E) or NULL. */
 int gl_comm_allgather_weights(gl_comm *c, gl_logdeg *s, double edge_tol, double *host_out);
+/* All-gather of a small host-resident fp64 vector: count doubles per rank in, (nranks, count) out. */
+int gl_comm_allgather_f64(gl_comm *c, const double *host_in, int64_t count, double *host_out);
+/* The gather payload: one self-describing record per rank -- the 64-byte header of
+ * graph_learning_amd/wire.py (magic, version, n_nodes, n_edges, problem id, iterations, theta, edge_tol,
+ * flags bit 0 = stopped on the tolerance) followed by the E condensed, thresholded weights -- gathered
+ * device-to-device; host_out is (nranks, 8 + E) doubles or NULL.  The reference keeps results as ndarray
+ * attributes (smooth_learning.py:299-300: theta_, weights_); this is their wire form. */
+int gl_comm_allgather_records(gl_comm *c, gl_logdeg *s, double edge_tol, int64_t problem_id, int64_t n_iter,
+                              double theta, int converged, double *host_out);
 
 /* ---- Laplacian-constrained GMRF (graph_learn/lgmrf.py, graph_learn/evaluation.py) ---- */
 /* relative_error(y_true, y_pred) (evaluation.py:8-25): ||pred-true||_F / ||true||_F, or the

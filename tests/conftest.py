@@ -24,6 +24,17 @@ def golden():
     return load_golden
 
 
+def c3_covariance(x32):
+    """S = X'X / d of the lgmrf_c3 fixture, rebuilt exactly as tests/golden/make_golden.py built it:
+    float32 signals widened to float64, summed sample by sample with elementwise operations only."""
+    x = np.asarray(x32, dtype=np.float64)
+    d, n = x.shape
+    cov = np.zeros((n, n))
+    for t in range(d):
+        cov += np.outer(x[t], x[t])
+    return cov / d
+
+
 def pytest_collection_modifyitems(config, items):
     """GPU tests are selected with -m gpu; without a device they are skipped, not failed."""
     have = None

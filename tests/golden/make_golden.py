@@ -346,7 +346,58 @@ def gen_clustering():
     save("clustering", **arrays)
 
 
+def c3_covariance(x):
+    """S = X'X / d summed sample by sample with elementwise operations only (no BLAS), so that the
+    test rebuilds bit-identical input from the stored signals on any machine."""
+    d, n = x.shape
+    cov = np.zeros((n, n))
+    for t in range(d):
+        cov += np.outer(x[t], x[t])
+    return cov / d
+
+
+def gen_lgmrf_c3():
+    """LGMRF on inputs shaped like BASELINE configs[2] (S = X'X/d, X ~ N(0, (L+I)^-1), d = n/4 < n: rank
+    deficient, mean(S) ~ 1e-3).  lgmrf.py:169-226 after a capped number of cycles: n = 512 after two
+    (full matrices, ~24 s) and n = 1024 after one (~85 s; diagonal, sampled rows and norms: this is the case
+    DESIGN.md section 5 cites for the reference's own blow-up on this input).  The signals are stored in
+    float32 (the input IS their float64 widening) to keep the fixture small."""
+    from scipy.linalg import solve_triangular
+
+    arrays = {}
+    for n, d, cycles in ((512, 128, 2), (1024, 256, 1)):
+        rng = default_rng(7)
+        lap = sample_er_laplacian(n, 6.0 / n, 0.3, 2.0, seed=rng)
+        chol = np.linalg.cholesky(lap + np.eye(n))
+        x = solve_triangular(chol, rng.standard_normal((n, d)), lower=True, trans="T").T
+        x32 = x.astype(np.float32)
+        cov = c3_covariance(x32.astype(np.float64))
+        m = ref_lgmrf.LGMRF(max_cycle=cycles).fit(cov.copy())
+        iu = np.triu_indices(n)
+        tag = f"n{n}"
+        arrays[f"{tag}_x32"] = x32
+        arrays[f"{tag}_cycles"] = np.int64(cycles)
+        arrays[f"{tag}_cov_mean"] = np.float64(cov.mean())
+        arrays[f"{tag}_conv"] = np.int64(m.converged_)
+        rows = np.array([0, n // 2 - 3, n - 1])
+        arrays[f"{tag}_rows"] = rows
+        if n == 512:
+            arrays[f"{tag}_lapl_triu"] = m.laplacian_[iu]
+        else:
+            arrays[f"{tag}_lapl_diag"] = np.diag(m.laplacian_).copy()
+            arrays[f"{tag}_lapl_rows"] = m.laplacian_[rows].copy()
+            arrays[f"{tag}_lapl_fro"] = np.float64(np.linalg.norm(m.laplacian_))
+            arrays[f"{tag}_lapl_absmax"] = np.float64(np.abs(m.laplacian_).max())
+        arrays[f"{tag}_inv_diag"] = np.diag(m.inv_laplacian_).copy()
+        arrays[f"{tag}_inv_rows"] = m.inv_laplacian_[rows].copy()
+        print(tag, "max|Theta| =", np.abs(m.laplacian_).max(), " mean(S) =", cov.mean(), flush=True)
+    save("lgmrf_c3", **arrays)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["lgmrf_c3"]:      # the two-minute one on its own
+        gen_lgmrf_c3()
+        sys.exit(0)
     gen_sum_squareform()
     gen_theta()
     gen_logmodel()
@@ -355,3 +406,4 @@ if __name__ == "__main__":
     gen_operators()
     gen_graphdict()
     gen_clustering()
+    gen_lgmrf_c3()

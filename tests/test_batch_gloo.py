@@ -41,6 +41,55 @@ WORKER = textwrap.dedent("""
 """)
 
 
+# A LogModelBatch-shaped run: the driver of graph_learning_amd.batch with its device session replaced by an
+# oracle-backed stand-in (same methods).  Problems get DIFFERENT theta (avg_degree rule) and DIFFERENT
+# iteration counts (converge mode), so a header that did not travel with its weights would show.
+BATCH_WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, os.environ["GL_ROOT"])
+    from scipy.spatial.distance import squareform
+    from graph_learning_amd.batch import GlooComm, LogModelBatch
+    from graph_learning_amd import wire
+    from oracle import logdeg as old
+
+    class OracleSession:
+        def __init__(self, n, ctx=None):
+            self.n, self.n_edges = n, n * (n - 1) // 2
+        def __enter__(self): return self
+        def __exit__(self, *a): pass
+        def set_signals(self, x, k):
+            self.z = old.signal_distances(x)
+            theta = 1.0 if k is None else old.theta_for_degree(squareform(self.z), k)
+            self.z = self.z * theta
+            return theta
+        def set_distances(self, z): self.z = np.asarray(z, dtype=float)
+        def init(self, a, b, step, edge_init): self.par = (a, b, step)
+        def iterate(self, maxit, tol):
+            a, b, step = self.par
+            _, info = old.learn_log_degrees(self.z, a, b, maxit=maxit, tol=tol, step_size=step, edge_tol=-np.inf,
+                                            return_info=True)
+            self.raw = info["raw"]
+            conv = info["rel"][0] < tol and info["rel"][1] < tol
+            return info["n_iter"], conv, info["rel"]
+        def weights_condensed(self, edge_tol=-np.inf):
+            w = self.raw.copy() if hasattr(self, "raw") else np.zeros(self.n_edges)
+            w[w < edge_tol] = 0
+            return w
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    comm = GlooComm(rank, world)
+    rng = np.random.default_rng(11)
+    xs = [rng.standard_normal((20 + 3 * k, 8)) * (1 + k) for k in range(5)]   # 5 problems, 2 ranks: one idle slot
+    b = LogModelBatch(avg_degree=3, maxit=400, tol=1e-3, edge_tol=1e-3, session_factory=OracleSession).fit(xs, comm)
+    recs = np.stack(b.records())
+    np.savez(os.path.join(os.environ["GL_OUT"], f"batch_{rank}.npz"), weights=b.weights_, theta=b.theta_,
+             n_iter=b.n_iter_, converged=b.converged_, records=recs)
+    comm.barrier()
+    comm.close()
+""")
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -80,3 +129,39 @@ def test_world_size_2_gloo(tmp_path):
         z = rng.uniform(0.1, 2.0, size=15)
         _, info = old.learn_log_degrees(z, 1, 1, maxit=40, tol=0.0, edge_tol=-np.inf, return_info=True)
         assert np.array_equal(r0[k], info["raw"])
+
+
+@pytest.mark.timeout(300)
+def test_world_size_2_logmodel_batch_carries_headers(tmp_path):
+    """theta_ / n_iter_ / converged_ of the problems the OTHER rank solved arrive through the gathered
+    record (wire.py header + weights in one all-gather), identically on both ranks."""
+    from scipy.spatial.distance import squareform
+
+    from graph_learning_amd import wire
+    from oracle import logdeg as old
+
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GL_ROOT=ROOT, GL_OUT=str(tmp_path), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, "-c", BATCH_WORKER], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=280)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    r0, r1 = np.load(tmp_path / "batch_0.npz"), np.load(tmp_path / "batch_1.npz")
+    for key in ("weights", "theta", "n_iter", "converged", "records"):
+        assert np.array_equal(r0[key], r1[key]), key
+    rng = np.random.default_rng(11)
+    xs = [rng.standard_normal((20 + 3 * k, 8)) * (1 + k) for k in range(5)]
+    seen_iters = set()
+    for k, x in enumerate(xs):   # problems 1 and 3 were solved by rank 1, the others by rank 0
+        o = old.LogModelOracle(avg_degree=3, maxit=400, tol=1e-3, edge_tol=1e-3).fit(x)
+        assert r0["theta"][k] == o.theta_ and r0["n_iter"][k] == o.info_["n_iter"]
+        assert bool(r0["converged"][k]) == (o.info_["n_iter"] < 400)
+        assert np.array_equal(squareform(r0["weights"][k]), o.weights_)
+        rec = wire.unpack(r0["records"][k])
+        assert (rec["problem_id"], rec["n_nodes"], rec["n_iter"], rec["theta"]) == (k, 8, o.info_["n_iter"], o.theta_)
+        seen_iters.add(int(r0["n_iter"][k]))
+    assert len(set(r0["theta"])) == 5 and len(seen_iters) > 1   # the headers really differ per problem

@@ -10,7 +10,9 @@ so final matrices are compared to 1e-6 relative to their scale, and `converged_`
 import numpy as np
 import pytest
 
+from conftest import c3_covariance
 from graph_learning_amd import LGMRF, nonnegative_qp_solver, relative_error
+from graph_learning_amd.synth import er_laplacian
 from oracle import lgmrf as olg
 
 pytestmark = pytest.mark.gpu
@@ -154,3 +156,102 @@ def test_qp_solver_mid_sizes(n):
         assert abs(iters - ref_iters) <= 1
         if iters == ref_iters:
             np.testing.assert_allclose(z, zr, rtol=0, atol=1e-10)
+
+
+# ------------------------------------------------------------------ BASELINE configs[2] shape
+LARGE_FORMS = ("auto", "tagged", "resident", "launch")
+
+
+def triu_to_square(v, n):
+    m = np.zeros((n, n))
+    m[np.triu_indices(n)] = v
+    return m + np.triu(m, 1).T
+
+
+@pytest.mark.parametrize("path", [1, 2])
+def test_lgmrf_c3_shape_n512_against_reference_fixture(golden, admm_form, path):
+    """Input shaped like BASELINE configs[2] (S = X'X/d, X ~ N(0, (L+I)^-1), d = n/4: rank deficient,
+    mean(S) = 2e-3), n = 512, two cycles of lgmrf.py:169-226 -- against the matrices the REFERENCE produced
+    (tests/golden/make_golden.py::gen_lgmrf_c3).  On this input every QP runs its 100 ADMM steps and the
+    iterate grows (max|Theta| = 22.58 after two cycles): the comparison is relative to that scale, and the
+    tolerance is 1e-6 because the input amplifies rounding (NumPy itself moves by 2e-9 relative when only the
+    BLAS thread count changes, tests/test_oracle_golden.py)."""
+    if admm_form not in LARGE_FORMS:
+        pytest.skip("single-wave / single-workgroup forms end at n = 160")
+    if path == 1 and admm_form != "auto":
+        pytest.skip("the general path (explicit Gauss-Jordan inverse per node) once: ~10 s at this size")
+    g = golden("lgmrf_c3")
+    n = 512
+    cov = c3_covariance(g["n512_x32"])
+    assert cov.mean() == float(g["n512_cov_mean"])                      # bit-identical input
+    m = LGMRF(max_cycle=int(g["n512_cycles"])).fit(cov.copy(), path=path)
+    ref = triu_to_square(g["n512_lapl_triu"], n)
+    scale = np.abs(ref).max()
+    assert scale == pytest.approx(22.578421533059075, rel=1e-12)
+    assert m.converged_ == int(g["n512_conv"]) == -1 and m.n_cycles_ == 2
+    err = np.abs(m.laplacian_ - ref).max() / scale
+    print(f"[lgmrf c3 n=512 form={admm_form} path={path}] max|Theta - ref| / max|ref| = {err:.2e}")
+    assert err < 1e-6
+    rows = g["n512_rows"]
+    assert np.abs(m.inv_laplacian_[rows] - g["n512_inv_rows"]).max() <= 1e-6 * np.abs(g["n512_inv_rows"]).max()
+    assert np.abs(np.diag(m.inv_laplacian_) - g["n512_inv_diag"]).max() <= 1e-6 * np.abs(g["n512_inv_diag"]).max()
+    assert np.array_equal(m.laplacian_, m.laplacian_.T)
+
+
+def test_lgmrf_c3_shape_n1024_blow_up_matches_reference(golden, admm_form):
+    """n = 1024, d = 256, ONE cycle: the reference itself diverges on this input (max|Theta| = 1.5348e4 after
+    the cycle, fixture made by the reference in 85 s); the device path reproduces diagonal, sampled rows,
+    Frobenius norm and maximum.  This is the evidence for DESIGN.md section 5 ("C3 as specified is ill-posed")."""
+    if admm_form != "auto":
+        pytest.skip("once, on the default form")
+    g = golden("lgmrf_c3")
+    cov = c3_covariance(g["n1024_x32"])
+    assert cov.mean() == float(g["n1024_cov_mean"])
+    m = LGMRF(max_cycle=1).fit(cov.copy())
+    scale = float(g["n1024_lapl_absmax"])
+    assert scale == pytest.approx(15348.155995583951, rel=1e-12)
+    assert m.converged_ == -1 and m.n_cycles_ == 1
+    rows = g["n1024_rows"]
+    e_rows = np.abs(m.laplacian_[rows] - g["n1024_lapl_rows"]).max() / scale
+    e_diag = np.abs(np.diag(m.laplacian_) - g["n1024_lapl_diag"]).max() / scale
+    print(f"[lgmrf c3 n=1024] rows {e_rows:.2e} diag {e_diag:.2e} (relative to max|Theta| = {scale:.6g})")
+    assert e_rows < 1e-5 and e_diag < 1e-5        # 1.5e4-fold growth in one cycle: rounding is amplified accordingly
+    assert np.abs(m.laplacian_).max() == pytest.approx(scale, rel=1e-5)
+    assert np.linalg.norm(m.laplacian_) == pytest.approx(float(g["n1024_lapl_fro"]), rel=1e-5)
+    assert np.abs(m.inv_laplacian_[rows] - g["n1024_inv_rows"]).max() <= 1e-5 * np.abs(g["n1024_inv_rows"]).max()
+
+
+def test_lgmrf_c3_full_size_one_cycle_properties(admm_form):
+    """BASELINE configs[2] at full size (n = 2048, d = 512), one cycle = 2048 node updates: size-independent
+    properties of a block-coordinate cycle -- Theta symmetric, Theta C = I (C is maintained by rank-one
+    updates, lgmrf.py:207-219), non-positive off-diagonals, C_uu = K_uu for the last node (lgmrf.py:213),
+    bit-reproducible
+    -- and the ms per node update printed for the record."""
+    import time
+
+    from scipy.linalg import solve_triangular
+
+    if admm_form not in ("auto", "tagged"):
+        pytest.skip("the default (tagged) form; the others are covered at n = 512")
+    n, d = 2048, 512
+    rng = np.random.default_rng(7)
+    lap = er_laplacian(n, 6.0 / n, 0.3, 2.0, seed=rng)
+    x = solve_triangular(np.linalg.cholesky(lap + np.eye(n)), rng.standard_normal((n, d)), lower=True, trans="T").T
+    cov = x.T @ x / d
+    t0 = time.perf_counter()
+    m = LGMRF(max_cycle=1).fit(cov.copy())
+    dt = time.perf_counter() - t0
+    print(f"[lgmrf c3 n=2048 d=512 form={admm_form}] one cycle {dt:.2f} s = {1e3 * dt / n:.3f} ms per node update "
+          f"(transfers included), max|Theta| = {np.abs(m.laplacian_).max():.4g}")
+    th, c = m.laplacian_, m.inv_laplacian_
+    assert m.n_cycles_ == 1 and m.converged_ == -1
+    assert np.isfinite(th).all() and np.isfinite(c).all()
+    assert np.array_equal(th, th.T) and np.array_equal(c, c.T)
+    assert (th[~np.eye(n, dtype=bool)] <= 0).all()
+    k = cov / cov.mean() + 2 * np.eye(n) - 1.0                         # lgmrf.py:229, 154-161 (type 1)
+    assert c[n - 1, n - 1] == pytest.approx(k[n - 1, n - 1], rel=1e-12)   # the last node updated (lgmrf.py:213)
+    resid = np.abs(th @ c - np.eye(n)).max()
+    print(f"[lgmrf c3 n=2048] max|Theta C - I| = {resid:.2e}")
+    assert resid < 1e-6 * max(1.0, np.abs(th).max() * np.abs(c).max())
+    m2 = LGMRF(max_cycle=1).fit(cov.copy())
+    assert np.array_equal(m2.laplacian_, th) and np.array_equal(m2.inv_laplacian_, c)

@@ -206,6 +206,32 @@ def test_c2_size_five_iterations_against_oracle():
     np.testing.assert_allclose(d, info["dual"], rtol=0, atol=ATOL)
 
 
+def test_c2_size_persistent_engine_against_oracle(engine):
+    """The kernel bench.py times -- the persistent engine at n=4096, d=1024, all iterations of a call in ONE
+    launch -- against the oracle (smooth_learning.py:146-167): 17 + 23 iterations in two launches (the
+    second starts from an odd iteration count), w and the dual variable to 1e-10."""
+    if engine == "stream":
+        pytest.skip("the streaming engine at this size is covered by the five-iteration test")
+    x, _ = logmodel_problem(4096, 1024, seed=1)
+    z_ref = old.signal_distances(x)
+    zt = z_ref * old.theta_for_degree(squareform(z_ref), 10)
+    with _lib.LogDegreeSession(4096) as s:
+        s.set_distances(zt)
+        s.init(1, 1, 0.5, None)
+        assert s.engine == "resident"          # forced ("resident") and the automatic choice ("small" does not apply)
+        n_it, conv, rel17 = s.iterate(17, 0.0)
+        assert n_it == 17 and not conv and s.engine == "resident"
+        n_it, conv, rel = s.iterate(23, 0.0)
+        assert n_it == 23 and not conv and s.total_iterations == 40
+        w = s.weights_condensed()
+        d = s.dual()
+    _, info = old.learn_log_degrees(zt, 1, 1, maxit=40, tol=0.0, edge_tol=-np.inf, return_info=True)
+    np.testing.assert_allclose(w, info["raw"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(d, info["dual"], rtol=0, atol=ATOL)
+    assert rel[0] == pytest.approx(info["rel"][0], rel=1e-9)
+    assert rel[1] == pytest.approx(info["rel"][1], rel=1e-9)
+
+
 def test_c2_size_properties_after_many_iterations():
     """Size-independent properties at n=4096 after 300 iterations: determinism, dual = prox
     fixed-point structure (dvar < 0), symmetry of the square output, degree identity."""
@@ -298,3 +324,35 @@ def test_deferred_theta_is_the_same_theta(n):
         w2 = s.weights_condensed(-np.inf)
         assert s.theta() == t1
         assert np.array_equal(w1, w2)
+
+
+def test_near_coincident_columns_keep_relative_accuracy():
+    """Columns that almost coincide: the Gram form G_ii + G_jj - 2 G_ij cancels there, the reference takes
+    direct differences (pdist, smooth_learning.py:278).  The device path recomputes such entries directly:
+    the smallest distances -- the ones theta is built from -- keep full relative accuracy."""
+    rng = np.random.default_rng(77)
+    n, d = 96, 300
+    x = rng.standard_normal((d, n)) * 3 + 5.0
+    for (a, b, eps) in ((1, 0, 1e-9), (40, 7, 1e-6), (95, 94, 1e-3), (60, 61, 0.0)):
+        x[:, a] = x[:, b] + eps * rng.standard_normal(d)
+    z_ref = old.signal_distances(x)
+    with _lib.LogDegreeSession(n) as s:
+        theta = s.set_signals(x, 4)
+        z = s.get_distances()
+    sq, sq_ref = squareform(z), squareform(z_ref)
+    assert sq[60, 61] == 0.0 == sq_ref[60, 61]
+    for (a, b) in ((1, 0), (40, 7), (95, 94)):
+        assert sq[a, b] == pytest.approx(sq_ref[a, b], rel=1e-12), (a, b)
+    mask = z_ref > 0
+    assert np.max(np.abs(z[mask] - z_ref[mask]) / z_ref[mask]) < 1e-11
+    assert theta == pytest.approx(old.theta_for_degree(sq_ref, 4), rel=1e-10)
+
+
+def test_set_distances_after_deferred_theta_resets_theta():
+    """A theta left on the device by set_signals(deferred) belongs to those distances: after set_distances the
+    session's theta is 1 again."""
+    x = np.random.default_rng(4).standard_normal((60, 20))
+    with _lib.LogDegreeSession(20) as s:
+        assert s.set_signals(x, 3, deferred=True) is None
+        s.set_distances(np.ones(190))
+        assert s.theta() == 1.0

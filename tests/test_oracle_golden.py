@@ -189,3 +189,26 @@ def test_operators_golden(golden, seed):
 def test_squared_pdiffs_golden(golden):
     g = golden("operators")
     assert np.array_equal(oop.squared_pdiffs(g["signals"]), g["sq_pdiffs"])
+
+
+def test_lgmrf_oracle_c3_shape_n512_equals_reference(golden):
+    """The oracle on the BASELINE-configs[2]-shaped input (n = 512, d = 128, two cycles; ~25 s) against
+    the reference's own output (lgmrf.py:169-226; make_golden.py::gen_lgmrf_c3): the growth of the iterate
+    on this rank-deficient input (max|Theta| = 22.58) is the reference algorithm's, not an artefact."""
+    from conftest import c3_covariance
+    from oracle import lgmrf as olg
+
+    g = golden("lgmrf_c3")
+    cov = c3_covariance(g["n512_x32"])
+    assert cov.mean() == float(g["n512_cov_mean"])
+    o = olg.LGMRFOracle(max_cycle=2).fit(cov.copy())
+    ref = g["n512_lapl_triu"]
+    got = o.laplacian_[np.triu_indices(512)]
+    assert np.abs(ref).max() == pytest.approx(22.578421533059075, rel=1e-12)
+    # The input is ill-conditioned (K has a large negative eigenvalue), so rounding differences are amplified:
+    # the same NumPy with another BLAS thread count (4 at generation, the machine's default here) already
+    # moves the result by 2e-9 relative.  1e-7 is the bar; bit equality is not available on this input.
+    assert np.abs(got - ref).max() <= 1e-7 * np.abs(ref).max()
+    assert o.converged_ == int(g["n512_conv"]) and min(o.qp_iters_) == 100     # every QP ran into its cap
+    rows = g["n512_rows"]
+    assert np.abs(o.inv_laplacian_[rows] - g["n512_inv_rows"]).max() <= 1e-7 * np.abs(g["n512_inv_rows"]).max()
