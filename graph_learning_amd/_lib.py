@@ -307,7 +307,13 @@ class LogDegreeSession:
     @property
     def engine(self) -> str:
         """"resident", "small" or "stream": the engine long iterate calls of this session run on."""
-        return {1: "resident", 2: "small"}.get(self._lib.gl_logdeg_engine(self._h), "stream")
+        return {1: "resident", 2: "small", 3: "resident"}.get(self._lib.gl_logdeg_engine(self._h), "stream")
+
+    @property
+    def engine_kernel(self) -> str:
+        """The kernel behind ``engine``: "k_tile" (tagged hand-offs, gl_tile.hip) or "k_resident" (grid barriers,
+        gl_resident.hip) for the resident family, "k_small", or "k_edge" for the streaming launches."""
+        return {1: "k_resident", 2: "k_small", 3: "k_tile"}.get(self._lib.gl_logdeg_engine(self._h), "k_edge")
 
     def time_edge_pass(self, reps=200) -> float:
         """Average edge-pass duration in microseconds (HIP events; state unchanged)."""

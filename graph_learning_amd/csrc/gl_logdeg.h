@@ -33,6 +33,7 @@ struct LogdegDev {
 };
 
 struct gl_resident;
+struct gl_tile;
 
 struct gl_logdeg {
     gl_ctx *ctx = nullptr;
@@ -59,7 +60,8 @@ struct gl_logdeg {
     hipGraphExec_t graph = nullptr;
     int graph_iters = 0;
     int wpc = 8;                  // edge waves per CU
-    gl_resident *res = nullptr;   // resident engine (register-held iterate), null when not applicable
+    gl_resident *res = nullptr;   // first resident engine (gl_resident.hip: grid barriers), null when not applicable
+    gl_tile *tile = nullptr;      // tile engine (gl_tile.hip: tagged hand-offs), preferred when it applies
     bool res_unchecked = false;   // an asynchronous resident launch has not had its error word read yet
     int64_t res_pending = 0;      // ... and this many iterations were asked of the unchecked launches together
     double tol_dev = 0.0;         // the tolerance word the streaming kernels see (dstat[2]) ...
@@ -80,6 +82,11 @@ int gl_resident_prepare(gl_logdeg *s);
 void gl_resident_free(gl_logdeg *s);
 int gl_resident_launch(gl_logdeg *s, int64_t iters, double tol);
 int gl_resident_finish(gl_logdeg *s, int64_t *iters_done, bool *stopped, bool *not_resident);
+// gl_tile.hip
+int gl_tile_prepare(gl_logdeg *s);
+void gl_tile_free(gl_logdeg *s);
+int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol);
+void gl_tile_dump_stamps(gl_logdeg *s);
 // gl_small.hip
 bool gl_small_applicable(const gl_logdeg *s);
 int gl_small_launch(gl_logdeg *s, int64_t iters, double tol);

@@ -885,7 +885,7 @@ GL_API int gl_logdeg_create(gl_ctx *ctx, int64_t n_nodes, gl_logdeg **out) {
     D.seg_dest = s->seg_dest;
     if ((rc = gl_h2d(ctx, s->col_ptr, ptr.data(), ptr.size() * sizeof(int))) != GL_OK ||
         (rc = gl_h2d(ctx, s->seg_dest, dest.data(), dest.size() * sizeof(int))) != GL_OK ||
-        (rc = gl_resident_prepare(s)) != GL_OK) {
+        (rc = gl_resident_prepare(s)) != GL_OK || (rc = gl_tile_prepare(s)) != GL_OK) {
         gl_logdeg_destroy(s);
         return rc;
     }
@@ -902,6 +902,7 @@ GL_API int gl_logdeg_destroy(gl_logdeg *s) {
     }
     drop_graph(s);
     gl_resident_free(s);
+    gl_tile_free(s);
     void *ptrs[] = {s->arena, s->sig_arena, s->square_out};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1048,7 +1049,15 @@ GL_API int gl_logdeg_init(gl_logdeg *s, double alpha, double beta, double step_s
 // The resident engine (gl_resident.hip) takes over when it applies and the call is long enough
 // to amortise loading / storing the register-held iterate.  GRAPHLEARN_AMD_ENGINE=stream disables it.
 static bool use_small(const gl_logdeg *s, int64_t iters) { return iters >= 8 && gl_small_applicable(s); }
-static bool use_resident(const gl_logdeg *s, int64_t iters) { return s->res != nullptr && iters >= 16; }
+static bool use_resident(const gl_logdeg *s, int64_t iters) { return (s->tile != nullptr || s->res != nullptr) && iters >= 16; }
+// the persistent launch of the session's resident-family engine: the tile engine where it applies
+static int persistent_launch(gl_logdeg *s, int64_t iters, double tol) {
+    return s->tile ? gl_tile_launch(s, iters, tol) : gl_resident_launch(s, iters, tol);
+}
+static void persistent_free(gl_logdeg *s) {
+    gl_resident_free(s);
+    gl_tile_free(s);
+}
 
 // error word of earlier asynchronous resident launches (read at the next synchronising call).  A launch whose
 // workgroups never met (shared GPU) modifies nothing, records where it stood (ctr[2]) and raises ctr[4] = 1;
@@ -1066,7 +1075,7 @@ static int resident_check(gl_logdeg *s) {
     if (ct[4] != 1 || stood < s->it - s->res_pending || stood > s->it)
         return gl_set_error(ctx, GL_E_HIP, "resident engine: grid barrier timed out in mid-run");
     GL_HIP(ctx, hipMemsetAsync(s->dev.ctr + 4, 0, 8, ctx->stream));
-    gl_resident_free(s);
+    persistent_free(s);
     const int64_t redo = s->it - stood;
     s->it = stood;
     s->res_pending = 0;
@@ -1104,7 +1113,7 @@ GL_API int gl_logdeg_iterate_async(gl_logdeg *s, int64_t n_iter) {
     }
     if (use_resident(s, n_iter)) {
         // tol = 0 never stops: the iteration count and the parity of the final buffer are known now
-        GL_TRY(gl_resident_launch(s, n_iter, 0.0));
+        GL_TRY(persistent_launch(s, n_iter, 0.0));
         const int64_t itf = s->it + n_iter;
         if ((itf & 1) != (s->it & 1)) {
             const size_t bytes = (size_t)s->dev.ntiles * GL_TILE_ELEMS * sizeof(double);
@@ -1153,7 +1162,7 @@ GL_API int gl_logdeg_iterate(gl_logdeg *s, int64_t maxit, double tol, int64_t *n
         int64_t ran = 0;
         bool stopped = false;
         bool not_resident = false;
-        GL_TRY(gl_resident_launch(s, maxit, tol));
+        GL_TRY(persistent_launch(s, maxit, tol));
         GL_TRY(gl_resident_finish(s, &ran, &stopped, &not_resident));
         if (!not_resident) {
             GL_HIP(ctx, hipMemcpyAsync(st, D.dstat, 2 * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1166,7 +1175,7 @@ GL_API int gl_logdeg_iterate(gl_logdeg *s, int64_t maxit, double tol, int64_t *n
             }
             return GL_OK;
         }
-        gl_resident_free(s);  // shared GPU: this session stays on the streaming engine
+        persistent_free(s);  // shared GPU: this session stays on the streaming engine
     }
     const int64_t start = s->it;
     const int64_t end = start + maxit;
@@ -1614,7 +1623,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
 GL_API int gl_logdeg_engine(gl_logdeg *s) {
     if (!s) return 0;
     if (s->inited && gl_small_applicable(s)) return 2;
-    return s->res ? 1 : 0;
+    return s->tile ? 3 : (s->res ? 1 : 0);
 }
 
 GL_API int gl_logdeg_time_edge_pass(gl_logdeg *s, int reps, double *avg_us_out) {

@@ -569,8 +569,8 @@ int gl_resident_prepare(gl_logdeg *s) {
     s->res = nullptr;
     bool forced = false;
     if (const char *e = getenv("GRAPHLEARN_AMD_ENGINE")) {
-        if (!strcmp(e, "stream")) return GL_OK;
-        forced = !strcmp(e, "resident");
+        if (!strcmp(e, "stream") || !strcmp(e, "tile")) return GL_OK;
+        forced = !strcmp(e, "resident") || !strcmp(e, "resident1");
     }
     const LogdegDev &D = s->dev;
     const int ncu = ctx->prop.multiProcessorCount;
@@ -735,7 +735,8 @@ int gl_resident_finish(gl_logdeg *s, int64_t *iters_done, bool *stopped, bool *n
         const size_t bytes = (size_t)D.ntiles * GL_TILE_ELEMS * sizeof(double);
         GL_HIP(ctx, hipMemcpyAsync(D.w[itf & 1], D.w[s->it & 1], bytes, hipMemcpyDeviceToDevice, ctx->stream));
     }
-    if (s->res->dbg) {
+    gl_tile_dump_stamps(s);
+    if (s->res && s->res->dbg) {
         const int NWG = s->res->dev.NWG;
         std::vector<unsigned long long> h((size_t)NWG * 16 * 6);
         (void)hipMemcpy(h.data(), s->res->dbg, h.size() * 8, hipMemcpyDeviceToHost);

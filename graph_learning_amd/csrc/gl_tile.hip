@@ -1,0 +1,1065 @@
+// Tile engine of the log-degree loop: ALL iterations of a call in one persistent launch, the edge iterate w
+// in REGISTERS, the distances z in LDS (and a short register ring for what does not fit), and every
+// inter-workgroup dependency carried by self-validating tagged records instead of grid barriers.
+//
+// Reference path: graph_learn/smooth_learning.py:146-167 (same per-edge arithmetic as gl_logdeg.hip).
+//
+// Why (measured on the first resident engine, gl_resident.hip, n = 4096: 23.4 us per iteration): its edge
+// phase (11.6 us) ran at the pace of the z stream (67 MB per iteration = 5.8 TB/s), and the other half of
+// an iteration was synchronisation: two grid barriers, a node phase on 64 of 252 workgroups, a stopping rule
+// behind a third round trip.  Here
+//   * one workgroup of 4 waves per CU, ONE wave per SIMD with the whole 512-entry register file: a wave owns
+//     C = 1 or 2 bulk tiles (64 x 64 edges each) and keeps their w in 128 registers per tile for the
+//     whole call; the workgroup's 160 KiB of LDS hold z: all 32 row pairs of a tile when C = 1, 16 of 32
+//     when C = 2 -- the other 16 stream through an 8-deep register ring that is refilled early in the pass, so
+//     the memory pipe is quiet when the hand-offs start.  Per iteration and CU 128 KB of z move instead of
+//     256 KB (C = 2), nothing at all for n <= 2880 (C = 1);
+//   * the diagonal tiles ("fringe") are dealt out as groups of <= 4 row pairs to waves that already work on
+//     the same node block; their w AND z stay in registers;
+//   * degree partials are pre-reduced inside the workgroup (LDS, fixed order) to ONE record per node block
+//     the workgroup touches (6-8 instead of 16), published as 16-byte granules {low word, tag}{high word, tag}
+//     with write-through stores; the owner of a node block (workgroup b owns block b) re-reads its records
+//     until every tag matches, updates the dual state -- which lives in the registers of its wave 0 -- and
+//     publishes {d, pbar} of its 64 nodes the same way; edge workgroups re-read the 6-8 blocks they need.
+//     One memory round trip per hand-off, no barrier, no flag ("the data is the flag", recipe R2 of the
+//     CDNA4 guide; the LGMRF ADMM of gl_lgmrf.hip uses the same records);
+//   * the stopping rule of iteration k is evaluated by every workgroup at the top of iteration k + 1, from
+//     records that arrive in the same round trip as the node values, before anything is modified -- and not
+//     at all while tol = 0 (fixed-iteration calls), except once at the end for the values reported.
+// Every sum has a fixed order (no atomics): bit-reproducible run to run.
+//
+// Nothing is written back before the end of the call (w lives in registers, the dual state in registers of
+// the owners), so a launch whose workgroups are not all co-resident (start-up rendezvous, bounded by the wall
+// clock) leaves the session untouched and the host redoes the call on the streaming engine.
+#include <algorithm>
+#include <vector>
+
+#include "gl_gridbar.h"
+#include "gl_lanes.h"
+#include "gl_logdeg.h"
+
+#ifndef GL_TILE_MIN_BULK_TILES
+#define GL_TILE_MIN_BULK_TILES 600
+#endif
+
+namespace {
+
+constexpr int TB = GL_TB;
+constexpr int SLOTS = TB / 2;  // 32 row pairs per tile
+constexpr int NBW = 11;        // node blocks one workgroup may touch
+
+// Geometry of a workgroup.  TW waves, C bulk tiles per wave, RING streamed z row pairs in registers, FR fringe
+// row pairs per wave.  The LDS holds 128 row pairs of z per workgroup: ZRES = 128 / (TW C) per tile.
+struct CfgWide {   // 4 waves x 2 tiles: one wave per SIMD with the whole register file (n up to 4096)
+    static constexpr int TW = 4, C = 2, RING = 8, FR = 4;
+};
+struct CfgPair {   // 8 waves x 1 tile: two waves per SIMD, 256 registers each (n up to 4096)
+    static constexpr int TW = 8, C = 1, RING = 4, FR = 2;
+};
+struct CfgHalf {   // 4 waves x 1 tile, z entirely in LDS, nothing streams (n up to ~2880)
+    static constexpr int TW = 4, C = 1, RING = 1, FR = 4;
+};
+
+typedef unsigned int tl_u4 __attribute__((ext_vector_type(4)));
+
+struct WaveDesc {  // 16 ints
+    int tile[2];   // bulk tile of chunk c (-1: none)
+    int I[2], J[2];
+    int si[2], sj[2];          // slots of I and J in the workgroup's block list
+    int ragged[2];             // the chunk's column block is the ragged last one
+    int fs, fa0, fcnt, fB;     // fringe group: block-list slot, first row pair, count (0: none), diagonal block
+};
+struct WgDesc {  // 64 ints
+    int nblk;
+    int own;             // node block this workgroup owns (-1: none)
+    int own_e0, own_e1;  // its records in `part`
+    int blk[NBW], ent[NBW], rowmask[NBW], colmask[NBW], frmask[NBW];
+    unsigned slice_lo, slice_hi;  // owners: bit r set = workgroup own + r nb takes part (publishes norm records)
+    int active;                   // this workgroup has edges or owns a block (the others leave after the rendezvous)
+    int pad[2];
+};
+static_assert(sizeof(WaveDesc) == 64 && sizeof(WgDesc) == 256, "descriptor sizes");
+
+struct TileDev {
+    double *w;        // tiled iterate buffer: read at the start, written at the end
+    const double *z;  // tiled scaled distances
+    double *dvar, *ybar, *pbar, *dprev;
+    double *bnorm;    // the streaming engine's [2][nb][4] norm partials (kept consistent at the end)
+    double *dstat;
+    long long *ctr;
+    const WaveDesc *wd;
+    const WgDesc *gd;
+    tl_u4 *part;   // [n_entries][2][64] granules: degree partials {S p, S w} of one workgroup for one node block
+    tl_u4 *nval;   // [nb][2][64] granules: {d, pbar} of a node block
+    tl_u4 *wnorm;  // [4][NWG][2] granules: {sum (q-y)^2, sum w^2} of a workgroup (ring by iteration)
+    tl_u4 *bnrm;   // [4][nb][4] granules: norm partials of a node block and of its slice of wnorm
+    unsigned *bar;  // rendezvous words (gl_gridbar.h layout)
+    unsigned long long *dbg;  // development only (GRAPHLEARN_AMD_RES_STAMPS=1): per-workgroup phase stamps
+    int64_t n, nb;
+    int NWG, n_entries;
+    double gamma, c, g2, a4g, tol;
+    long long it0;
+    int maxit;
+    unsigned tag0;
+    int rendezvous;
+};
+
+__device__ __forceinline__ double tl_val(tl_u4 g) {
+    return __longlong_as_double((long long)(((unsigned long long)g.z << 32) | g.x));
+}
+__device__ __forceinline__ tl_u4 tl_gran(double v, unsigned tag) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    tl_u4 g;
+    g.x = (unsigned)b, g.y = tag, g.z = (unsigned)(b >> 32), g.w = tag;
+    return g;
+}
+__device__ __forceinline__ bool tl_ok(tl_u4 g, unsigned tag) { return g.y == tag && g.w == tag; }
+
+// false: give up (error word raised by somebody, or one second without progress)
+__device__ __forceinline__ bool tl_spin(unsigned &spins, unsigned long long t0, unsigned *err) {
+    __builtin_amdgcn_s_sleep(2);
+    if ((++spins & 63u) == 0u) {
+        if (gl_ld_u32(err) != 0u) return false;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+    return true;
+}
+
+__device__ __forceinline__ double2 tl_ldz(const double *base, unsigned byte_off) {
+    return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
+// One bulk tile: 32 row pairs, w in registers.  Row pairs s < NS come through the register ring (shared by
+// the wave's chunks: the stream of an iteration is chunk 0's first NS row pairs, then chunk 1's), the others
+// from the tile's LDS slice.  Row sums by a halving butterfly per 8 row pairs, column sums in registers;
+// everything leaves through LDS (s_out: [4][64] = row p, row w, column p, column w).
+template <class K, bool RAGGED, bool NORMS, int CI>
+__device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[SLOTS], double2 (&zr)[K::RING], const double2 *zl,
+                                              const unsigned (&zb)[2], const bool (&has)[2], const double2 *s_rows,
+                                              const double dj0, const double dj1, const double pj0, const double pj1,
+                                              const double m0, const double m1, double *s_out, const int lane, double &nqy,
+                                              double &nw) {
+    constexpr int C = K::C, RING = K::RING;
+    constexpr int NS = SLOTS - 128 / (K::TW * K::C);  // streamed row pairs per chunk
+    const int half = lane >> 5, c0 = 2 * (lane & 31);
+    const double c = P.c, g = P.gamma, g2 = P.g2;
+    double colp0 = 0, colp1 = 0, colw0 = 0, colw1 = 0;
+    // One wave per SIMD: nobody hides an LDS round trip, so the LDS operands of row pair s + 1 are requested
+    // before row pair s is computed (the empty asm after every row pair is a scheduling boundary).
+    // LDS-resident z is stored pre-multiplied (2 gamma z, rounded as the product is in the reference, :150).
+    double2 rv_n = s_rows[half];
+    double2 zl_n = double2{0.0, 0.0};
+    if (NS == 0) zl_n = zl[0];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        double rowp[8], roww[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int s = 8 * gq + k;
+            double2 gz;  // 2 gamma z of this row pair
+            if (s < NS) {
+                const int pos = (CI * NS + s) % RING;
+                gz = double2{g2 * zr[pos].x, g2 * zr[pos].y};
+                // refill: element e of the stream (wraps into the next iteration: z never changes)
+                const int e = CI * NS + s + RING;
+                const int tc = (e / (NS > 0 ? NS : 1)) % C, ts = e % (NS > 0 ? NS : 1);
+                // (a wave with one tile only: its stream is that tile's row pairs alone, same positions)
+                zr[pos] = tl_ldz(P.z, (has[tc] ? zb[tc] : zb[CI]) + (unsigned)(ts * (2 * TB) * 8));
+            } else {
+                gz = zl_n;
+            }
+            const double2 rv = rv_n;  // {d_i, pbar_i}: one address per half-wave (broadcast)
+            if (s + 1 < SLOTS) {
+                rv_n = s_rows[2 * (s + 1) + half];
+                if (s + 1 >= NS) zl_n = zl[(s + 1 - NS) * 64];
+            }
+            const double di = rv.x, pi = rv.y;
+            const double2 wv = wreg[s];
+            double wn[2], pp[2], nq2[2], nw2[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const double w = e ? wv.y : wv.x;
+                const double y = c * w - g * (di + (e ? dj1 : dj0));   // :147
+                const double tt = y - (e ? gz.y : gz.x);               // :150
+                const double pr = tt > 0 ? tt : 0.0;
+                const double q = c * pr - g * (pi + (e ? pj1 : pj0));  // :153
+                if (RAGGED) {
+                    const double m = e ? m1 : m0;
+                    wn[e] = m * ((w - y) + q);
+                    pp[e] = m * pr;
+                } else {
+                    wn[e] = (w - y) + q;  // :163
+                    pp[e] = pr;
+                }
+                if (NORMS) {
+                    const double dq = q - y;  // == -y + q (:158)
+                    nq2[e] = RAGGED ? (e ? m1 : m0) * (dq * dq) : dq * dq;
+                    nw2[e] = w * w;
+                }
+            }
+            if (NORMS) {
+                nqy += nq2[0] + nq2[1];
+                nw += nw2[0] + nw2[1];
+            }
+            colp0 += pp[0];
+            colp1 += pp[1];
+            colw0 += wn[0];
+            colw1 += wn[1];
+            rowp[k] = pp[0] + pp[1];
+            roww[k] = wn[0] + wn[1];
+            wreg[s] = double2{wn[0], wn[1]};
+            if (NORMS)
+                asm volatile("" : "+v"(nqy), "+v"(nw), "+v"(colp0), "+v"(colp1), "+v"(colw0), "+v"(colw1));
+            else
+                asm volatile("" : "+v"(colp0), "+v"(colp1), "+v"(colw0), "+v"(colw1));
+        }
+        const double rw = halfwave_rows8(roww, lane);
+        const double rp = halfwave_rows8(rowp, lane);
+        if ((lane & 3) == 0) {
+            const int row = 16 * gq + 2 * ((lane >> 2) & 7) + half;
+            s_out[row] = rp;
+            s_out[TB + row] = rw;
+        }
+    }
+    colp0 = add_xor32(colp0);
+    colp1 = add_xor32(colp1);
+    colw0 = add_xor32(colw0);
+    colw1 = add_xor32(colw1);
+    if (half == 0) {
+        s_out[2 * TB + c0] = colp0;
+        s_out[2 * TB + c0 + 1] = colp1;
+        s_out[3 * TB + c0] = colw0;
+        s_out[3 * TB + c0 + 1] = colw1;
+    }
+}
+
+template <class K, bool RAGGED>
+__global__ __launch_bounds__(K::TW * 64, K::TW / 4) void k_tile(TileDev P) {
+    constexpr int TW = K::TW, C = K::C, RING = K::RING, FRMAX = K::FR;
+    constexpr int ZRES = 128 / (TW * C);              // LDS-resident row pairs of z per chunk
+    constexpr int NS = SLOTS - ZRES;                  // streamed ones
+    constexpr int NACQ = (NBW + TW - 1) / TW;         // node blocks one wave fetches
+    __shared__ double2 s_z[TW * C][ZRES][64];         // 128 KiB
+    __shared__ double2 s_node[NBW][TB];               // {d, pbar} of the node blocks this workgroup touches
+    __shared__ double s_part[8][4][TB];               // per chunk: row p, row w, column p, column w (owner phase: s_own)
+    __shared__ double s_fr[TW][2][TB];                // per wave: its fringe group's contribution to its diagonal block
+    __shared__ double s_wn[TW][2];
+    __shared__ double s_ns[2];
+    __shared__ int s_flag[4];                         // {rendezvous ok, failed, stop, -}
+    __shared__ double s_rel[2];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = blockIdx.x;
+    const int half = lane >> 5, c0 = 2 * (lane & 31), lofs = half * TB + c0;
+    if (P.ctr[4] != 0) return;  // an earlier launch of this session failed and has not been looked at yet
+
+    const WaveDesc wdv = P.wd[wg * TW + wave];
+    // the workgroup's descriptor: lane l keeps word l, wave-uniform reads go through v_readlane
+    const int gdw = reinterpret_cast<const int *>(P.gd + wg)[lane];
+    auto gd_int = [&](int idx) { return __builtin_amdgcn_readlane(gdw, idx); };
+    constexpr int GD_BLK = 4, GD_ENT = GD_BLK + NBW, GD_ROW = GD_ENT + NBW, GD_COL = GD_ROW + NBW, GD_FR = GD_COL + NBW;
+    constexpr int GD_SLICE = GD_FR + NBW, GD_ACTIVE = GD_SLICE + 2;
+    const int nblk = gd_int(0), own = gd_int(1), own_e0 = gd_int(2), own_e1 = gd_int(3);
+    const unsigned long long slice_mask = ((unsigned long long)(unsigned)gd_int(GD_SLICE + 1) << 32) | (unsigned)gd_int(GD_SLICE);
+    const bool active = gd_int(GD_ACTIVE) != 0;
+    unsigned *err = P.bar + 32;
+
+    // ---- static work of this wave
+    bool has[2] = {wdv.tile[0] >= 0, C == 2 && wdv.tile[1] >= 0};
+    unsigned zb[2] = {0u, 0u};
+    double2 wreg[C][SLOTS];
+    double2 zr[RING];
+#pragma unroll
+    for (int k = 0; k < RING; ++k) zr[k] = double2{0.0, 0.0};
+#pragma unroll
+    for (int ci = 0; ci < C; ++ci) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) wreg[ci][s] = double2{0.0, 0.0};
+        if (has[ci]) {
+            const int64_t tb = (int64_t)wdv.tile[ci] * GL_TILE_ELEMS + lofs;
+            zb[ci] = (unsigned)(tb * 8);
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) wreg[ci][s] = *reinterpret_cast<const double2 *>(P.w + tb + s * (2 * TB));
+#pragma unroll
+            for (int s = NS; s < SLOTS; ++s) {  // LDS-resident part, pre-multiplied: 2 gamma z
+                const double2 zv = *reinterpret_cast<const double2 *>(P.z + tb + s * (2 * TB));
+                s_z[wave * C + ci][s - NS][lane] = double2{P.g2 * zv.x, P.g2 * zv.y};
+            }
+        }
+    }
+    if (NS > 0) {  // the ring starts with chunk 0's first row pairs
+#pragma unroll
+        for (int k = 0; k < RING; ++k) {
+            const int tc = (k / (NS > 0 ? NS : 1)) % C, ts = k % (NS > 0 ? NS : 1);
+            if (has[tc]) zr[k] = tl_ldz(P.z, zb[tc] + (unsigned)(ts * (2 * TB) * 8));
+        }
+    }
+    // fringe group: row pairs fa0 .. fa0 + fcnt - 1 of diagonal tile (fB, fB), w and z in registers
+    const int fcnt = wdv.fcnt, fa0 = wdv.fa0, fB = wdv.fB, fs = wdv.fs;
+    double2 fw[FRMAX], fz[FRMAX];
+    int64_t ftb = 0;
+    if (fcnt > 0) ftb = gl_tile_id(fB, fB, P.nb) * GL_TILE_ELEMS + lofs;
+#pragma unroll
+    for (int f = 0; f < FRMAX; ++f) {
+        fw[f] = fz[f] = double2{0.0, 0.0};
+        if (f < fcnt) {
+            fw[f] = *reinterpret_cast<const double2 *>(P.w + ftb + (int64_t)(fa0 + f) * (2 * TB));
+            fz[f] = *reinterpret_cast<const double2 *>(P.z + ftb + (int64_t)(fa0 + f) * (2 * TB));
+        }
+    }
+    // ragged last block column: 0 / 1 factors of my two columns
+    double m0[2] = {1.0, 1.0}, m1[2] = {1.0, 1.0};
+    if (RAGGED) {
+#pragma unroll
+        for (int ci = 0; ci < C; ++ci)
+            if (has[ci]) {
+                m0[ci] = (int64_t)wdv.J[ci] * TB + c0 < P.n ? 1.0 : 0.0;
+                m1[ci] = (int64_t)wdv.J[ci] * TB + c0 + 1 < P.n ? 1.0 : 0.0;
+            }
+    }
+    // ---- dual state of my node block (owner workgroups, wave 0, lane = node)
+    double d_cur = 0, yb_cur = 0, pb_cur = 0, d_prev = 0;
+    double bn_last[4] = {0, 0, 0, 0};
+    const int64_t own_i = (int64_t)own * TB + lane;
+    if (own >= 0 && wave == 0) {
+        d_cur = P.dvar[own_i];
+        yb_cur = P.ybar[own_i];
+        pb_cur = P.pbar[own_i];
+        d_prev = P.dprev[own_i];
+    }
+    const auto r_part = __builtin_amdgcn_make_buffer_rsrc((void *)P.part, 0, (int)((int64_t)P.n_entries * 2 * TB * 16), 0x00020000);
+    const auto r_nval = __builtin_amdgcn_make_buffer_rsrc((void *)P.nval, 0, (int)(P.nb * 2 * TB * 16), 0x00020000);
+    const auto r_wn = __builtin_amdgcn_make_buffer_rsrc((void *)P.wnorm, 0, (int)(4 * P.NWG * 2 * 16), 0x00020000);
+    const auto r_bn = __builtin_amdgcn_make_buffer_rsrc((void *)P.bnrm, 0, (int)(4 * P.nb * 4 * 16), 0x00020000);
+
+    // ---- start-up rendezvous: every workgroup of the grid is on the chip, or nobody touches anything
+    if (tid == 0) {
+        const GlGridBar gb{P.bar, P.rendezvous};
+        GlBarState bs{};
+        s_flag[0] = gl_barrier_setup(gb, bs) ? 1 : 0;
+        s_flag[1] = 0;
+        s_flag[2] = 0;
+    }
+    __syncthreads();
+    const bool met = s_flag[0] != 0;
+    if (met && !active) return;  // nothing to do here: no edges, no node block (nobody waits for this workgroup)
+    bool failed = !met;
+    int done_iters = 0, stopped = 0;
+    double rel_p = INFINITY, rel_d = INFINITY;
+    const bool rule_on = P.tol > 0;
+    bool evaluated = false;
+
+    for (int it = 0; met && it <= P.maxit; ++it) {
+        const unsigned tag_in = P.tag0 + (unsigned)it;        // node values that are the input of iteration `it`
+        const unsigned tag_out = P.tag0 + (unsigned)it + 1u;  // what iteration `it` produces
+        const bool last_pass = it == P.maxit;
+        // does this workgroup evaluate the rule of iteration it - 1 now?
+        const bool want_rule = it >= 1 && (last_pass ? wg == 0 : rule_on);
+        if (last_pass && !want_rule) break;
+        const bool stamp = P.dbg != nullptr && it >= 8 && it < 24 && !last_pass;
+        unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+        if (stamp) ts[0] = __builtin_amdgcn_s_memrealtime();
+
+        // ================= acquire: {d, pbar} of my node blocks, and the norm records of iteration it - 1 =================
+        {
+            bool good = true;
+            if (!last_pass) {
+                if (it == 0) {  // the state the previous call (or init) left in memory
+#pragma unroll
+                    for (int j = 0; j < NACQ; ++j) {
+                        const int k = wave + TW * j;
+                        if (k < nblk) {
+                            const int64_t i = (int64_t)gd_int(GD_BLK + k) * TB + lane;
+                            s_node[k][lane] = double2{P.dvar[i], P.pbar[i]};
+                        }
+                    }
+                } else {
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    unsigned spins = 0;
+                    tl_u4 g[NACQ][2];
+                    for (;;) {
+                        bool ok = true;
+#pragma unroll
+                        for (int j = 0; j < NACQ; ++j) {
+                            const int k = wave + TW * j;
+                            g[j][0] = g[j][1] = tl_u4{0u, tag_in, 0u, tag_in};
+                            if (k < nblk) {
+                                const int off = (gd_int(GD_BLK + k) * 2 * TB + lane) * 16;
+                                g[j][0] = __builtin_amdgcn_raw_buffer_load_b128(r_nval, off, 0, 16);
+                                g[j][1] = __builtin_amdgcn_raw_buffer_load_b128(r_nval, off + TB * 16, 0, 16);
+                            }
+                            ok = ok && tl_ok(g[j][0], tag_in) && tl_ok(g[j][1], tag_in);
+                        }
+                        asm volatile("" ::: "memory");
+                        if (__all(ok)) break;
+                        if (!tl_spin(spins, t0, err)) {
+                            good = false;
+                            break;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < NACQ; ++j) {
+                        const int k = wave + TW * j;
+                        if (k < nblk) s_node[k][lane] = double2{tl_val(g[j][0]), tl_val(g[j][1])};
+                    }
+                }
+            }
+            if (want_rule && wave == TW - 1) {  // one record per node block, lane = block
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                unsigned spins = 0;
+                tl_u4 r[4];
+                const bool mine = lane < P.nb;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        r[q] = tl_u4{0u, tag_in, 0u, tag_in};
+                        if (mine) r[q] = __builtin_amdgcn_raw_buffer_load_b128(r_bn, ((((it - 1) & 3) * (int)P.nb + lane) * 4 + q) * 16, 0, 16);
+                        ok = ok && tl_ok(r[q], tag_in);
+                    }
+                    asm volatile("" ::: "memory");
+                    if (__all(ok)) break;
+                    if (!tl_spin(spins, t0, err)) {
+                        good = false;
+                        break;
+                    }
+                }
+                double b[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b[q] = wave_sum(mine ? tl_val(r[q]) : 0.0);
+                if (lane == 0) {
+                    const long long itp = P.it0 + it - 1;  // the iteration these norms belong to
+                    double rp = INFINITY, rd = INFINITY;
+                    if (itp >= 1) {  // never at iteration 0 (:156-161)
+                        rp = sqrt(b[0]) / sqrt(b[1]);
+                        rd = sqrt(b[2]) / sqrt(b[3]);
+                    }
+                    s_rel[0] = rp;
+                    s_rel[1] = rd;
+                    s_flag[2] = (itp >= 1 && rp < P.tol && rd < P.tol) ? 1 : 0;
+                }
+            }
+            if (!good) s_flag[1] = 1;
+        }
+        __syncthreads();
+        if (s_flag[1]) {
+            failed = true;
+            break;
+        }
+        if (want_rule) {
+            rel_p = s_rel[0];
+            rel_d = s_rel[1];
+            evaluated = true;
+            if (s_flag[2]) stopped = 1;
+        }
+        if (stopped || last_pass) break;  // the rule of iteration it - 1 holds: its iterate is the result
+
+        // ================= edge phase =================
+        if (stamp) ts[1] = __builtin_amdgcn_s_memrealtime();
+        double nqy = 0, nw = 0;
+        // the norms of the stopping rule are only formed when somebody will look at them: every iteration while
+        // tol > 0, else in the last iteration of the call (the ratios the host reports)
+        const bool norms = rule_on || it + 1 == P.maxit;
+#pragma unroll
+        for (int ci = 0; ci < C; ++ci) {
+            if (has[ci]) {
+                const double2 cv0 = s_node[wdv.sj[ci]][c0], cv1 = s_node[wdv.sj[ci]][c0 + 1];
+                if (ci == 0) {
+                    if (norms)
+                        tl_chunk_pass<K, RAGGED, true, 0>(P, wreg[0], zr, &s_z[wave * C][0][lane], zb, has, &s_node[wdv.si[0]][0],
+                                                          cv0.x, cv1.x, cv0.y, cv1.y, m0[0], m1[0], &s_part[wave * C][0][0], lane,
+                                                          nqy, nw);
+                    else
+                        tl_chunk_pass<K, RAGGED, false, 0>(P, wreg[0], zr, &s_z[wave * C][0][lane], zb, has, &s_node[wdv.si[0]][0],
+                                                           cv0.x, cv1.x, cv0.y, cv1.y, m0[0], m1[0], &s_part[wave * C][0][0], lane,
+                                                           nqy, nw);
+                } else {
+                    if (norms)
+                        tl_chunk_pass<K, RAGGED, true, C - 1>(P, wreg[C - 1], zr, &s_z[wave * C + C - 1][0][lane], zb, has,
+                                                              &s_node[wdv.si[C - 1]][0], cv0.x, cv1.x, cv0.y, cv1.y, m0[C - 1],
+                                                              m1[C - 1], &s_part[wave * C + C - 1][0][0], lane, nqy, nw);
+                    else
+                        tl_chunk_pass<K, RAGGED, false, C - 1>(P, wreg[C - 1], zr, &s_z[wave * C + C - 1][0][lane], zb, has,
+                                                               &s_node[wdv.si[C - 1]][0], cv0.x, cv1.x, cv0.y, cv1.y, m0[C - 1],
+                                                               m1[C - 1], &s_part[wave * C + C - 1][0][0], lane, nqy, nw);
+                }
+            }
+        }
+        if (fcnt > 0) {  // my fringe row pairs (diagonal tile: entries i < j < n only)
+            const double c = P.c, g = P.gamma, g2 = P.g2;
+            const double2 cv0 = s_node[fs][c0], cv1 = s_node[fs][c0 + 1];
+            double colp0 = 0, colp1 = 0, colw0 = 0, colw1 = 0;
+            double rsp[FRMAX], rsw[FRMAX];
+#pragma unroll
+            for (int f = 0; f < FRMAX; ++f) {
+                rsp[f] = rsw[f] = 0.0;
+                if (f < fcnt) {
+                    const int a = fa0 + f;
+                    const double2 rv = s_node[fs][2 * a + half];
+                    const int64_t i = (int64_t)fB * TB + 2 * a + half;
+                    double wn[2], pp[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int64_t j = (int64_t)fB * TB + c0 + e;
+                        const bool valid = i < j && j < P.n;
+                        const double w = e ? fw[f].y : fw[f].x, z = e ? fz[f].y : fz[f].x;
+                        const double y = c * w - g * (rv.x + (e ? cv1.x : cv0.x));
+                        const double tt = y - g2 * z;
+                        const double pr = tt > 0 ? tt : 0.0;
+                        const double q = c * pr - g * (rv.y + (e ? cv1.y : cv0.y));
+                        const double wnew = (w - y) + q;
+                        const double dq = q - y;
+                        pp[e] = valid ? pr : 0.0;
+                        wn[e] = valid ? wnew : 0.0;
+                        nqy += valid ? dq * dq : 0.0;
+                        nw += valid ? w * w : 0.0;
+                    }
+                    colp0 += pp[0];
+                    colp1 += pp[1];
+                    colw0 += wn[0];
+                    colw1 += wn[1];
+                    fw[f] = double2{wn[0], wn[1]};
+                    rsp[f] = half_sum(pp[0] + pp[1]);
+                    rsw[f] = half_sum(wn[0] + wn[1]);
+                }
+            }
+            colp0 = add_xor32(colp0);
+            colp1 = add_xor32(colp1);
+            colw0 = add_xor32(colw0);
+            colw1 = add_xor32(colw1);
+            if (half == 0) {
+                s_fr[wave][0][c0] = colp0;
+                s_fr[wave][0][c0 + 1] = colp1;
+                s_fr[wave][1][c0] = colw0;
+                s_fr[wave][1][c0 + 1] = colw1;
+            }
+            // the row sums join the same vector (rows and columns of a diagonal tile are the same node block);
+            // LDS operations of one wave execute in order
+            if ((lane & 31) == 0) {
+#pragma unroll
+                for (int f = 0; f < FRMAX; ++f)
+                    if (f < fcnt) {
+                        const int r = 2 * (fa0 + f) + half;
+                        s_fr[wave][0][r] += rsp[f];
+                        s_fr[wave][1][r] += rsw[f];
+                    }
+            }
+        }
+        nqy = wave_sum(nqy);
+        nw = wave_sum(nw);
+        if (lane == 0) {
+            s_wn[wave][0] = nqy;
+            s_wn[wave][1] = nw;
+        }
+        if (stamp) ts[2] = __builtin_amdgcn_s_memrealtime();
+        __syncthreads();
+
+        // ================= publish: one record per node block I touch =================
+#pragma unroll 1
+        for (int k = wave; k < nblk; k += TW) {
+            double sp = 0, sw = 0;
+            const int rm = gd_int(GD_ROW + k), cm = gd_int(GD_COL + k), fm = gd_int(GD_FR + k);
+#pragma unroll
+            for (int cs = 0; cs < C * TW; ++cs) {
+                if ((rm >> cs) & 1) {
+                    sp += s_part[cs][0][lane];
+                    sw += s_part[cs][1][lane];
+                }
+                if ((cm >> cs) & 1) {
+                    sp += s_part[cs][2][lane];
+                    sw += s_part[cs][3][lane];
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < TW; ++v)
+                if ((fm >> v) & 1) {
+                    sp += s_fr[v][0][lane];
+                    sw += s_fr[v][1][lane];
+                }
+            const int off = (gd_int(GD_ENT + k) * 2 * TB + lane) * 16;
+            __builtin_amdgcn_raw_buffer_store_b128(tl_gran(sp, tag_out), r_part, off, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(tl_gran(sw, tag_out), r_part, off + TB * 16, 0, 16);
+        }
+        if (tid == 0) {
+            double a = s_wn[0][0], b = s_wn[0][1];
+#pragma unroll
+            for (int v = 1; v < TW; ++v) {
+                a += s_wn[v][0];
+                b += s_wn[v][1];
+            }
+            const int off = (((it & 3) * P.NWG + wg) * 2) * 16;
+            __builtin_amdgcn_raw_buffer_store_b128(tl_gran(a, tag_out), r_wn, off, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(tl_gran(b, tag_out), r_wn, off + 16, 0, 16);
+        }
+        done_iters = it + 1;
+        if (stamp) ts[3] = __builtin_amdgcn_s_memrealtime();
+
+        // ================= node phase: the owner of a block sums its records and updates the dual state =================
+        if (own >= 0) {
+            __syncthreads();  // everybody has read s_part (its first TW KiB become s_own now)
+            double (*s_own)[2][TB] = reinterpret_cast<double (*)[2][TB]>(&s_part[0][0][0]);
+            bool good = true;
+            double sp = 0, sw = 0;
+            {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                unsigned spins = 0;
+                constexpr int RND = 32 / TW;  // records per wave and round
+                for (int eb = own_e0 + wave; eb < own_e1 && good; eb += TW * RND) {
+                    tl_u4 g[RND][2];
+                    for (;;) {
+                        bool ok = true;
+#pragma unroll
+                        for (int u = 0; u < RND; ++u) {
+                            const int e = eb + u * TW;
+                            g[u][0] = g[u][1] = tl_u4{0u, tag_out, 0u, tag_out};
+                            if (e < own_e1) {
+                                const int off = (e * 2 * TB + lane) * 16;
+                                g[u][0] = __builtin_amdgcn_raw_buffer_load_b128(r_part, off, 0, 16);
+                                g[u][1] = __builtin_amdgcn_raw_buffer_load_b128(r_part, off + TB * 16, 0, 16);
+                            }
+                            ok = ok && tl_ok(g[u][0], tag_out) && tl_ok(g[u][1], tag_out);
+                        }
+                        asm volatile("" ::: "memory");
+                        if (__all(ok)) break;
+                        if (!tl_spin(spins, t0, err)) {
+                            good = false;
+                            break;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < RND; ++u)
+                        if (eb + u * TW < own_e1) {
+                            sp += tl_val(g[u][0]);
+                            sw += tl_val(g[u][1]);
+                        }
+                }
+                s_own[wave][0][lane] = sp;
+                s_own[wave][1][lane] = sw;
+                if (wave == TW - 1) {  // my slice of the workgroups' norm records: workgroups own, own + nb, ...
+                    tl_u4 a = tl_u4{0u, tag_out, 0u, tag_out}, b = a;
+                    const int src = own + lane * (int)P.nb;
+                    const bool mine = src < P.NWG && ((slice_mask >> lane) & 1ull);
+                    for (; good;) {
+                        if (mine) {
+                            const int off = (((it & 3) * P.NWG + src) * 2) * 16;
+                            a = __builtin_amdgcn_raw_buffer_load_b128(r_wn, off, 0, 16);
+                            b = __builtin_amdgcn_raw_buffer_load_b128(r_wn, off + 16, 0, 16);
+                        }
+                        asm volatile("" ::: "memory");
+                        if (__all(tl_ok(a, tag_out) && tl_ok(b, tag_out))) break;
+                        if (!tl_spin(spins, t0, err)) good = false;
+                    }
+                    const double n0 = wave_sum(mine ? tl_val(a) : 0.0), n1 = wave_sum(mine ? tl_val(b) : 0.0);
+                    if (lane == 0) {
+                        s_ns[0] = n0;
+                        s_ns[1] = n1;
+                    }
+                }
+                if (!good) s_flag[1] = 1;
+            }
+            if (stamp) ts[4] = __builtin_amdgcn_s_memrealtime();
+            __syncthreads();
+            if (s_flag[1]) {
+                failed = true;
+                break;
+            }
+            if (wave == 0) {
+                sp = s_own[0][0][lane];
+                sw = s_own[0][1][lane];
+#pragma unroll
+                for (int v = 1; v < TW; ++v) {
+                    sp += s_own[v][0][lane];
+                    sw += s_own[v][1][lane];
+                }
+                const bool real = own_i < P.n;
+                const double qb = pb_cur + P.gamma * sp;  // :154
+                const double dq = qb - yb_cur;            // == -ybar + qbar (:159)
+                double dq2 = real ? dq * dq : 0.0;
+                double d2 = real ? d_cur * d_cur : 0.0;
+                const double dnew = (d_cur - yb_cur) + qb;                  // :164
+                const double ybn = dnew + P.gamma * sw;                     // :148 of the next iteration
+                const double pbn = (ybn - sqrt(ybn * ybn + P.a4g)) / 2;     // :151
+                d_prev = d_cur;
+                d_cur = real ? dnew : 0.0;
+                yb_cur = real ? ybn : 0.0;
+                pb_cur = real ? pbn : 0.0;
+                const int off = (own * 2 * TB + lane) * 16;
+                __builtin_amdgcn_raw_buffer_store_b128(tl_gran(d_cur, tag_out), r_nval, off, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(tl_gran(pb_cur, tag_out), r_nval, off + TB * 16, 0, 16);
+                dq2 = wave_sum(dq2);
+                d2 = wave_sum(d2);
+                bn_last[0] = s_ns[0];
+                bn_last[1] = s_ns[1];
+                bn_last[2] = dq2;
+                bn_last[3] = d2;
+                if (lane < 4) {
+                    const double v = lane == 0 ? bn_last[0] : (lane == 1 ? bn_last[1] : (lane == 2 ? dq2 : d2));
+                    __builtin_amdgcn_raw_buffer_store_b128(tl_gran(v, tag_out), r_bn, ((((it & 3) * (int)P.nb + own) * 4) + lane) * 16, 0, 16);
+                }
+            }
+            // (s_own is read by wave 0 only; the next writes to that LDS come after the next acquire's barrier)
+        }
+        if (stamp && tid == 0) {
+            ts[5] = __builtin_amdgcn_s_memrealtime();
+            unsigned long long *o = P.dbg + ((size_t)wg * 16 + (it - 8)) * 6;
+            for (int q = 0; q < 6; ++q) o[q] = ts[q];
+        }
+    }
+
+    if (failed) {  // nothing of the session's state has been written
+        if (wg == 0 && tid == 0) {
+            P.ctr[2] = P.it0;
+            P.ctr[4] = met ? 2 : 1;  // 1: the workgroups never met; 2: a hand-off was lost in mid-run
+        }
+        return;
+    }
+    // ---- registers back to the iterate buffer, dual state back to memory, bookkeeping for the host / the other engines
+#pragma unroll
+    for (int ci = 0; ci < C; ++ci)
+        if (has[ci]) {
+            const int64_t tb = (int64_t)wdv.tile[ci] * GL_TILE_ELEMS + lofs;
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) *reinterpret_cast<double2 *>(P.w + tb + s * (2 * TB)) = wreg[ci][s];
+        }
+#pragma unroll
+    for (int f = 0; f < FRMAX; ++f)
+        if (f < fcnt) *reinterpret_cast<double2 *>(P.w + ftb + (int64_t)(fa0 + f) * (2 * TB)) = fw[f];
+    if (own >= 0 && wave == 0 && done_iters > 0) {
+        P.dvar[own_i] = d_cur;
+        P.ybar[own_i] = yb_cur;
+        P.pbar[own_i] = pb_cur;
+        P.dprev[own_i] = d_prev;
+        if (lane < 4)
+            P.bnorm[((P.it0 + done_iters - 1) & 1) * 4 * P.nb + 4 * own + lane] =
+                lane == 0 ? bn_last[0] : (lane == 1 ? bn_last[1] : (lane == 2 ? bn_last[2] : bn_last[3]));
+    }
+    if (wg == 0 && tid == 0) {
+        const long long itf = P.it0 + done_iters;
+        if (evaluated) {  // the ratios of the last iteration whose rule was evaluated (inf for iteration 0, :156-161)
+            P.dstat[0] = rel_p;
+            P.dstat[1] = rel_d;
+        }
+        P.ctr[0] = stopped;
+        P.ctr[1] = itf;
+        P.ctr[2] = itf;
+        P.ctr[3] = itf > 0 ? itf - 1 : 0;
+        P.ctr[4] = 0;
+    }
+}
+
+}  // namespace
+
+// =========================================================================== host side
+enum { TILE_WIDE = 0, TILE_PAIR = 1, TILE_HALF = 2 };
+
+struct gl_tile {
+    TileDev dev{};
+    int cfg = TILE_WIDE;
+    void *arena = nullptr;      // descriptors, record buffers, rendezvous words: one allocation
+    size_t gran_off = 0, gran_bytes = 0;  // the record buffers inside it
+    unsigned long long *dbg = nullptr;
+    unsigned next_tag = 1u;     // first tag of the next launch (a launch uses maxit + 2 consecutive ones, never 0)
+    int C = 1;
+};
+
+void gl_tile_free(gl_logdeg *s) {
+    if (!s || !s->tile) return;
+    if (s->tile->arena) (void)hipFree(s->tile->arena);
+    if (s->tile->dbg) (void)hipFree(s->tile->dbg);
+    delete s->tile;
+    s->tile = nullptr;
+}
+
+// Builds the static work decomposition.  GL_OK with s->tile == nullptr when the engine does not apply.
+int gl_tile_prepare(gl_logdeg *s) {
+    gl_ctx *ctx = s->ctx;
+    s->tile = nullptr;
+    bool forced = false;
+    if (const char *e = getenv("GRAPHLEARN_AMD_ENGINE")) {
+        if (!strcmp(e, "stream") || !strcmp(e, "resident1")) return GL_OK;
+        forced = !strcmp(e, "resident") || !strcmp(e, "tile");
+    }
+    const LogdegDev &D = s->dev;
+    const int ncu = ctx->prop.multiProcessorCount;
+    const int nb = (int)D.nb;
+    if (nb > 64) return GL_OK;  // one norm record per lane in the rule's poll; larger lattices do not fit the register files anyway
+    // bulk tiles in super-tile order (2 block rows x 4 block columns): consecutive tiles share node blocks, so a
+    // workgroup's tiles touch few of them
+    std::vector<std::pair<int, int>> bulk;
+    for (int IB = 0; 2 * IB < nb; ++IB)
+        for (int JB = 0; 4 * JB < nb; ++JB)
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 4; ++b) {
+                    const int I = 2 * IB + a, J = 4 * JB + b;
+                    if (I < J && J < nb) bulk.push_back({I, J});
+                }
+    const int F = (int)bulk.size();
+    if (F > 8 * ncu) return GL_OK;  // does not fit the register files
+    if (!forced && F < GL_TILE_MIN_BULK_TILES) return GL_OK;
+    // geometry: up to 4 tiles per workgroup everything of z is LDS-resident (CfgHalf); beyond, 8 tiles per
+    // workgroup as 4 waves x 2 (CfgWide, default) or 8 waves x 1 (CfgPair, GRAPHLEARN_AMD_TILE_CFG=pair)
+    int cfg = F > 4 * ncu ? TILE_WIDE : TILE_HALF;
+    if (const char *e = getenv("GRAPHLEARN_AMD_TILE_CFG")) {
+#ifdef GL_TILE_WITH_PAIR
+        if (!strcmp(e, "pair")) cfg = TILE_PAIR;
+#endif
+        if (!strcmp(e, "wide")) cfg = TILE_WIDE;
+        if (!strcmp(e, "half") && F <= 4 * ncu) cfg = TILE_HALF;
+    }
+    const int TW = cfg == TILE_PAIR ? CfgPair::TW : 4, C = cfg == TILE_WIDE ? 2 : 1;
+    const int FRMAX = cfg == TILE_PAIR ? CfgPair::FR : 4;
+    int NWG = (F + TW * C - 1) / (TW * C);
+    NWG = std::max(NWG, std::min(ncu, std::max(2 * nb, (32 * nb + TW * 3 - 1) / (TW * 3))));
+    NWG = std::min(std::max(NWG, nb), ncu);
+    if (NWG < nb) return GL_OK;  // every node block needs an owner workgroup
+    const int nwaves = NWG * TW;
+    std::vector<WaveDesc> wd((size_t)nwaves);
+    for (WaveDesc &w : wd) {
+        w.tile[0] = w.tile[1] = -1;
+        w.I[0] = w.I[1] = w.J[0] = w.J[1] = 0;
+        w.si[0] = w.si[1] = w.sj[0] = w.sj[1] = 0;
+        w.ragged[0] = w.ragged[1] = 0;
+        w.fs = w.fa0 = w.fcnt = 0;
+        w.fB = -1;
+    }
+    for (int f = 0; f < F; ++f) {
+        WaveDesc &w = wd[(size_t)(f / C)];
+        const int c = f % C;
+        w.tile[c] = (int)gl_tile_id(bulk[(size_t)f].first, bulk[(size_t)f].second, nb);
+        w.I[c] = bulk[(size_t)f].first;
+        w.J[c] = bulk[(size_t)f].second;
+        w.ragged[c] = (D.n % TB != 0 && w.J[c] == nb - 1) ? 1 : 0;
+    }
+    // fringe: the 32 row pairs of diagonal tile (B, B) go, in groups, to waves that already work on block B
+    // (then the workgroup's block list does not grow), else to waves without any work yet
+    const int waves_with_tiles = (F + C - 1) / C;
+    const int t0 = waves_with_tiles > 0 ? std::max(1, std::min(FRMAX, (SLOTS * nb) / waves_with_tiles)) : FRMAX;
+    for (int B = 0; B < nb; ++B) {
+        bool placed = false;
+        for (int cap = t0; cap <= FRMAX && !placed; ++cap) {
+            std::vector<std::pair<int, int>> plan;  // (wave, count)
+            int need = SLOTS;
+            for (int pass = 0; pass < 2 && need > 0; ++pass)
+                for (int v = 0; v < nwaves && need > 0; ++v) {
+                    const WaveDesc &w = wd[(size_t)v];
+                    if (w.fcnt != 0) continue;
+                    const bool works_on_b = (w.tile[0] >= 0 && (w.I[0] == B || w.J[0] == B)) ||
+                                            (w.tile[1] >= 0 && (w.I[1] == B || w.J[1] == B));
+                    const bool idle = w.tile[0] < 0;
+                    if (pass == 0 ? !works_on_b : !idle) continue;
+                    const int take = std::min(pass == 0 ? cap : FRMAX, need);
+                    plan.push_back({v, take});
+                    need -= take;
+                }
+            if (need > 0) continue;
+            int a = 0;
+            for (auto &pr : plan) {
+                WaveDesc &w = wd[(size_t)pr.first];
+                w.fB = B;
+                w.fa0 = a;
+                w.fcnt = pr.second;
+                a += pr.second;
+            }
+            placed = true;
+        }
+        if (!placed) return GL_OK;  // (tiny lattices on few workgroups: the other engines serve them)
+    }
+    // block lists, records, masks
+    std::vector<WgDesc> gd((size_t)NWG);
+    std::vector<std::vector<int>> touch((size_t)nb);  // block -> workgroups (ascending)
+    for (int g = 0; g < NWG; ++g) {
+        WgDesc &G = gd[(size_t)g];
+        memset(&G, 0, sizeof G);
+        G.own = g < nb ? g : -1;
+        auto slot_of = [&](int B) -> int {
+            for (int k = 0; k < G.nblk; ++k)
+                if (G.blk[k] == B) return k;
+            if (G.nblk >= NBW) return -1;
+            G.blk[G.nblk] = B;
+            return G.nblk++;
+        };
+        for (int v = 0; v < TW; ++v) {
+            WaveDesc &w = wd[(size_t)(g * TW + v)];
+            for (int c = 0; c < 2; ++c)
+                if (w.tile[c] >= 0) {
+                    w.si[c] = slot_of(w.I[c]);
+                    w.sj[c] = slot_of(w.J[c]);
+                    if (w.si[c] < 0 || w.sj[c] < 0) return GL_OK;  // too many node blocks for one workgroup's LDS
+                    G.rowmask[w.si[c]] |= 1 << (v * C + c);
+                    G.colmask[w.sj[c]] |= 1 << (v * C + c);
+                }
+            if (w.fcnt > 0) {
+                w.fs = slot_of(w.fB);
+                if (w.fs < 0) return GL_OK;
+                G.frmask[w.fs] |= 1 << v;
+            }
+        }
+        for (int k = 0; k < G.nblk; ++k) touch[(size_t)G.blk[k]].push_back(g);
+        G.active = (G.nblk > 0 || G.own >= 0) ? 1 : 0;
+    }
+    if (NWG > 64 * nb) return GL_OK;  // an owner reads its slice of the norm records with one lane per workgroup
+    for (int B = 0; B < nb; ++B)
+        for (int r = 0; B + r * nb < NWG; ++r)
+            if (gd[(size_t)(B + r * nb)].active) (r < 32 ? gd[(size_t)B].slice_lo : gd[(size_t)B].slice_hi) |= 1u << (r & 31);
+    int n_entries = 0;
+    for (int B = 0; B < nb; ++B) {
+        gd[(size_t)B].own_e0 = n_entries;
+        for (int g : touch[(size_t)B]) {
+            WgDesc &G = gd[(size_t)g];
+            for (int k = 0; k < G.nblk; ++k)
+                if (G.blk[k] == B) G.ent[k] = n_entries;
+            ++n_entries;
+        }
+        gd[(size_t)B].own_e1 = n_entries;
+        if (touch[(size_t)B].empty()) return gl_set_error(ctx, GL_E_STATE, "internal: node block %d has no producer", B);
+    }
+
+    gl_tile *t = new (std::nothrow) gl_tile();
+    if (!t) return GL_E_NOMEM;
+    auto up256 = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b_wd = up256(wd.size() * sizeof(WaveDesc)), b_gd = up256(gd.size() * sizeof(WgDesc));
+    const size_t b_part = up256((size_t)n_entries * 2 * TB * 16), b_nval = up256((size_t)nb * 2 * TB * 16);
+    const size_t b_wn = up256((size_t)4 * NWG * 2 * 16), b_bn = up256((size_t)4 * nb * 4 * 16);
+    const size_t b_bar = up256((size_t)GL_BAR_WORDS * 4);
+    const size_t total = b_wd + b_gd + b_part + b_nval + b_wn + b_bn + b_bar;
+    if (hipMalloc(&t->arena, total) != hipSuccess) {
+        delete t;
+        return gl_set_error(ctx, GL_E_NOMEM, "tile engine: hipMalloc(%zu) failed", total);
+    }
+    char *at = (char *)t->arena;
+    TileDev &P = t->dev;
+    P.wd = (const WaveDesc *)at, at += b_wd;
+    P.gd = (const WgDesc *)at, at += b_gd;
+    t->gran_off = (size_t)(at - (char *)t->arena);
+    P.part = (tl_u4 *)at, at += b_part;
+    P.nval = (tl_u4 *)at, at += b_nval;
+    P.wnorm = (tl_u4 *)at, at += b_wn;
+    P.bnrm = (tl_u4 *)at, at += b_bn;
+    t->gran_bytes = (size_t)(at - (char *)t->arena) - t->gran_off;
+    P.bar = (unsigned *)at;
+    hipError_t e = hipMemsetAsync(t->arena, 0, total, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync((void *)P.wd, wd.data(), wd.size() * sizeof(WaveDesc), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync((void *)P.gd, gd.data(), gd.size() * sizeof(WgDesc), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // wd / gd are locals
+    if (e != hipSuccess) {
+        (void)hipFree(t->arena);
+        delete t;
+        return gl_set_error(ctx, GL_E_HIP, "tile engine set-up: %s", hipGetErrorString(e));
+    }
+    P.z = D.z;
+    P.dvar = D.dvar;
+    P.ybar = D.ybar;
+    P.pbar = D.pbar;
+    P.dprev = D.dprev;
+    P.bnorm = D.bnorm;
+    P.dstat = D.dstat;
+    P.ctr = D.ctr;
+    P.n = D.n;
+    P.nb = D.nb;
+    P.NWG = NWG;
+    P.n_entries = n_entries;
+    t->C = C;
+    t->cfg = cfg;
+    P.dbg = nullptr;
+    if (getenv("GRAPHLEARN_AMD_RES_STAMPS") && hipMalloc((void **)&t->dbg, (size_t)NWG * 16 * 6 * 8) == hipSuccess) {
+        (void)hipMemset(t->dbg, 0, (size_t)NWG * 16 * 6 * 8);
+        P.dbg = t->dbg;
+        fprintf(stderr, "[tile] n %lld nb %d F %d cfg %d NWG %d entries %d\n", (long long)D.n, nb, F, cfg, NWG, n_entries);
+    }
+    s->tile = t;
+    return GL_OK;
+}
+
+// Runs up to `iters` iterations in ONE launch (asynchronous).  The iterate stays in w[it0 & 1]; the caller fixes
+// the ping-pong parity afterwards.
+int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol) {
+    gl_ctx *ctx = s->ctx;
+    gl_tile *t = s->tile;
+    TileDev P = t->dev;
+    const LogdegDev &D = s->dev;
+    P.w = D.w[s->it & 1];
+    P.gamma = D.gamma;
+    P.c = D.c;
+    P.g2 = D.g2;
+    P.a4g = D.a4g;
+    P.tol = tol;
+    P.it0 = s->it;
+    P.maxit = (int)std::min<int64_t>(iters, 1 << 30);
+    if (t->next_tag == 0u || t->next_tag > 0xE0000000u - (unsigned)P.maxit) {  // the tags would wrap into old ones
+        GL_HIP(ctx, hipMemsetAsync((char *)t->arena + t->gran_off, 0, t->gran_bytes, ctx->stream));
+        t->next_tag = 1u;
+    }
+    P.tag0 = t->next_tag;
+    t->next_tag += (unsigned)P.maxit + 2u;
+    P.rendezvous = P.NWG + (getenv("GRAPHLEARN_AMD_RES_TEST_NOT_RESIDENT") ? 1 : 0);
+    GL_HIP(ctx, hipMemsetAsync(P.bar, 0, GL_BAR_WORDS * 4, ctx->stream));
+    const bool ragged = D.n % TB != 0;
+    const dim3 grid((unsigned)P.NWG);
+    if (t->cfg == TILE_WIDE) {
+        if (ragged)
+            k_tile<CfgWide, true><<<grid, dim3(CfgWide::TW * 64), 0, ctx->stream>>>(P);
+        else
+            k_tile<CfgWide, false><<<grid, dim3(CfgWide::TW * 64), 0, ctx->stream>>>(P);
+#ifdef GL_TILE_WITH_PAIR
+    } else if (t->cfg == TILE_PAIR) {
+        if (ragged)
+            k_tile<CfgPair, true><<<grid, dim3(CfgPair::TW * 64), 0, ctx->stream>>>(P);
+        else
+            k_tile<CfgPair, false><<<grid, dim3(CfgPair::TW * 64), 0, ctx->stream>>>(P);
+#endif
+    } else {
+        if (ragged)
+            k_tile<CfgHalf, true><<<grid, dim3(CfgHalf::TW * 64), 0, ctx->stream>>>(P);
+        else
+            k_tile<CfgHalf, false><<<grid, dim3(CfgHalf::TW * 64), 0, ctx->stream>>>(P);
+    }
+    GL_HIP(ctx, hipGetLastError());
+    return GL_OK;
+}
+
+// development: phase stamps of iterations 8..23 of the last launch (GRAPHLEARN_AMD_RES_STAMPS=1), after a sync
+void gl_tile_dump_stamps(gl_logdeg *s) {
+    if (!s || !s->tile || !s->tile->dbg) return;
+    const int NWG = s->tile->dev.NWG, nb = (int)s->tile->dev.nb;
+    std::vector<unsigned long long> h((size_t)NWG * 16 * 6);
+    (void)hipMemcpy(h.data(), s->tile->dbg, h.size() * 8, hipMemcpyDeviceToHost);
+    // per iteration: the latest end of an edge phase, the latest publish, the latest owner's node values out,
+    // relative to the earliest start of that iteration's acquire
+    double acq = 0, edge = 0, pub = 0, own_wait = 0, own_upd = 0, span = 0, edge_max = 0, acq_min = 0;
+    int kc = 0;
+    for (int k = 1; k < 16; ++k) {
+        unsigned long long t_first = ~0ull, t_next = ~0ull;
+        double e_max = 0, a_min = 1e30, a_sum = 0, e_sum = 0, p_sum = 0, w_sum = 0, u_sum = 0;
+        int cnt = 0, ocnt = 0;
+        for (int w = 0; w < NWG; ++w) {
+            const unsigned long long *o = &h[((size_t)w * 16 + k) * 6], *pv = &h[((size_t)w * 16 + k - 1) * 6];
+            if (!o[5] || !pv[5]) continue;
+            t_first = std::min(t_first, pv[0]);
+            t_next = std::min(t_next, o[0]);
+            a_sum += (double)(o[1] - o[0]);
+            a_min = std::min(a_min, (double)(o[1] - o[0]));
+            e_sum += (double)(o[2] - o[1]);
+            e_max = std::max(e_max, (double)(o[2] - o[1]));
+            p_sum += (double)(o[3] - o[2]);
+            ++cnt;
+            if (w < nb && o[4]) {
+                w_sum += (double)(o[4] - o[3]);
+                u_sum += (double)(o[5] - o[4]);
+                ++ocnt;
+            }
+        }
+        if (!cnt) continue;
+        acq += a_sum / cnt, edge += e_sum / cnt, pub += p_sum / cnt, edge_max += e_max, acq_min += a_min;
+        if (ocnt) own_wait += w_sum / ocnt, own_upd += u_sum / ocnt;
+        span += (double)(t_next - t_first);
+        ++kc;
+    }
+    if (kc)
+        fprintf(stderr, "[tile stamps] us per iteration %.2f | mean: acquire (wait for node values) %.2f (fastest %.2f)  edge %.2f (slowest %.2f)  "
+                        "publish %.2f  owner: wait for records %.2f  update + publish %.2f\n",
+                span / kc / 100, acq / kc / 100, acq_min / kc / 100, edge / kc / 100, edge_max / kc / 100, pub / kc / 100, own_wait / kc / 100,
+                own_upd / kc / 100);
+}

@@ -25,12 +25,14 @@ ATOL = 1e-10
 CASES = ["logmodel_n7_d23", "logmodel_n16_d40", "logmodel_n64_d256"]
 
 
-@pytest.fixture(autouse=True, params=["stream", "resident", "small"])
+@pytest.fixture(autouse=True, params=["stream", "resident", "resident1", "small"])
 def engine(request, monkeypatch):
-    """Every test of this file runs on the three iteration engines: streaming (one edge-pass + one
-    node-pass launch per iteration), resident (iterate held in registers / LDS, grid barriers; by default
-    only chosen for n > 2240, forced here) and small (n <= 128: one workgroup, one launch per call; where
-    it does not apply the automatic choice takes over)."""
+    """Every test of this file runs on every iteration engine: streaming (one edge-pass + one node-pass launch
+    per iteration), the resident family forced -- "resident": the tile engine (gl_tile.hip: iterate in registers,
+    z in LDS, tagged hand-offs) wherever its work decomposition applies, else the first resident engine;
+    "resident1": the first resident engine (gl_resident.hip: grid barriers); by default the family is only
+    chosen for n > 2240 -- and small (n <= 128: one workgroup, one launch per call; where it does not apply the
+    automatic choice takes over)."""
     monkeypatch.setenv("GRAPHLEARN_AMD_ENGINE", request.param)
     return request.param
 
@@ -218,7 +220,8 @@ def test_c2_size_persistent_engine_against_oracle(engine):
     with _lib.LogDegreeSession(4096) as s:
         s.set_distances(zt)
         s.init(1, 1, 0.5, None)
-        assert s.engine == "resident"          # forced ("resident") and the automatic choice ("small" does not apply)
+        assert s.engine == "resident"          # forced, and the automatic choice ("small" does not apply)
+        assert s.engine_kernel == ("k_resident" if engine == "resident1" else "k_tile")
         n_it, conv, rel17 = s.iterate(17, 0.0)
         assert n_it == 17 and not conv and s.engine == "resident"
         n_it, conv, rel = s.iterate(23, 0.0)
@@ -260,8 +263,8 @@ def test_resident_engine_falls_back_when_workgroups_do_not_meet(golden, engine, 
     """The resident engine's workgroups must all be on the chip at once.  When they are not (shared
     GPU), the start-up rendezvous times out before anything is modified and the call is served by
     the streaming engine -- synchronously and for an asynchronous call at its next sync point."""
-    if engine != "resident":
-        pytest.skip("resident engine only")
+    if engine not in ("resident", "resident1"):
+        pytest.skip("resident family only")
     g = golden("logmodel_n64_d256")
     zt = g["z"] * float(g["theta_deg6"])
     monkeypatch.setenv("GRAPHLEARN_AMD_RES_TEST_NOT_RESIDENT", "1")  # rendezvous expects one workgroup too many
@@ -288,24 +291,26 @@ def test_resident_engine_falls_back_when_workgroups_do_not_meet(golden, engine, 
 def test_resident_matches_streaming_at_ragged_large_sizes(n, engine, monkeypatch):
     """Resident engine on lattices with a ragged last block (n not a multiple of 64) and many fringe
     tiles: 60 iterations agree with the streaming engine up to summation order, and the dual too."""
-    if engine != "resident":
-        pytest.skip("compares the two large-size engines once")
+    if engine not in ("resident", "resident1"):
+        pytest.skip("compares each persistent engine with the streaming one")
     rng = np.random.default_rng(n)
     e = n * (n - 1) // 2
     z = rng.uniform(0.05, 3.0, size=e)
     out = {}
-    for eng in ("stream", "resident"):
+    for eng in ("stream", engine):
         monkeypatch.setenv("GRAPHLEARN_AMD_ENGINE", eng)
         with _lib.LogDegreeSession(n) as s:
             s.set_distances(z)
             s.init(1.2, 0.8, 0.5, None)
-            assert s.engine == eng
+            assert s.engine == ("stream" if eng == "stream" else "resident")
+            if eng == "resident":
+                assert s.engine_kernel == "k_tile"
             n_it, conv, rel = s.iterate(60, 0.0)
             out[eng] = (s.weights_condensed(), s.dual(), rel)
-    np.testing.assert_allclose(out["resident"][0], out["stream"][0], rtol=0, atol=1e-13)
-    np.testing.assert_allclose(out["resident"][1], out["stream"][1], rtol=0, atol=1e-12)
-    assert out["resident"][2][0] == pytest.approx(out["stream"][2][0], rel=1e-9)
-    assert out["resident"][2][1] == pytest.approx(out["stream"][2][1], rel=1e-9)
+    np.testing.assert_allclose(out[engine][0], out["stream"][0], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(out[engine][1], out["stream"][1], rtol=0, atol=1e-12)
+    assert out[engine][2][0] == pytest.approx(out["stream"][2][0], rel=1e-9)
+    assert out[engine][2][1] == pytest.approx(out["stream"][2][1], rel=1e-9)
 
 
 @pytest.mark.parametrize("n", [12, 128, 150])
