@@ -132,8 +132,9 @@ def main():
         gpu_ms = comm.max_over_ranks(gpu_ms)
 
     engine = sess.engine                                 # "resident" (n=4096 default) or "stream"
+    engine_kernel = sess.engine_kernel                   # "k_tile" (default), "k_resident" or "k_edge"
     if engine == "resident" and args.steps < 16:         # calls shorter than 16 iterations run on the streaming engine
-        engine = "stream"
+        engine, engine_kernel = "stream", "k_edge"
     # steady state and fixed cost per call: a long call (2000 steps, or the timed one if it is longer) gives the
     # per-iteration rate; what the timed call took beyond steps x that rate is the call's fixed cost
     # (launch, loading the iterate into registers / LDS, storing it back)
@@ -173,7 +174,10 @@ def main():
         # processes steps x 24 E algorithmic bytes.  Streaming engine: k_edge<false>, one launch per
         # iteration, timed alone by gl_logdeg_time_edge_pass.
         if engine == "resident":
-            kernel, kprefix = "k_resident (persistent: edge phase + node phase + stopping rule, iterate in registers/LDS)", "k_resident"
+            kprefix = engine_kernel
+            kernel = ("k_tile (persistent: iterate w in registers, z half in LDS / half streamed, degree partials and node "
+                      "values handed over as tagged records)" if engine_kernel == "k_tile" else
+                      "k_resident (persistent: edge phase + node phase + stopping rule, iterate in registers/LDS, grid barriers)")
             launch_us, launch_bytes, its_per_launch = gpu_ms * 1e3, bytes_it * args.steps, args.steps
         else:
             kernel, kprefix = "k_edge<false> (edge pass: prox update of all edges + degree sums)", "k_edge"
@@ -193,9 +197,12 @@ def main():
                                f"iteration of a {prof.get('iterations_per_launch', 2000)}-iteration launch) x {its_per_launch}")
         except Exception:
             traffic = None
-        # the resident engine keeps w on chip: its real stream is z (8 E) + the degree partials, so the honest
-        # bound for THIS kernel is that stream at the HBM rate; both fractions are reported
-        z_stream_bytes = 4 * n * (n - 1)
+        # The persistent engines keep w on chip, so the bytes they really move per iteration are far below the
+        # algorithmic 24 E: k_resident streams z (8 E) + degree slabs, k_tile half of z (4 E; nothing at all when the
+        # lattice is small enough for z to live in LDS) + ~6 MB of records.  Priced against the same 8 TB/s that is
+        # `streamed_frac`: how close the kernel is to the memory system's limit (it is not: it is bound by fp64 issue
+        # and hand-off latency).
+        streamed_bytes = (2 if engine_kernel == "k_tile" else 4) * n * (n - 1)
         out = {
             "metric": "primal-dual iterations/sec, LogModel n=4096 d=1024",
             "value": its_per_s,
@@ -213,7 +220,7 @@ def main():
                                    f"(BASELINE configs[1]); one independent problem per GPU",
                        "edges": n * (n - 1) // 2, "theta": theta, "setup_s_distances_theta": setup_s,
                        "gather_s": gather_s, "comm": getattr(comm, "kind", None), "gpu_us_per_iteration": iter_us,
-                       "engine": engine, "streaming_edge_pass_us": edge_us,
+                       "engine": engine, "engine_kernel": engine_kernel, "streaming_edge_pass_us": edge_us,
                        "first_call_us": first_call_us, "fixed_call_us": fixed_call_us,
                        "steady_state": {"steps": long_steps, "us_per_iteration": steady_us,
                                         "iterations_per_s": 1e6 / steady_us,
@@ -224,13 +231,14 @@ def main():
                          "kernel": kernel, "iterations_per_launch": its_per_launch,
                          "algorithmic_bytes_per_launch": launch_bytes, "avg_launch_us": launch_us,
                          "traffic_source": traffic_src,
-                         "z_stream_frac": (z_stream_bytes * its_per_launch / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS)
-                         if engine == "resident" else None,
+                         "streamed_bytes_per_iteration": streamed_bytes if engine == "resident" else bytes_it,
+                         "streamed_frac": (streamed_bytes * its_per_launch / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS)
+                         if engine == "resident" else achieved / HBM_PEAK_GBS,
                          "note": ("achieved = ALGORITHMIC bytes (24 E per iteration: read w, read z, write w; SURVEY 8d) / "
-                                  "launch time.  This engine keeps w in registers / LDS, so the bytes it really streams per "
-                                  "iteration are z (8 E) + degree partials: `z_stream_frac` prices that stream against the "
-                                  "same 8 TB/s and is the fraction to read as 'how close to the memory system's limit'; "
-                                  "`frac` can exceed 1") if engine == "resident" else None},
+                                  "launch time, so `frac` exceeds 1 for an engine that does not move those bytes: w lives in "
+                                  "registers and half of z in LDS.  `streamed_frac` prices what the kernel really streams "
+                                  "(`streamed_bytes_per_iteration`) against the same 8 TB/s; the kernel is bound by fp64 "
+                                  "issue and hand-off latency, not by memory (DESIGN.md section 3a)") if engine == "resident" else None},
         }
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
             z = sess.get_distances() * theta

@@ -85,7 +85,7 @@ int gl_resident_finish(gl_logdeg *s, int64_t *iters_done, bool *stopped, bool *n
 // gl_tile.hip
 int gl_tile_prepare(gl_logdeg *s);
 void gl_tile_free(gl_logdeg *s);
-int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol);
+int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms);
 void gl_tile_dump_stamps(gl_logdeg *s);
 // gl_small.hip
 bool gl_small_applicable(const gl_logdeg *s);

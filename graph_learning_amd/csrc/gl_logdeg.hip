@@ -1051,8 +1051,8 @@ GL_API int gl_logdeg_init(gl_logdeg *s, double alpha, double beta, double step_s
 static bool use_small(const gl_logdeg *s, int64_t iters) { return iters >= 8 && gl_small_applicable(s); }
 static bool use_resident(const gl_logdeg *s, int64_t iters) { return (s->tile != nullptr || s->res != nullptr) && iters >= 16; }
 // the persistent launch of the session's resident-family engine: the tile engine where it applies
-static int persistent_launch(gl_logdeg *s, int64_t iters, double tol) {
-    return s->tile ? gl_tile_launch(s, iters, tol) : gl_resident_launch(s, iters, tol);
+static int persistent_launch(gl_logdeg *s, int64_t iters, double tol, bool norms) {
+    return s->tile ? gl_tile_launch(s, iters, tol, norms) : gl_resident_launch(s, iters, tol);
 }
 static void persistent_free(gl_logdeg *s) {
     gl_resident_free(s);
@@ -1113,7 +1113,7 @@ GL_API int gl_logdeg_iterate_async(gl_logdeg *s, int64_t n_iter) {
     }
     if (use_resident(s, n_iter)) {
         // tol = 0 never stops: the iteration count and the parity of the final buffer are known now
-        GL_TRY(persistent_launch(s, n_iter, 0.0));
+        GL_TRY(persistent_launch(s, n_iter, 0.0, false));  // nobody reads the ratios of an asynchronous call
         const int64_t itf = s->it + n_iter;
         if ((itf & 1) != (s->it & 1)) {
             const size_t bytes = (size_t)s->dev.ntiles * GL_TILE_ELEMS * sizeof(double);
@@ -1162,7 +1162,7 @@ GL_API int gl_logdeg_iterate(gl_logdeg *s, int64_t maxit, double tol, int64_t *n
         int64_t ran = 0;
         bool stopped = false;
         bool not_resident = false;
-        GL_TRY(persistent_launch(s, maxit, tol));
+        GL_TRY(persistent_launch(s, maxit, tol, true));
         GL_TRY(gl_resident_finish(s, &ran, &stopped, &not_resident));
         if (!not_resident) {
             GL_HIP(ctx, hipMemcpyAsync(st, D.dstat, 2 * 8, hipMemcpyDeviceToHost, ctx->stream));

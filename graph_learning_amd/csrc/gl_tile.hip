@@ -8,14 +8,16 @@
 // phase (11.6 us) ran at the pace of the z stream (67 MB per iteration = 5.8 TB/s), and the other half of
 // an iteration was synchronisation: two grid barriers, a node phase on 64 of 252 workgroups, a stopping rule
 // behind a third round trip.  Here
-//   * one workgroup of 4 waves per CU, ONE wave per SIMD with the whole 512-entry register file: a wave owns
-//     C = 1 or 2 bulk tiles (64 x 64 edges each) and keeps their w in 128 registers per tile for the
-//     whole call; the workgroup's 160 KiB of LDS hold z: all 32 row pairs of a tile when C = 1, 16 of 32
-//     when C = 2 -- the other 16 stream through an 8-deep register ring that is refilled early in the pass, so
-//     the memory pipe is quiet when the hand-offs start.  Per iteration and CU 128 KB of z move instead of
-//     256 KB (C = 2), nothing at all for n <= 2880 (C = 1);
-//   * the diagonal tiles ("fringe") are dealt out as groups of <= 4 row pairs to waves that already work on
-//     the same node block; their w AND z stay in registers;
+//   * one workgroup of 8 waves per CU (two per SIMD: a lone wave issues fp64 at half rate -- measured, 410
+//     cycles per row pair against 200), 256 registers each.  The unit of work is a CHUNK: U = 32, 16 or 8
+//     consecutive row pairs (2 x 64 edges each) of one 64 x 64 tile; a wave owns one chunk and keeps its w in
+//     4 U registers for the whole call.  The workgroup's LDS holds 128 row pairs of z: everything when
+//     U <= 16 (nothing streams at all), 16 of a tile's 32 row pairs when U = 32 (n up to 4096) -- the other 16
+//     pass through a 4-deep register ring that is refilled during the first half of the pass, so the memory
+//     pipe is quiet when the hand-offs start.  LDS-resident z is stored pre-multiplied (2 gamma z);
+//   * the diagonal tiles ("fringe") are dealt out as groups of <= 2 row pairs to waves that already work on
+//     the same node block; their w and z stay in registers, their degree partials are folded into the wave's
+//     own partial vectors;
 //   * degree partials are pre-reduced inside the workgroup (LDS, fixed order) to ONE record per node block
 //     the workgroup touches (6-8 instead of 16), published as 16-byte granules {low word, tag}{high word, tag}
 //     with write-through stores; the owner of a node block (workgroup b owns block b) re-reads its records
@@ -25,7 +27,8 @@
 //     CDNA4 guide; the LGMRF ADMM of gl_lgmrf.hip uses the same records);
 //   * the stopping rule of iteration k is evaluated by every workgroup at the top of iteration k + 1, from
 //     records that arrive in the same round trip as the node values, before anything is modified -- and not
-//     at all while tol = 0 (fixed-iteration calls), except once at the end for the values reported.
+//     at all while tol = 0 (fixed-iteration calls), except once at the end for the values reported; the norms
+//     themselves are only formed in the iterations whose rule is evaluated.
 // Every sum has a fixed order (no atomics): bit-reproducible run to run.
 //
 // Nothing is written back before the end of the call (w lives in registers, the dual state in registers of
@@ -39,46 +42,43 @@
 #include "gl_logdeg.h"
 
 #ifndef GL_TILE_MIN_BULK_TILES
-#define GL_TILE_MIN_BULK_TILES 600
+#define GL_TILE_MIN_BULK_TILES 3
 #endif
 
 namespace {
 
 constexpr int TB = GL_TB;
 constexpr int SLOTS = TB / 2;  // 32 row pairs per tile
-constexpr int NBW = 11;        // node blocks one workgroup may touch
-
-// Geometry of a workgroup.  TW waves, C bulk tiles per wave, RING streamed z row pairs in registers, FR fringe
-// row pairs per wave.  The LDS holds 128 row pairs of z per workgroup: ZRES = 128 / (TW C) per tile.
-struct CfgWide {   // 4 waves x 2 tiles: one wave per SIMD with the whole register file (n up to 4096)
-    static constexpr int TW = 4, C = 2, RING = 8, FR = 4;
-};
-struct CfgPair {   // 8 waves x 1 tile: two waves per SIMD, 256 registers each (n up to 4096)
-    static constexpr int TW = 8, C = 1, RING = 4, FR = 2;
-};
-struct CfgHalf {   // 4 waves x 1 tile, z entirely in LDS, nothing streams (n up to ~2880)
-    static constexpr int TW = 4, C = 1, RING = 1, FR = 4;
-};
+constexpr int TW = 8;          // waves per workgroup (two per SIMD)
+constexpr int TT = TW * 64;
+constexpr int NBW = 15;        // node blocks one workgroup may touch (8 chunks: at most 16 distinct ones)
+constexpr int FRMAX = 2;       // fringe row pairs per wave
+constexpr int RING = 4;        // register ring of streamed z row pairs (U = 32)
+constexpr int NACQ = (NBW + TW - 1) / TW;  // node blocks one wave fetches
+constexpr int RND = 4;         // records per wave and round of an owner's poll
 
 typedef unsigned int tl_u4 __attribute__((ext_vector_type(4)));
 
 struct WaveDesc {  // 16 ints
-    int tile[2];   // bulk tile of chunk c (-1: none)
-    int I[2], J[2];
-    int si[2], sj[2];          // slots of I and J in the workgroup's block list
-    int ragged[2];             // the chunk's column block is the ragged last one
-    int fs, fa0, fcnt, fB;     // fringe group: block-list slot, first row pair, count (0: none), diagonal block
+    int tile;      // bulk tile of my chunk (-1: none)
+    int I, J;      // its node blocks
+    int a0;        // first row pair of the chunk inside the tile
+    int si, sj;    // slots of I and J in the workgroup's block list
+    int fcnt;      // fringe group: row pairs fa0 .. fa0 + fcnt - 1 of diagonal tile (fB, fB); 0: none
+    int fa0, fB, fs;  // ... its first row pair, node block, slot of that block in the workgroup's list
+    int ftgt;      // where its degree partials are folded: 0 = my row vectors (fB == I, or no chunk), 2 = my column vectors (fB == J)
+    int pad[5];
 };
-struct WgDesc {  // 64 ints
+struct WgDesc {  // 128 ints
     int nblk;
     int own;             // node block this workgroup owns (-1: none)
     int own_e0, own_e1;  // its records in `part`
-    int blk[NBW], ent[NBW], rowmask[NBW], colmask[NBW], frmask[NBW];
+    int blk[NBW], ent[NBW], rowmask[NBW], colmask[NBW];
     unsigned slice_lo, slice_hi;  // owners: bit r set = workgroup own + r nb takes part (publishes norm records)
     int active;                   // this workgroup has edges or owns a block (the others leave after the rendezvous)
-    int pad[2];
+    int pad[128 - 7 - 4 * NBW];
 };
-static_assert(sizeof(WaveDesc) == 64 && sizeof(WgDesc) == 256, "descriptor sizes");
+static_assert(sizeof(WaveDesc) == 64 && sizeof(WgDesc) == 512, "descriptor sizes");
 
 struct TileDev {
     double *w;        // tiled iterate buffer: read at the start, written at the end
@@ -132,47 +132,47 @@ __device__ __forceinline__ double2 tl_ldz(const double *base, unsigned byte_off)
     return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
-// One bulk tile: 32 row pairs, w in registers.  Row pairs s < NS come through the register ring (shared by
-// the wave's chunks: the stream of an iteration is chunk 0's first NS row pairs, then chunk 1's), the others
-// from the tile's LDS slice.  Row sums by a halving butterfly per 8 row pairs, column sums in registers;
-// everything leaves through LDS (s_out: [4][64] = row p, row w, column p, column w).
-template <class K, bool RAGGED, bool NORMS, int CI>
-__device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[SLOTS], double2 (&zr)[K::RING], const double2 *zl,
-                                              const unsigned (&zb)[2], const bool (&has)[2], const double2 *s_rows,
-                                              const double dj0, const double dj1, const double pj0, const double pj1,
-                                              const double m0, const double m1, double *s_out, const int lane, double &nqy,
-                                              double &nw) {
-    constexpr int C = K::C, RING = K::RING;
-    constexpr int NS = SLOTS - 128 / (K::TW * K::C);  // streamed row pairs per chunk
+// One chunk: U row pairs of a bulk tile, w in registers.  With U = 32 the first 16 row pairs come through the
+// register ring (refilled RING row pairs ahead; the refills of the second half of the stream are next
+// iteration's first row pairs: z never changes), the others -- and everything when U <= 16 -- from the chunk's
+// LDS slice, pre-multiplied by 2 gamma.  Row sums by a halving butterfly per 4 row pairs, column sums in
+// registers; everything leaves through LDS (row p, row w, column p, column w vectors of 64; rows are those of
+// the whole tile, the chunk fills its own 2 U of them).
+// The LDS operands of row pair s + 1 are requested before row pair s is computed: the empty asm after every
+// row pair (it pins the running sums, which LLVM otherwise sinks to the end of the unrolled body, spilling every
+// addend on the way) is a scheduling boundary.
+template <int U, bool RAGGED, bool NORMS>
+__device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[U], double2 (&zr)[RING], const double2 *zl,
+                                              const unsigned zb, const double2 *s_rows, const double dj0, const double dj1,
+                                              const double pj0, const double pj1, const double m0, const double m1,
+                                              double *s_row, double *s_col, const int lane, double &nqy, double &nw) {
+    constexpr int NS = U == SLOTS ? SLOTS / 2 : 0;  // streamed row pairs
     const int half = lane >> 5, c0 = 2 * (lane & 31);
     const double c = P.c, g = P.gamma, g2 = P.g2;
     double colp0 = 0, colp1 = 0, colw0 = 0, colw1 = 0;
-    // One wave per SIMD: nobody hides an LDS round trip, so the LDS operands of row pair s + 1 are requested
-    // before row pair s is computed (the empty asm after every row pair is a scheduling boundary).
-    // LDS-resident z is stored pre-multiplied (2 gamma z, rounded as the product is in the reference, :150).
+    // not loop-invariant for the compiler: otherwise it hoists one 64-bit address per streamed row pair (and the
+    // LDS addresses) out of the iteration loop, for each instantiation of this pass, and spills them all
+    unsigned zbv = zb;
+    asm volatile("" : "+v"(zbv));
     double2 rv_n = s_rows[half];
     double2 zl_n = double2{0.0, 0.0};
     if (NS == 0) zl_n = zl[0];
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-        double rowp[8], roww[8];
+    for (int gq = 0; gq < U / 4; ++gq) {
+        double rowp[4], roww[4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int s = 8 * gq + k;
-            double2 gz;  // 2 gamma z of this row pair
+        for (int k = 0; k < 4; ++k) {
+            const int s = 4 * gq + k;
+            double2 gz;  // 2 gamma z of this row pair (:150)
             if (s < NS) {
-                const int pos = (CI * NS + s) % RING;
+                const int pos = s % RING;
                 gz = double2{g2 * zr[pos].x, g2 * zr[pos].y};
-                // refill: element e of the stream (wraps into the next iteration: z never changes)
-                const int e = CI * NS + s + RING;
-                const int tc = (e / (NS > 0 ? NS : 1)) % C, ts = e % (NS > 0 ? NS : 1);
-                // (a wave with one tile only: its stream is that tile's row pairs alone, same positions)
-                zr[pos] = tl_ldz(P.z, (has[tc] ? zb[tc] : zb[CI]) + (unsigned)(ts * (2 * TB) * 8));
+                zr[pos] = tl_ldz(P.z, zbv + (unsigned)(((s + RING) % (NS > 0 ? NS : 1)) * (2 * TB) * 8));
             } else {
                 gz = zl_n;
             }
             const double2 rv = rv_n;  // {d_i, pbar_i}: one address per half-wave (broadcast)
-            if (s + 1 < SLOTS) {
+            if (s + 1 < U) {
                 rv_n = s_rows[2 * (s + 1) + half];
                 if (s + 1 >= NS) zl_n = zl[(s + 1 - NS) * 64];
             }
@@ -216,12 +216,12 @@ __device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[
             else
                 asm volatile("" : "+v"(colp0), "+v"(colp1), "+v"(colw0), "+v"(colw1));
         }
-        const double rw = halfwave_rows8(roww, lane);
-        const double rp = halfwave_rows8(rowp, lane);
-        if ((lane & 3) == 0) {
-            const int row = 16 * gq + 2 * ((lane >> 2) & 7) + half;
-            s_out[row] = rp;
-            s_out[TB + row] = rw;
+        const double rw = halfwave_rows4(roww, lane);  // lane l: the total of row pair (l >> 3) & 3 of the group
+        const double rp = halfwave_rows4(rowp, lane);
+        if ((lane & 7) == 0) {
+            const int row = 2 * (4 * gq + ((lane >> 3) & 3)) + half;
+            s_row[row] = rp;       // (s_row points at the chunk's first row inside the tile's row vector)
+            s_row[TB + row] = rw;
         }
     }
     colp0 = add_xor32(colp0);
@@ -229,23 +229,23 @@ __device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[
     colw0 = add_xor32(colw0);
     colw1 = add_xor32(colw1);
     if (half == 0) {
-        s_out[2 * TB + c0] = colp0;
-        s_out[2 * TB + c0 + 1] = colp1;
-        s_out[3 * TB + c0] = colw0;
-        s_out[3 * TB + c0 + 1] = colw1;
+        s_col[c0] = colp0;
+        s_col[c0 + 1] = colp1;
+        s_col[TB + c0] = colw0;
+        s_col[TB + c0 + 1] = colw1;
     }
 }
 
-template <class K, bool RAGGED>
-__global__ __launch_bounds__(K::TW * 64, K::TW / 4) void k_tile(TileDev P) {
-    constexpr int TW = K::TW, C = K::C, RING = K::RING, FRMAX = K::FR;
-    constexpr int ZRES = 128 / (TW * C);              // LDS-resident row pairs of z per chunk
-    constexpr int NS = SLOTS - ZRES;                  // streamed ones
-    constexpr int NACQ = (NBW + TW - 1) / TW;         // node blocks one wave fetches
-    __shared__ double2 s_z[TW * C][ZRES][64];         // 128 KiB
+// NORMS: the norms of the stopping rule are formed every iteration (calls with tol > 0, and synchronous calls, which
+// report the ratios of their last iteration); without, the pass is a fifth shorter (asynchronous fixed-iteration calls).
+// One instantiation of the pass per kernel: two of them inside one loop cost 150 registers (measured).
+template <int U, bool RAGGED, bool NORMS>
+__global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
+    constexpr int ZRES = U == SLOTS ? SLOTS / 2 : U;  // LDS-resident row pairs of z per chunk
+    constexpr int NS = U - ZRES;                      // streamed ones
+    __shared__ double2 s_z[TW][ZRES][64];             // up to 128 KiB
     __shared__ double2 s_node[NBW][TB];               // {d, pbar} of the node blocks this workgroup touches
-    __shared__ double s_part[8][4][TB];               // per chunk: row p, row w, column p, column w (owner phase: s_own)
-    __shared__ double s_fr[TW][2][TB];                // per wave: its fringe group's contribution to its diagonal block
+    __shared__ double s_part[TW][4][TB];              // per chunk: row p, row w, column p, column w (owner phase: s_own)
     __shared__ double s_wn[TW][2];
     __shared__ double s_ns[2];
     __shared__ int s_flag[4];                         // {rendezvous ok, failed, stop, -}
@@ -257,68 +257,64 @@ __global__ __launch_bounds__(K::TW * 64, K::TW / 4) void k_tile(TileDev P) {
     if (P.ctr[4] != 0) return;  // an earlier launch of this session failed and has not been looked at yet
 
     const WaveDesc wdv = P.wd[wg * TW + wave];
-    // the workgroup's descriptor: lane l keeps word l, wave-uniform reads go through v_readlane
-    const int gdw = reinterpret_cast<const int *>(P.gd + wg)[lane];
-    auto gd_int = [&](int idx) { return __builtin_amdgcn_readlane(gdw, idx); };
-    constexpr int GD_BLK = 4, GD_ENT = GD_BLK + NBW, GD_ROW = GD_ENT + NBW, GD_COL = GD_ROW + NBW, GD_FR = GD_COL + NBW;
-    constexpr int GD_SLICE = GD_FR + NBW, GD_ACTIVE = GD_SLICE + 2;
+    // the workgroup's descriptor: lane l keeps words l and 64 + l, wave-uniform reads go through v_readlane
+    const int gdw0 = reinterpret_cast<const int *>(P.gd + wg)[lane], gdw1 = reinterpret_cast<const int *>(P.gd + wg)[64 + lane];
+    auto gd_int = [&](int idx) { return idx < 64 ? __builtin_amdgcn_readlane(gdw0, idx) : __builtin_amdgcn_readlane(gdw1, idx - 64); };
+    constexpr int GD_BLK = 4, GD_ENT = GD_BLK + NBW, GD_ROW = GD_ENT + NBW, GD_COL = GD_ROW + NBW;
+    constexpr int GD_SLICE = GD_COL + NBW, GD_ACTIVE = GD_SLICE + 2;
     const int nblk = gd_int(0), own = gd_int(1), own_e0 = gd_int(2), own_e1 = gd_int(3);
     const unsigned long long slice_mask = ((unsigned long long)(unsigned)gd_int(GD_SLICE + 1) << 32) | (unsigned)gd_int(GD_SLICE);
     const bool active = gd_int(GD_ACTIVE) != 0;
     unsigned *err = P.bar + 32;
 
     // ---- static work of this wave
-    bool has[2] = {wdv.tile[0] >= 0, C == 2 && wdv.tile[1] >= 0};
-    unsigned zb[2] = {0u, 0u};
-    double2 wreg[C][SLOTS];
+    const bool has = wdv.tile >= 0;
+    const int a0 = wdv.a0;
+    unsigned zb = 0u;
+    double2 wreg[U];
     double2 zr[RING];
 #pragma unroll
     for (int k = 0; k < RING; ++k) zr[k] = double2{0.0, 0.0};
 #pragma unroll
-    for (int ci = 0; ci < C; ++ci) {
+    for (int s = 0; s < U; ++s) wreg[s] = double2{0.0, 0.0};
+    if (has) {
+        const int64_t tb = (int64_t)wdv.tile * GL_TILE_ELEMS + (int64_t)a0 * (2 * TB) + lofs;
+        zb = (unsigned)(tb * 8);
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) wreg[ci][s] = double2{0.0, 0.0};
-        if (has[ci]) {
-            const int64_t tb = (int64_t)wdv.tile[ci] * GL_TILE_ELEMS + lofs;
-            zb[ci] = (unsigned)(tb * 8);
+        for (int s = 0; s < U; ++s) wreg[s] = *reinterpret_cast<const double2 *>(P.w + tb + s * (2 * TB));
 #pragma unroll
-            for (int s = 0; s < SLOTS; ++s) wreg[ci][s] = *reinterpret_cast<const double2 *>(P.w + tb + s * (2 * TB));
+        for (int s = NS; s < U; ++s) {  // LDS-resident part, pre-multiplied: 2 gamma z
+            const double2 zv = *reinterpret_cast<const double2 *>(P.z + tb + s * (2 * TB));
+            s_z[wave][s - NS][lane] = double2{P.g2 * zv.x, P.g2 * zv.y};
+        }
+        if (NS > 0) {
 #pragma unroll
-            for (int s = NS; s < SLOTS; ++s) {  // LDS-resident part, pre-multiplied: 2 gamma z
-                const double2 zv = *reinterpret_cast<const double2 *>(P.z + tb + s * (2 * TB));
-                s_z[wave * C + ci][s - NS][lane] = double2{P.g2 * zv.x, P.g2 * zv.y};
-            }
+            for (int k = 0; k < RING; ++k) zr[k] = tl_ldz(P.z, zb + (unsigned)(k * (2 * TB) * 8));
         }
     }
-    if (NS > 0) {  // the ring starts with chunk 0's first row pairs
-#pragma unroll
-        for (int k = 0; k < RING; ++k) {
-            const int tc = (k / (NS > 0 ? NS : 1)) % C, ts = k % (NS > 0 ? NS : 1);
-            if (has[tc]) zr[k] = tl_ldz(P.z, zb[tc] + (unsigned)(ts * (2 * TB) * 8));
-        }
+    if (U < SLOTS) {  // rows of the tile outside my chunk contribute nothing to my row vectors
+        s_part[wave][0][lane] = 0.0;
+        s_part[wave][1][lane] = 0.0;
     }
-    // fringe group: row pairs fa0 .. fa0 + fcnt - 1 of diagonal tile (fB, fB), w and z in registers
-    const int fcnt = wdv.fcnt, fa0 = wdv.fa0, fB = wdv.fB, fs = wdv.fs;
-    double2 fw[FRMAX], fz[FRMAX];
+    // fringe group: row pairs fa0 .. fa0 + fcnt - 1 of diagonal tile (fB, fB), w and 2 gamma z in registers
+    const int fcnt = wdv.fcnt, fa0 = wdv.fa0, fB = wdv.fB, fs = wdv.fs, ftgt = wdv.ftgt;
+    double2 fw[FRMAX], fgz[FRMAX];
     int64_t ftb = 0;
     if (fcnt > 0) ftb = gl_tile_id(fB, fB, P.nb) * GL_TILE_ELEMS + lofs;
 #pragma unroll
     for (int f = 0; f < FRMAX; ++f) {
-        fw[f] = fz[f] = double2{0.0, 0.0};
+        fw[f] = fgz[f] = double2{0.0, 0.0};
         if (f < fcnt) {
             fw[f] = *reinterpret_cast<const double2 *>(P.w + ftb + (int64_t)(fa0 + f) * (2 * TB));
-            fz[f] = *reinterpret_cast<const double2 *>(P.z + ftb + (int64_t)(fa0 + f) * (2 * TB));
+            const double2 zv = *reinterpret_cast<const double2 *>(P.z + ftb + (int64_t)(fa0 + f) * (2 * TB));
+            fgz[f] = double2{P.g2 * zv.x, P.g2 * zv.y};
         }
     }
     // ragged last block column: 0 / 1 factors of my two columns
-    double m0[2] = {1.0, 1.0}, m1[2] = {1.0, 1.0};
-    if (RAGGED) {
-#pragma unroll
-        for (int ci = 0; ci < C; ++ci)
-            if (has[ci]) {
-                m0[ci] = (int64_t)wdv.J[ci] * TB + c0 < P.n ? 1.0 : 0.0;
-                m1[ci] = (int64_t)wdv.J[ci] * TB + c0 + 1 < P.n ? 1.0 : 0.0;
-            }
+    double m0 = 1.0, m1 = 1.0;
+    if (RAGGED && has) {
+        m0 = (int64_t)wdv.J * TB + c0 < P.n ? 1.0 : 0.0;
+        m1 = (int64_t)wdv.J * TB + c0 + 1 < P.n ? 1.0 : 0.0;
     }
     // ---- dual state of my node block (owner workgroups, wave 0, lane = node)
     double d_cur = 0, yb_cur = 0, pb_cur = 0, d_prev = 0;
@@ -357,7 +353,7 @@ __global__ __launch_bounds__(K::TW * 64, K::TW / 4) void k_tile(TileDev P) {
         const unsigned tag_out = P.tag0 + (unsigned)it + 1u;  // what iteration `it` produces
         const bool last_pass = it == P.maxit;
         // does this workgroup evaluate the rule of iteration it - 1 now?
-        const bool want_rule = it >= 1 && (last_pass ? wg == 0 : rule_on);
+        const bool want_rule = NORMS && it >= 1 && (last_pass ? wg == 0 : rule_on);
         if (last_pass && !want_rule) break;
         const bool stamp = P.dbg != nullptr && it >= 8 && it < 24 && !last_pass;
         unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
@@ -376,7 +372,7 @@ __global__ __launch_bounds__(K::TW * 64, K::TW / 4) void k_tile(TileDev P) {
                             s_node[k][lane] = double2{P.dvar[i], P.pbar[i]};
                         }
                     }
-                } else {
+                } else if (wave < nblk) {
                     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                     unsigned spins = 0;
                     tl_u4 g[NACQ][2];
@@ -460,36 +456,13 @@ __global__ __launch_bounds__(K::TW * 64, K::TW / 4) void k_tile(TileDev P) {
         // ================= edge phase =================
         if (stamp) ts[1] = __builtin_amdgcn_s_memrealtime();
         double nqy = 0, nw = 0;
-        // the norms of the stopping rule are only formed when somebody will look at them: every iteration while
-        // tol > 0, else in the last iteration of the call (the ratios the host reports)
-        const bool norms = rule_on || it + 1 == P.maxit;
-#pragma unroll
-        for (int ci = 0; ci < C; ++ci) {
-            if (has[ci]) {
-                const double2 cv0 = s_node[wdv.sj[ci]][c0], cv1 = s_node[wdv.sj[ci]][c0 + 1];
-                if (ci == 0) {
-                    if (norms)
-                        tl_chunk_pass<K, RAGGED, true, 0>(P, wreg[0], zr, &s_z[wave * C][0][lane], zb, has, &s_node[wdv.si[0]][0],
-                                                          cv0.x, cv1.x, cv0.y, cv1.y, m0[0], m1[0], &s_part[wave * C][0][0], lane,
-                                                          nqy, nw);
-                    else
-                        tl_chunk_pass<K, RAGGED, false, 0>(P, wreg[0], zr, &s_z[wave * C][0][lane], zb, has, &s_node[wdv.si[0]][0],
-                                                           cv0.x, cv1.x, cv0.y, cv1.y, m0[0], m1[0], &s_part[wave * C][0][0], lane,
-                                                           nqy, nw);
-                } else {
-                    if (norms)
-                        tl_chunk_pass<K, RAGGED, true, C - 1>(P, wreg[C - 1], zr, &s_z[wave * C + C - 1][0][lane], zb, has,
-                                                              &s_node[wdv.si[C - 1]][0], cv0.x, cv1.x, cv0.y, cv1.y, m0[C - 1],
-                                                              m1[C - 1], &s_part[wave * C + C - 1][0][0], lane, nqy, nw);
-                    else
-                        tl_chunk_pass<K, RAGGED, false, C - 1>(P, wreg[C - 1], zr, &s_z[wave * C + C - 1][0][lane], zb, has,
-                                                               &s_node[wdv.si[C - 1]][0], cv0.x, cv1.x, cv0.y, cv1.y, m0[C - 1],
-                                                               m1[C - 1], &s_part[wave * C + C - 1][0][0], lane, nqy, nw);
-                }
-            }
+        if (has) {
+            const double2 cv0 = s_node[wdv.sj][c0], cv1 = s_node[wdv.sj][c0 + 1];
+            tl_chunk_pass<U, RAGGED, NORMS>(P, wreg, zr, &s_z[wave][0][lane], zb, &s_node[wdv.si][2 * a0], cv0.x, cv1.x, cv0.y, cv1.y,
+                                            m0, m1, &s_part[wave][0][2 * a0], &s_part[wave][2][0], lane, nqy, nw);
         }
         if (fcnt > 0) {  // my fringe row pairs (diagonal tile: entries i < j < n only)
-            const double c = P.c, g = P.gamma, g2 = P.g2;
+            const double c = P.c, g = P.gamma;
             const double2 cv0 = s_node[fs][c0], cv1 = s_node[fs][c0 + 1];
             double colp0 = 0, colp1 = 0, colw0 = 0, colw1 = 0;
             double rsp[FRMAX], rsw[FRMAX];
@@ -505,17 +478,19 @@ __global__ __launch_bounds__(K::TW * 64, K::TW / 4) void k_tile(TileDev P) {
                     for (int e = 0; e < 2; ++e) {
                         const int64_t j = (int64_t)fB * TB + c0 + e;
                         const bool valid = i < j && j < P.n;
-                        const double w = e ? fw[f].y : fw[f].x, z = e ? fz[f].y : fz[f].x;
+                        const double w = e ? fw[f].y : fw[f].x;
                         const double y = c * w - g * (rv.x + (e ? cv1.x : cv0.x));
-                        const double tt = y - g2 * z;
+                        const double tt = y - (e ? fgz[f].y : fgz[f].x);
                         const double pr = tt > 0 ? tt : 0.0;
                         const double q = c * pr - g * (rv.y + (e ? cv1.y : cv0.y));
                         const double wnew = (w - y) + q;
-                        const double dq = q - y;
                         pp[e] = valid ? pr : 0.0;
                         wn[e] = valid ? wnew : 0.0;
-                        nqy += valid ? dq * dq : 0.0;
-                        nw += valid ? w * w : 0.0;
+                        if (NORMS) {
+                            const double dq = q - y;
+                            nqy += valid ? dq * dq : 0.0;
+                            nw += valid ? w * w : 0.0;
+                        }
                     }
                     colp0 += pp[0];
                     colp1 += pp[1];
@@ -530,26 +505,34 @@ __global__ __launch_bounds__(K::TW * 64, K::TW / 4) void k_tile(TileDev P) {
             colp1 = add_xor32(colp1);
             colw0 = add_xor32(colw0);
             colw1 = add_xor32(colw1);
+            // Rows and columns of a diagonal tile are the same node block, and that block is my chunk's row or
+            // column block (or I have no chunk): the group's partials are folded into those vectors of mine.
+            // LDS operations of one wave execute in order.
+            double *vp = &s_part[wave][ftgt][0], *vw = &s_part[wave][ftgt + 1][0];
             if (half == 0) {
-                s_fr[wave][0][c0] = colp0;
-                s_fr[wave][0][c0 + 1] = colp1;
-                s_fr[wave][1][c0] = colw0;
-                s_fr[wave][1][c0 + 1] = colw1;
+                // (row vectors of a chunk shorter than a tile are zero outside its rows: rewritten every pass)
+                const bool keep0 = has && (ftgt == 2 || (c0 >= 2 * a0 && c0 < 2 * (a0 + U)));
+                const double b0 = keep0 ? vp[c0] : 0.0, b1 = keep0 ? vp[c0 + 1] : 0.0;
+                const double e0 = keep0 ? vw[c0] : 0.0, e1 = keep0 ? vw[c0 + 1] : 0.0;
+                vp[c0] = b0 + colp0;
+                vp[c0 + 1] = b1 + colp1;
+                vw[c0] = e0 + colw0;
+                vw[c0 + 1] = e1 + colw1;
             }
-            // the row sums join the same vector (rows and columns of a diagonal tile are the same node block);
-            // LDS operations of one wave execute in order
             if ((lane & 31) == 0) {
 #pragma unroll
                 for (int f = 0; f < FRMAX; ++f)
                     if (f < fcnt) {
                         const int r = 2 * (fa0 + f) + half;
-                        s_fr[wave][0][r] += rsp[f];
-                        s_fr[wave][1][r] += rsw[f];
+                        vp[r] += rsp[f];
+                        vw[r] += rsw[f];
                     }
             }
         }
-        nqy = wave_sum(nqy);
-        nw = wave_sum(nw);
+        if (NORMS) {
+            nqy = wave_sum(nqy);
+            nw = wave_sum(nw);
+        }
         if (lane == 0) {
             s_wn[wave][0] = nqy;
             s_wn[wave][1] = nw;
@@ -561,9 +544,9 @@ __global__ __launch_bounds__(K::TW * 64, K::TW / 4) void k_tile(TileDev P) {
 #pragma unroll 1
         for (int k = wave; k < nblk; k += TW) {
             double sp = 0, sw = 0;
-            const int rm = gd_int(GD_ROW + k), cm = gd_int(GD_COL + k), fm = gd_int(GD_FR + k);
+            const int rm = gd_int(GD_ROW + k), cm = gd_int(GD_COL + k);
 #pragma unroll
-            for (int cs = 0; cs < C * TW; ++cs) {
+            for (int cs = 0; cs < TW; ++cs) {
                 if ((rm >> cs) & 1) {
                     sp += s_part[cs][0][lane];
                     sw += s_part[cs][1][lane];
@@ -573,12 +556,6 @@ __global__ __launch_bounds__(K::TW * 64, K::TW / 4) void k_tile(TileDev P) {
                     sw += s_part[cs][3][lane];
                 }
             }
-#pragma unroll
-            for (int v = 0; v < TW; ++v)
-                if ((fm >> v) & 1) {
-                    sp += s_fr[v][0][lane];
-                    sw += s_fr[v][1][lane];
-                }
             const int off = (gd_int(GD_ENT + k) * 2 * TB + lane) * 16;
             __builtin_amdgcn_raw_buffer_store_b128(tl_gran(sp, tag_out), r_part, off, 0, 16);
             __builtin_amdgcn_raw_buffer_store_b128(tl_gran(sw, tag_out), r_part, off + TB * 16, 0, 16);
@@ -599,15 +576,14 @@ __global__ __launch_bounds__(K::TW * 64, K::TW / 4) void k_tile(TileDev P) {
 
         // ================= node phase: the owner of a block sums its records and updates the dual state =================
         if (own >= 0) {
-            __syncthreads();  // everybody has read s_part (its first TW KiB become s_own now)
+            __syncthreads();  // everybody has read s_part (its first 8 KiB become s_own now)
             double (*s_own)[2][TB] = reinterpret_cast<double (*)[2][TB]>(&s_part[0][0][0]);
             bool good = true;
             double sp = 0, sw = 0;
             {
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 unsigned spins = 0;
-                constexpr int RND = 32 / TW;  // records per wave and round
-                for (int eb = own_e0 + wave; eb < own_e1 && good; eb += TW * RND) {
+                for (int eb = own_e0 + wave; eb < own_e1 && good; eb += TW * RND) {  // rounds of up to RND records per wave
                     tl_u4 g[RND][2];
                     for (;;) {
                         bool ok = true;
@@ -700,7 +676,11 @@ __global__ __launch_bounds__(K::TW * 64, K::TW / 4) void k_tile(TileDev P) {
                     __builtin_amdgcn_raw_buffer_store_b128(tl_gran(v, tag_out), r_bn, ((((it & 3) * (int)P.nb + own) * 4) + lane) * 16, 0, 16);
                 }
             }
-            // (s_own is read by wave 0 only; the next writes to that LDS come after the next acquire's barrier)
+            __syncthreads();  // s_own has been read: s_part is free for the next pass (its zeros first, below)
+            if (U < SLOTS) {  // s_own overwrote row vectors: back to zero outside the chunks' rows
+                s_part[wave][0][lane] = 0.0;
+                s_part[wave][1][lane] = 0.0;
+            }
         }
         if (stamp && tid == 0) {
             ts[5] = __builtin_amdgcn_s_memrealtime();
@@ -717,13 +697,11 @@ __global__ __launch_bounds__(K::TW * 64, K::TW / 4) void k_tile(TileDev P) {
         return;
     }
     // ---- registers back to the iterate buffer, dual state back to memory, bookkeeping for the host / the other engines
+    if (has) {
+        const int64_t tb = (int64_t)wdv.tile * GL_TILE_ELEMS + (int64_t)a0 * (2 * TB) + lofs;
 #pragma unroll
-    for (int ci = 0; ci < C; ++ci)
-        if (has[ci]) {
-            const int64_t tb = (int64_t)wdv.tile[ci] * GL_TILE_ELEMS + lofs;
-#pragma unroll
-            for (int s = 0; s < SLOTS; ++s) *reinterpret_cast<double2 *>(P.w + tb + s * (2 * TB)) = wreg[ci][s];
-        }
+        for (int s = 0; s < U; ++s) *reinterpret_cast<double2 *>(P.w + tb + s * (2 * TB)) = wreg[s];
+    }
 #pragma unroll
     for (int f = 0; f < FRMAX; ++f)
         if (f < fcnt) *reinterpret_cast<double2 *>(P.w + ftb + (int64_t)(fa0 + f) * (2 * TB)) = fw[f];
@@ -753,16 +731,13 @@ __global__ __launch_bounds__(K::TW * 64, K::TW / 4) void k_tile(TileDev P) {
 }  // namespace
 
 // =========================================================================== host side
-enum { TILE_WIDE = 0, TILE_PAIR = 1, TILE_HALF = 2 };
-
 struct gl_tile {
     TileDev dev{};
-    int cfg = TILE_WIDE;
+    int U = SLOTS;              // row pairs per chunk: 32, 16 or 8
     void *arena = nullptr;      // descriptors, record buffers, rendezvous words: one allocation
     size_t gran_off = 0, gran_bytes = 0;  // the record buffers inside it
     unsigned long long *dbg = nullptr;
     unsigned next_tag = 1u;     // first tag of the next launch (a launch uses maxit + 2 consecutive ones, never 0)
-    int C = 1;
 };
 
 void gl_tile_free(gl_logdeg *s) {
@@ -786,57 +761,57 @@ int gl_tile_prepare(gl_logdeg *s) {
     const int ncu = ctx->prop.multiProcessorCount;
     const int nb = (int)D.nb;
     if (nb > 64) return GL_OK;  // one norm record per lane in the rule's poll; larger lattices do not fit the register files anyway
-    // bulk tiles in super-tile order (2 block rows x 4 block columns): consecutive tiles share node blocks, so a
-    // workgroup's tiles touch few of them
-    std::vector<std::pair<int, int>> bulk;
-    for (int IB = 0; 2 * IB < nb; ++IB)
-        for (int JB = 0; 4 * JB < nb; ++JB)
-            for (int a = 0; a < 2; ++a)
-                for (int b = 0; b < 4; ++b) {
-                    const int I = 2 * IB + a, J = 4 * JB + b;
-                    if (I < J && J < nb) bulk.push_back({I, J});
-                }
-    const int F = (int)bulk.size();
-    if (F > 8 * ncu) return GL_OK;  // does not fit the register files
-    if (!forced && F < GL_TILE_MIN_BULK_TILES) return GL_OK;
-    // geometry: up to 4 tiles per workgroup everything of z is LDS-resident (CfgHalf); beyond, 8 tiles per
-    // workgroup as 4 waves x 2 (CfgWide, default) or 8 waves x 1 (CfgPair, GRAPHLEARN_AMD_TILE_CFG=pair)
-    int cfg = F > 4 * ncu ? TILE_WIDE : TILE_HALF;
-    if (const char *e = getenv("GRAPHLEARN_AMD_TILE_CFG")) {
-#ifdef GL_TILE_WITH_PAIR
-        if (!strcmp(e, "pair")) cfg = TILE_PAIR;
-#endif
-        if (!strcmp(e, "wide")) cfg = TILE_WIDE;
-        if (!strcmp(e, "half") && F <= 4 * ncu) cfg = TILE_HALF;
+    const int F = nb * (nb - 1) / 2;  // bulk (off-diagonal) tiles
+    if (F > TW * ncu) return GL_OK;   // does not fit the register files
+    if (!forced && F < GL_TILE_MIN_BULK_TILES) return GL_OK;  // (n <= 128 belongs to the small engine)
+    // chunk length: the finest split that still fits one chunk per wave of the chip (shorter edge phase)
+    int U = F * 4 <= TW * ncu ? 8 : (F * 2 <= TW * ncu ? 16 : 32);
+    if (const char *e = getenv("GRAPHLEARN_AMD_TILE_U")) {
+        const int u = atoi(e);
+        if ((u == 8 || u == 16 || u == 32) && F * (SLOTS / u) <= TW * ncu) U = u;
     }
-    const int TW = cfg == TILE_PAIR ? CfgPair::TW : 4, C = cfg == TILE_WIDE ? 2 : 1;
-    const int FRMAX = cfg == TILE_PAIR ? CfgPair::FR : 4;
-    int NWG = (F + TW * C - 1) / (TW * C);
-    NWG = std::max(NWG, std::min(ncu, std::max(2 * nb, (32 * nb + TW * 3 - 1) / (TW * 3))));
-    NWG = std::min(std::max(NWG, nb), ncu);
-    if (NWG < nb) return GL_OK;  // every node block needs an owner workgroup
+    // Order of the bulk tiles.  A workgroup's 8 chunks are U / 4 tiles: one "super-tile" of SR block rows x SC block
+    // columns (2 x 4, 2 x 2, 1 x 2), which touches SR + SC node blocks only.  Complete super-tiles come first, one per
+    // workgroup; the tiles of incomplete ones (along the diagonal and the lattice's edge) follow row by row.
+    const int SR = U == 8 ? 1 : 2, SC = U == 32 ? 4 : 2;
+    std::vector<std::pair<int, int>> bulk, rest;
+    for (int IB = 0; SR * IB < nb; ++IB)
+        for (int JB = 0; SC * JB < nb; ++JB) {
+            std::vector<std::pair<int, int>> st;
+            for (int a = 0; a < SR; ++a)
+                for (int b = 0; b < SC; ++b) {
+                    const int I = SR * IB + a, J = SC * JB + b;
+                    if (I < J && J < nb) st.push_back({I, J});
+                }
+            auto &dst = (int)st.size() == SR * SC ? bulk : rest;
+            dst.insert(dst.end(), st.begin(), st.end());
+        }
+    std::sort(rest.begin(), rest.end());
+    bulk.insert(bulk.end(), rest.begin(), rest.end());
+    const int per_tile = SLOTS / U, nchunks = F * per_tile;
+    int NWG = (nchunks + TW - 1) / TW;
+    NWG = std::max(NWG, (SLOTS * nb * 4 + TW * FRMAX * 3 - 1) / (TW * FRMAX * 3));  // room for the fringe, a third to spare
+    NWG = std::max(NWG, nb);                                                         // every node block needs an owner
+    if (NWG > ncu || NWG > 64 * nb) return GL_OK;
     const int nwaves = NWG * TW;
     std::vector<WaveDesc> wd((size_t)nwaves);
     for (WaveDesc &w : wd) {
-        w.tile[0] = w.tile[1] = -1;
-        w.I[0] = w.I[1] = w.J[0] = w.J[1] = 0;
-        w.si[0] = w.si[1] = w.sj[0] = w.sj[1] = 0;
-        w.ragged[0] = w.ragged[1] = 0;
-        w.fs = w.fa0 = w.fcnt = 0;
+        memset(&w, 0, sizeof w);
+        w.tile = -1;
         w.fB = -1;
     }
-    for (int f = 0; f < F; ++f) {
-        WaveDesc &w = wd[(size_t)(f / C)];
-        const int c = f % C;
-        w.tile[c] = (int)gl_tile_id(bulk[(size_t)f].first, bulk[(size_t)f].second, nb);
-        w.I[c] = bulk[(size_t)f].first;
-        w.J[c] = bulk[(size_t)f].second;
-        w.ragged[c] = (D.n % TB != 0 && w.J[c] == nb - 1) ? 1 : 0;
+    for (int q = 0; q < nchunks; ++q) {
+        WaveDesc &w = wd[(size_t)q];
+        const int f = q / per_tile;
+        w.tile = (int)gl_tile_id(bulk[(size_t)f].first, bulk[(size_t)f].second, nb);
+        w.I = bulk[(size_t)f].first;
+        w.J = bulk[(size_t)f].second;
+        w.a0 = (q % per_tile) * U;
     }
-    // fringe: the 32 row pairs of diagonal tile (B, B) go, in groups, to waves that already work on block B
-    // (then the workgroup's block list does not grow), else to waves without any work yet
-    const int waves_with_tiles = (F + C - 1) / C;
-    const int t0 = waves_with_tiles > 0 ? std::max(1, std::min(FRMAX, (SLOTS * nb) / waves_with_tiles)) : FRMAX;
+    // fringe: the 32 row pairs of diagonal tile (B, B) go, in groups, to waves whose chunk already works on block B
+    // (then the workgroup's block list does not grow and the partials fold into the chunk's vectors), else to
+    // waves without a chunk
+    const int t0 = nchunks > 0 ? std::max(1, std::min(FRMAX, (SLOTS * nb) / nchunks)) : FRMAX;
     for (int B = 0; B < nb; ++B) {
         bool placed = false;
         for (int cap = t0; cap <= FRMAX && !placed; ++cap) {
@@ -846,9 +821,8 @@ int gl_tile_prepare(gl_logdeg *s) {
                 for (int v = 0; v < nwaves && need > 0; ++v) {
                     const WaveDesc &w = wd[(size_t)v];
                     if (w.fcnt != 0) continue;
-                    const bool works_on_b = (w.tile[0] >= 0 && (w.I[0] == B || w.J[0] == B)) ||
-                                            (w.tile[1] >= 0 && (w.I[1] == B || w.J[1] == B));
-                    const bool idle = w.tile[0] < 0;
+                    const bool works_on_b = w.tile >= 0 && (w.I == B || w.J == B);
+                    const bool idle = w.tile < 0;
                     if (pass == 0 ? !works_on_b : !idle) continue;
                     const int take = std::min(pass == 0 ? cap : FRMAX, need);
                     plan.push_back({v, take});
@@ -861,11 +835,12 @@ int gl_tile_prepare(gl_logdeg *s) {
                 w.fB = B;
                 w.fa0 = a;
                 w.fcnt = pr.second;
+                w.ftgt = (w.tile >= 0 && w.I != B) ? 2 : 0;  // my column vectors when B is my column block
                 a += pr.second;
             }
             placed = true;
         }
-        if (!placed) return GL_OK;  // (tiny lattices on few workgroups: the other engines serve them)
+        if (!placed) return GL_OK;  // (cannot happen with the room reserved above; the other engines would serve)
     }
     // block lists, records, masks
     std::vector<WgDesc> gd((size_t)NWG);
@@ -883,24 +858,22 @@ int gl_tile_prepare(gl_logdeg *s) {
         };
         for (int v = 0; v < TW; ++v) {
             WaveDesc &w = wd[(size_t)(g * TW + v)];
-            for (int c = 0; c < 2; ++c)
-                if (w.tile[c] >= 0) {
-                    w.si[c] = slot_of(w.I[c]);
-                    w.sj[c] = slot_of(w.J[c]);
-                    if (w.si[c] < 0 || w.sj[c] < 0) return GL_OK;  // too many node blocks for one workgroup's LDS
-                    G.rowmask[w.si[c]] |= 1 << (v * C + c);
-                    G.colmask[w.sj[c]] |= 1 << (v * C + c);
-                }
+            if (w.tile >= 0) {
+                w.si = slot_of(w.I);
+                w.sj = slot_of(w.J);
+                if (w.si < 0 || w.sj < 0) return GL_OK;  // too many node blocks for one workgroup's LDS
+                G.rowmask[w.si] |= 1 << v;
+                G.colmask[w.sj] |= 1 << v;
+            }
             if (w.fcnt > 0) {
                 w.fs = slot_of(w.fB);
                 if (w.fs < 0) return GL_OK;
-                G.frmask[w.fs] |= 1 << v;
+                if (w.tile < 0) G.rowmask[w.fs] |= 1 << v;  // a wave without a chunk: its row vectors carry the group alone
             }
         }
         for (int k = 0; k < G.nblk; ++k) touch[(size_t)G.blk[k]].push_back(g);
         G.active = (G.nblk > 0 || G.own >= 0) ? 1 : 0;
     }
-    if (NWG > 64 * nb) return GL_OK;  // an owner reads its slice of the norm records with one lane per workgroup
     for (int B = 0; B < nb; ++B)
         for (int r = 0; B + r * nb < NWG; ++r)
             if (gd[(size_t)(B + r * nb)].active) (r < 32 ? gd[(size_t)B].slice_lo : gd[(size_t)B].slice_hi) |= 1u << (r & 31);
@@ -961,21 +934,24 @@ int gl_tile_prepare(gl_logdeg *s) {
     P.nb = D.nb;
     P.NWG = NWG;
     P.n_entries = n_entries;
-    t->C = C;
-    t->cfg = cfg;
+    t->U = U;
     P.dbg = nullptr;
     if (getenv("GRAPHLEARN_AMD_RES_STAMPS") && hipMalloc((void **)&t->dbg, (size_t)NWG * 16 * 6 * 8) == hipSuccess) {
         (void)hipMemset(t->dbg, 0, (size_t)NWG * 16 * 6 * 8);
         P.dbg = t->dbg;
-        fprintf(stderr, "[tile] n %lld nb %d F %d cfg %d NWG %d entries %d\n", (long long)D.n, nb, F, cfg, NWG, n_entries);
+        int maxblk = 0;
+        for (const WgDesc &G : gd) maxblk = std::max(maxblk, G.nblk);
+        fprintf(stderr, "[tile] n %lld nb %d F %d U %d NWG %d records %d (%.1f per block) max blocks per workgroup %d\n", (long long)D.n, nb,
+                F, U, NWG, n_entries, (double)n_entries / nb, maxblk);
     }
     s->tile = t;
     return GL_OK;
 }
 
 // Runs up to `iters` iterations in ONE launch (asynchronous).  The iterate stays in w[it0 & 1]; the caller fixes
-// the ping-pong parity afterwards.
-int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol) {
+// the ping-pong parity afterwards.  norms = false (only with tol = 0): the ratios of the stopping rule are not
+// formed at all (dstat keeps its previous values).
+int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms) {
     gl_ctx *ctx = s->ctx;
     gl_tile *t = s->tile;
     TileDev P = t->dev;
@@ -986,6 +962,7 @@ int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol) {
     P.g2 = D.g2;
     P.a4g = D.a4g;
     P.tol = tol;
+    if (tol > 0) norms = true;
     P.it0 = s->it;
     P.maxit = (int)std::min<int64_t>(iters, 1 << 30);
     if (t->next_tag == 0u || t->next_tag > 0xE0000000u - (unsigned)P.maxit) {  // the tags would wrap into old ones
@@ -997,25 +974,23 @@ int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol) {
     P.rendezvous = P.NWG + (getenv("GRAPHLEARN_AMD_RES_TEST_NOT_RESIDENT") ? 1 : 0);
     GL_HIP(ctx, hipMemsetAsync(P.bar, 0, GL_BAR_WORDS * 4, ctx->stream));
     const bool ragged = D.n % TB != 0;
-    const dim3 grid((unsigned)P.NWG);
-    if (t->cfg == TILE_WIDE) {
-        if (ragged)
-            k_tile<CfgWide, true><<<grid, dim3(CfgWide::TW * 64), 0, ctx->stream>>>(P);
-        else
-            k_tile<CfgWide, false><<<grid, dim3(CfgWide::TW * 64), 0, ctx->stream>>>(P);
-#ifdef GL_TILE_WITH_PAIR
-    } else if (t->cfg == TILE_PAIR) {
-        if (ragged)
-            k_tile<CfgPair, true><<<grid, dim3(CfgPair::TW * 64), 0, ctx->stream>>>(P);
-        else
-            k_tile<CfgPair, false><<<grid, dim3(CfgPair::TW * 64), 0, ctx->stream>>>(P);
-#endif
-    } else {
-        if (ragged)
-            k_tile<CfgHalf, true><<<grid, dim3(CfgHalf::TW * 64), 0, ctx->stream>>>(P);
-        else
-            k_tile<CfgHalf, false><<<grid, dim3(CfgHalf::TW * 64), 0, ctx->stream>>>(P);
-    }
+    const dim3 grid((unsigned)P.NWG), block(TT);
+    auto go = [&](auto kern) { kern<<<grid, block, 0, ctx->stream>>>(P); };
+#define GL_TILE_GO(UU)                                                                       \
+    do {                                                                                     \
+        if (ragged) {                                                                        \
+            if (norms) go(k_tile<UU, true, true>); else go(k_tile<UU, true, false>);         \
+        } else {                                                                             \
+            if (norms) go(k_tile<UU, false, true>); else go(k_tile<UU, false, false>);       \
+        }                                                                                    \
+    } while (0)
+    if (t->U == 32)
+        GL_TILE_GO(32);
+    else if (t->U == 16)
+        GL_TILE_GO(16);
+    else
+        GL_TILE_GO(8);
+#undef GL_TILE_GO
     GL_HIP(ctx, hipGetLastError());
     return GL_OK;
 }
