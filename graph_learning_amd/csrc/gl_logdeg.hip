@@ -1070,6 +1070,7 @@ static int resident_check(gl_logdeg *s) {
     GL_HIP(ctx, hipMemcpyAsync(ct, s->dev.ctr, 5 * 8, hipMemcpyDeviceToHost, ctx->stream));
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     s->res_unchecked = false;
+    gl_tile_dump_stamps(s);  // development only (GRAPHLEARN_AMD_RES_STAMPS)
     if (ct[4] == 0) return GL_OK;
     const int64_t stood = (int64_t)ct[2];  // (ctr[1] is re-armed after every launch; ctr[2] = the streaming engine's iteration index)
     if (ct[4] != 1 || stood < s->it - s->res_pending || stood > s->it)

@@ -533,7 +533,8 @@ int small_set_attrs(gl_ctx *ctx) {  // per context: one process may drive severa
 bool gl_small_applicable(const gl_logdeg *s) {
     if (s->n > SMALL_MAX_N) return false;
     if (const char *e = getenv("GRAPHLEARN_AMD_ENGINE"))
-        if (!strcmp(e, "stream") || !strcmp(e, "resident")) return false;  // another engine is asked for
+        if (!strcmp(e, "stream") || !strcmp(e, "resident") || !strcmp(e, "resident1") || !strcmp(e, "tile"))
+            return false;  // another engine is asked for
     return true;
 }
 

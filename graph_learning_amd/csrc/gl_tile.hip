@@ -41,6 +41,9 @@
 #include "gl_lanes.h"
 #include "gl_logdeg.h"
 
+#ifndef GL_TILE_PIN
+#define GL_TILE_PIN 2  // row pairs between two scheduling boundaries of the pass (independent work for the fp64 pipe)
+#endif
 #ifndef GL_TILE_MIN_BULK_TILES
 #define GL_TILE_MIN_BULK_TILES 3
 #endif
@@ -132,10 +135,10 @@ __device__ __forceinline__ double2 tl_ldz(const double *base, unsigned byte_off)
     return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
-// One chunk: U row pairs of a bulk tile, w in registers.  With U = 32 the first 16 row pairs come through the
-// register ring (refilled RING row pairs ahead; the refills of the second half of the stream are next
-// iteration's first row pairs: z never changes), the others -- and everything when U <= 16 -- from the chunk's
-// LDS slice, pre-multiplied by 2 gamma.  Row sums by a halving butterfly per 4 row pairs, column sums in
+// One chunk: U row pairs of a bulk tile, w in registers.  With U = 32 the even row pairs come through the
+// register ring (refilled RING streamed row pairs = 2 RING row pairs ahead: the odd ones in between double the
+// lead time a register buys; the last refills of a pass are next iteration's first row pairs: z never changes),
+// the odd ones -- and everything when U <= 16 -- from the chunk's LDS slice, pre-multiplied by 2 gamma.  Row sums by a halving butterfly per 4 row pairs, column sums in
 // registers; everything leaves through LDS (row p, row w, column p, column w vectors of 64; rows are those of
 // the whole tile, the chunk fills its own 2 U of them).
 // The LDS operands of row pair s + 1 are requested before row pair s is computed: the empty asm after every
@@ -145,7 +148,8 @@ template <int U, bool RAGGED, bool NORMS>
 __device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[U], double2 (&zr)[RING], const double2 *zl,
                                               const unsigned zb, const double2 *s_rows, const double dj0, const double dj1,
                                               const double pj0, const double pj1, const double m0, const double m1,
-                                              double *s_row, double *s_col, const int lane, double &nqy, double &nw) {
+                                              double *s_row, double *s_col, const int lane, const bool younger, double &nqy,
+                                              double &nw) {
     constexpr int NS = U == SLOTS ? SLOTS / 2 : 0;  // streamed row pairs
     const int half = lane >> 5, c0 = 2 * (lane & 31);
     const double c = P.c, g = P.gamma, g2 = P.g2;
@@ -156,25 +160,34 @@ __device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[
     asm volatile("" : "+v"(zbv));
     double2 rv_n = s_rows[half];
     double2 zl_n = double2{0.0, 0.0};
-    if (NS == 0) zl_n = zl[0];
+    if (NS == 0) zl_n = zl[0];  // (U = 32: row pair 0 streams)
+    // Two waves share a SIMD (waves v and v + 4); both at priority 0 the older one takes the issue slots it wants and
+    // the younger the rest, then finishes alone at half the fp64 rate (measured: 5.8 against 8.1 us at n = 4096).  The
+    // younger half therefore runs the first half of its pass at priority 1: both end together.
+    if (younger) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int gq = 0; gq < U / 4; ++gq) {
         double rowp[4], roww[4];
+        if (gq == U / 8) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int s = 4 * gq + k;
             double2 gz;  // 2 gamma z of this row pair (:150)
-            if (s < NS) {
-                const int pos = s % RING;
+            constexpr bool STREAMS = NS > 0;
+            const bool streamed = STREAMS && (s & 1) == 0;  // U = 32: even row pairs stream, odd ones live in LDS
+            if (streamed) {
+                const int pos = (s / 2) % RING;
                 gz = double2{g2 * zr[pos].x, g2 * zr[pos].y};
-                zr[pos] = tl_ldz(P.z, zbv + (unsigned)(((s + RING) % (NS > 0 ? NS : 1)) * (2 * TB) * 8));
+                // refill with the RING-th next streamed row pair (2 RING row pairs ahead; wraps into the next iteration)
+                zr[pos] = tl_ldz(P.z, zbv + (unsigned)(((s + 2 * RING) % SLOTS) * (2 * TB) * 8));
             } else {
                 gz = zl_n;
             }
             const double2 rv = rv_n;  // {d_i, pbar_i}: one address per half-wave (broadcast)
             if (s + 1 < U) {
                 rv_n = s_rows[2 * (s + 1) + half];
-                if (s + 1 >= NS) zl_n = zl[(s + 1 - NS) * 64];
+                if (!STREAMS) zl_n = zl[(s + 1) * 64];
+                else if (((s + 1) & 1) == 1) zl_n = zl[((s + 1) / 2) * 64];
             }
             const double di = rv.x, pi = rv.y;
             const double2 wv = wreg[s];
@@ -211,10 +224,12 @@ __device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[
             rowp[k] = pp[0] + pp[1];
             roww[k] = wn[0] + wn[1];
             wreg[s] = double2{wn[0], wn[1]};
-            if (NORMS)
-                asm volatile("" : "+v"(nqy), "+v"(nw), "+v"(colp0), "+v"(colp1), "+v"(colw0), "+v"(colw1));
-            else
-                asm volatile("" : "+v"(colp0), "+v"(colp1), "+v"(colw0), "+v"(colw1));
+            if (k % GL_TILE_PIN == GL_TILE_PIN - 1) {
+                if (NORMS)
+                    asm volatile("" : "+v"(nqy), "+v"(nw), "+v"(colp0), "+v"(colp1), "+v"(colw0), "+v"(colw1));
+                else
+                    asm volatile("" : "+v"(colp0), "+v"(colp1), "+v"(colw0), "+v"(colw1));
+            }
         }
         const double rw = halfwave_rows4(roww, lane);  // lane l: the total of row pair (l >> 3) & 3 of the group
         const double rp = halfwave_rows4(rowp, lane);
@@ -283,13 +298,14 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
 #pragma unroll
         for (int s = 0; s < U; ++s) wreg[s] = *reinterpret_cast<const double2 *>(P.w + tb + s * (2 * TB));
 #pragma unroll
-        for (int s = NS; s < U; ++s) {  // LDS-resident part, pre-multiplied: 2 gamma z
+        for (int s = 0; s < U; ++s) {  // LDS-resident part (U = 32: the odd row pairs), pre-multiplied: 2 gamma z
+            if (NS > 0 && (s & 1) == 0) continue;
             const double2 zv = *reinterpret_cast<const double2 *>(P.z + tb + s * (2 * TB));
-            s_z[wave][s - NS][lane] = double2{P.g2 * zv.x, P.g2 * zv.y};
+            s_z[wave][NS > 0 ? s / 2 : s][lane] = double2{P.g2 * zv.x, P.g2 * zv.y};
         }
         if (NS > 0) {
 #pragma unroll
-            for (int k = 0; k < RING; ++k) zr[k] = tl_ldz(P.z, zb + (unsigned)(k * (2 * TB) * 8));
+            for (int k = 0; k < RING; ++k) zr[k] = tl_ldz(P.z, zb + (unsigned)(2 * k * (2 * TB) * 8));
         }
     }
     if (U < SLOTS) {  // rows of the tile outside my chunk contribute nothing to my row vectors
@@ -459,7 +475,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         if (has) {
             const double2 cv0 = s_node[wdv.sj][c0], cv1 = s_node[wdv.sj][c0 + 1];
             tl_chunk_pass<U, RAGGED, NORMS>(P, wreg, zr, &s_z[wave][0][lane], zb, &s_node[wdv.si][2 * a0], cv0.x, cv1.x, cv0.y, cv1.y,
-                                            m0, m1, &s_part[wave][0][2 * a0], &s_part[wave][2][0], lane, nqy, nw);
+                                            m0, m1, &s_part[wave][0][2 * a0], &s_part[wave][2][0], lane, wave >= TW / 2, nqy, nw);
         }
         if (fcnt > 0) {  // my fringe row pairs (diagonal tile: entries i < j < n only)
             const double c = P.c, g = P.gamma;
@@ -538,6 +554,11 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             s_wn[wave][1] = nw;
         }
         if (stamp) ts[2] = __builtin_amdgcn_s_memrealtime();
+        if (stamp && lane == 0) {  // per-wave duration of the pass (after the workgroup's stamps)
+            unsigned long long *o = P.dbg + (size_t)P.NWG * 16 * 6 + (((size_t)wg * 16 + (it - 8)) * TW + wave) * 2;
+            o[0] = ts[1];
+            o[1] = ts[2];
+        }
         __syncthreads();
 
         // ================= publish: one record per node block I touch =================
@@ -936,8 +957,8 @@ int gl_tile_prepare(gl_logdeg *s) {
     P.n_entries = n_entries;
     t->U = U;
     P.dbg = nullptr;
-    if (getenv("GRAPHLEARN_AMD_RES_STAMPS") && hipMalloc((void **)&t->dbg, (size_t)NWG * 16 * 6 * 8) == hipSuccess) {
-        (void)hipMemset(t->dbg, 0, (size_t)NWG * 16 * 6 * 8);
+    if (getenv("GRAPHLEARN_AMD_RES_STAMPS") && hipMalloc((void **)&t->dbg, (size_t)NWG * 16 * (6 + 2 * TW) * 8) == hipSuccess) {
+        (void)hipMemset(t->dbg, 0, (size_t)NWG * 16 * (6 + 2 * TW) * 8);
         P.dbg = t->dbg;
         int maxblk = 0;
         for (const WgDesc &G : gd) maxblk = std::max(maxblk, G.nblk);
@@ -999,8 +1020,37 @@ int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms) {
 void gl_tile_dump_stamps(gl_logdeg *s) {
     if (!s || !s->tile || !s->tile->dbg) return;
     const int NWG = s->tile->dev.NWG, nb = (int)s->tile->dev.nb;
-    std::vector<unsigned long long> h((size_t)NWG * 16 * 6);
+    std::vector<unsigned long long> h((size_t)NWG * 16 * (6 + 2 * TW));
     (void)hipMemcpy(h.data(), s->tile->dbg, h.size() * 8, hipMemcpyDeviceToHost);
+    {  // per-wave pass durations: mean, and mean over workgroups of (slowest - fastest wave of the workgroup)
+        const unsigned long long *pw = h.data() + (size_t)NWG * 16 * 6;
+        double sum = 0, skew = 0, mx = 0, first_last = 0;
+        long cnt = 0, wcnt = 0;
+        double per_wave[TW] = {0};
+        long per_cnt[TW] = {0};
+        for (int w = 0; w < NWG; ++w)
+            for (int k = 1; k < 16; ++k) {
+                double lo = 1e30, hi = 0;
+                unsigned long long e_first = ~0ull, e_last = 0;
+                for (int v = 0; v < TW; ++v) {
+                    const unsigned long long *o = pw + (((size_t)w * 16 + k) * TW + v) * 2;
+                    if (!o[1]) continue;
+                    const double d = (double)(o[1] - o[0]);
+                    sum += d, ++cnt;
+                    per_wave[v] += d, ++per_cnt[v];
+                    lo = std::min(lo, d), hi = std::max(hi, d);
+                    e_first = std::min(e_first, o[1]), e_last = std::max(e_last, o[1]);
+                    mx = std::max(mx, d);
+                }
+                if (hi > 0) skew += hi - lo, first_last += (double)(e_last - e_first), ++wcnt;
+            }
+        if (cnt) {
+            fprintf(stderr, "[tile stamps] pass per wave: mean %.2f us, slowest %.2f; inside a workgroup slowest - fastest %.2f, last end - first end %.2f; by wave:",
+                    sum / cnt / 100, mx / 100, skew / wcnt / 100, first_last / wcnt / 100);
+            for (int v = 0; v < TW; ++v) fprintf(stderr, " %.2f", per_cnt[v] ? per_wave[v] / per_cnt[v] / 100 : 0.0);
+            fprintf(stderr, "\n");
+        }
+    }
     // per iteration: the latest end of an edge phase, the latest publish, the latest owner's node values out,
     // relative to the earliest start of that iteration's acquire
     double acq = 0, edge = 0, pub = 0, own_wait = 0, own_upd = 0, span = 0, edge_max = 0, acq_min = 0;

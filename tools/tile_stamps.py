@@ -14,4 +14,6 @@ for n in [int(a) for a in sys.argv[1:]] or [130, 2048, 4096]:
         s.init(1, 1, 0.5, None)
         s.iterate(100, 0.0)
         print(n, s.engine_kernel, flush=True)
-        s.iterate(100, 0.0)      # stamps of this launch are printed by the library
+        s.iterate(100, 0.0)      # stamps of this launch (with norms) are printed by the library
+        s.iterate_async(100)     # ... and of the variant without norms, at the next synchronising call
+        s.dual()
