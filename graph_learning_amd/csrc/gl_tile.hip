@@ -41,6 +41,9 @@
 #include "gl_lanes.h"
 #include "gl_logdeg.h"
 
+#ifndef GL_TILE_LDS_PREFETCH
+#define GL_TILE_LDS_PREFETCH 1  // request the LDS operands of row pair s + 1 before row pair s is computed
+#endif
 #ifndef GL_TILE_PIN
 #define GL_TILE_PIN 2  // row pairs between two scheduling boundaries of the pass (independent work for the fp64 pipe)
 #endif
@@ -54,7 +57,7 @@ constexpr int TB = GL_TB;
 constexpr int SLOTS = TB / 2;  // 32 row pairs per tile
 constexpr int TW = 8;          // waves per workgroup (two per SIMD)
 constexpr int TT = TW * 64;
-constexpr int NBW = 15;        // node blocks one workgroup may touch (8 chunks: at most 16 distinct ones)
+constexpr int NBW = 13;        // node blocks one workgroup may touch (8 chunks: at most 16 distinct ones; 9 seen)
 constexpr int FRMAX = 2;       // fringe row pairs per wave
 constexpr int RING = 4;        // register ring of streamed z row pairs (U = 32)
 constexpr int NACQ = (NBW + TW - 1) / TW;  // node blocks one wave fetches
@@ -183,12 +186,17 @@ __device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[
             } else {
                 gz = zl_n;
             }
+#if GL_TILE_LDS_PREFETCH
             const double2 rv = rv_n;  // {d_i, pbar_i}: one address per half-wave (broadcast)
             if (s + 1 < U) {
                 rv_n = s_rows[2 * (s + 1) + half];
                 if (!STREAMS) zl_n = zl[(s + 1) * 64];
                 else if (((s + 1) & 1) == 1) zl_n = zl[((s + 1) / 2) * 64];
             }
+#else
+            const double2 rv = s_rows[2 * s + half];
+            if (!streamed) gz = zl[(STREAMS ? s / 2 : s) * 64];
+#endif
             const double di = rv.x, pi = rv.y;
             const double2 wv = wreg[s];
             double wn[2], pp[2], nq2[2], nw2[2];
@@ -210,7 +218,7 @@ __device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[
                 if (NORMS) {
                     const double dq = q - y;  // == -y + q (:158)
                     nq2[e] = RAGGED ? (e ? m1 : m0) * (dq * dq) : dq * dq;
-                    nw2[e] = w * w;
+                    nw2[e] = wn[e] * wn[e];  // of the NEW iterate: next iteration's denominator (see s_wcarry)
                 }
             }
             if (NORMS) {
@@ -261,7 +269,10 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     __shared__ double2 s_z[TW][ZRES][64];             // up to 128 KiB
     __shared__ double2 s_node[NBW][TB];               // {d, pbar} of the node blocks this workgroup touches
     __shared__ double s_part[TW][4][TB];              // per chunk: row p, row w, column p, column w (owner phase: s_own)
+    __shared__ double s_dual[4][TB];                  // owner workgroups: d, ybar, pbar, d of the previous iteration
+    __shared__ double s_bn[4];                        // ... and the norm partials of its last update
     __shared__ double s_wn[TW][2];
+    __shared__ double s_wcarry[TW];                   // per wave: sum of squares of its current w (the rule's denominator)
     __shared__ double s_ns[2];
     __shared__ int s_flag[4];                         // {rendezvous ok, failed, stop, -}
     __shared__ double s_rel[2];
@@ -326,21 +337,30 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             fgz[f] = double2{P.g2 * zv.x, P.g2 * zv.y};
         }
     }
+    if (NORMS) {  // sum of squares of the iterate this call starts from
+        double acc = 0;
+#pragma unroll
+        for (int s = 0; s < U; ++s) acc += wreg[s].x * wreg[s].x + wreg[s].y * wreg[s].y;
+#pragma unroll
+        for (int f = 0; f < FRMAX; ++f) acc += fw[f].x * fw[f].x + fw[f].y * fw[f].y;
+        acc = wave_sum(acc);
+        if (lane == 0) s_wcarry[wave] = acc;
+    }
     // ragged last block column: 0 / 1 factors of my two columns
     double m0 = 1.0, m1 = 1.0;
     if (RAGGED && has) {
         m0 = (int64_t)wdv.J * TB + c0 < P.n ? 1.0 : 0.0;
         m1 = (int64_t)wdv.J * TB + c0 + 1 < P.n ? 1.0 : 0.0;
     }
-    // ---- dual state of my node block (owner workgroups, wave 0, lane = node)
-    double d_cur = 0, yb_cur = 0, pb_cur = 0, d_prev = 0;
-    double bn_last[4] = {0, 0, 0, 0};
+    // ---- dual state of my node block (owner workgroups, wave 0, lane = node): in LDS, not in registers that
+    //      every wave of the grid would have to set aside
     const int64_t own_i = (int64_t)own * TB + lane;
     if (own >= 0 && wave == 0) {
-        d_cur = P.dvar[own_i];
-        yb_cur = P.ybar[own_i];
-        pb_cur = P.pbar[own_i];
-        d_prev = P.dprev[own_i];
+        s_dual[0][lane] = P.dvar[own_i];
+        s_dual[1][lane] = P.ybar[own_i];
+        s_dual[2][lane] = P.pbar[own_i];
+        s_dual[3][lane] = P.dprev[own_i];
+        if (lane < 4) s_bn[lane] = 0.0;
     }
     const auto r_part = __builtin_amdgcn_make_buffer_rsrc((void *)P.part, 0, (int)((int64_t)P.n_entries * 2 * TB * 16), 0x00020000);
     const auto r_nval = __builtin_amdgcn_make_buffer_rsrc((void *)P.nval, 0, (int)(P.nb * 2 * TB * 16), 0x00020000);
@@ -505,7 +525,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                         if (NORMS) {
                             const double dq = q - y;
                             nqy += valid ? dq * dq : 0.0;
-                            nw += valid ? w * w : 0.0;
+                            nw += wn[e] * wn[e];
                         }
                     }
                     colp0 += pp[0];
@@ -550,8 +570,11 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             nw = wave_sum(nw);
         }
         if (lane == 0) {
+            // ||w_old||^2 of this iteration was accumulated when w_old was produced (squaring the old values inside
+            // the pass keeps them alive and costs 75 registers): the sum over the new values is for the next one
             s_wn[wave][0] = nqy;
-            s_wn[wave][1] = nw;
+            s_wn[wave][1] = NORMS ? s_wcarry[wave] : 0.0;
+            if (NORMS) s_wcarry[wave] = nw;
         }
         if (stamp) ts[2] = __builtin_amdgcn_s_memrealtime();
         if (stamp && lane == 0) {  // per-wave duration of the pass (after the workgroup's stamps)
@@ -672,6 +695,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     sw += s_own[v][1][lane];
                 }
                 const bool real = own_i < P.n;
+                const double d_cur = s_dual[0][lane], yb_cur = s_dual[1][lane], pb_cur = s_dual[2][lane];
                 const double qb = pb_cur + P.gamma * sp;  // :154
                 const double dq = qb - yb_cur;            // == -ybar + qbar (:159)
                 double dq2 = real ? dq * dq : 0.0;
@@ -679,21 +703,19 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 const double dnew = (d_cur - yb_cur) + qb;                  // :164
                 const double ybn = dnew + P.gamma * sw;                     // :148 of the next iteration
                 const double pbn = (ybn - sqrt(ybn * ybn + P.a4g)) / 2;     // :151
-                d_prev = d_cur;
-                d_cur = real ? dnew : 0.0;
-                yb_cur = real ? ybn : 0.0;
-                pb_cur = real ? pbn : 0.0;
+                const double d_new = real ? dnew : 0.0, pb_new = real ? pbn : 0.0;
+                s_dual[3][lane] = d_cur;
+                s_dual[0][lane] = d_new;
+                s_dual[1][lane] = real ? ybn : 0.0;
+                s_dual[2][lane] = pb_new;
                 const int off = (own * 2 * TB + lane) * 16;
-                __builtin_amdgcn_raw_buffer_store_b128(tl_gran(d_cur, tag_out), r_nval, off, 0, 16);
-                __builtin_amdgcn_raw_buffer_store_b128(tl_gran(pb_cur, tag_out), r_nval, off + TB * 16, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(tl_gran(d_new, tag_out), r_nval, off, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(tl_gran(pb_new, tag_out), r_nval, off + TB * 16, 0, 16);
                 dq2 = wave_sum(dq2);
                 d2 = wave_sum(d2);
-                bn_last[0] = s_ns[0];
-                bn_last[1] = s_ns[1];
-                bn_last[2] = dq2;
-                bn_last[3] = d2;
                 if (lane < 4) {
-                    const double v = lane == 0 ? bn_last[0] : (lane == 1 ? bn_last[1] : (lane == 2 ? dq2 : d2));
+                    const double v = lane == 0 ? s_ns[0] : (lane == 1 ? s_ns[1] : (lane == 2 ? dq2 : d2));
+                    s_bn[lane] = v;
                     __builtin_amdgcn_raw_buffer_store_b128(tl_gran(v, tag_out), r_bn, ((((it & 3) * (int)P.nb + own) * 4) + lane) * 16, 0, 16);
                 }
             }
@@ -727,13 +749,11 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     for (int f = 0; f < FRMAX; ++f)
         if (f < fcnt) *reinterpret_cast<double2 *>(P.w + ftb + (int64_t)(fa0 + f) * (2 * TB)) = fw[f];
     if (own >= 0 && wave == 0 && done_iters > 0) {
-        P.dvar[own_i] = d_cur;
-        P.ybar[own_i] = yb_cur;
-        P.pbar[own_i] = pb_cur;
-        P.dprev[own_i] = d_prev;
-        if (lane < 4)
-            P.bnorm[((P.it0 + done_iters - 1) & 1) * 4 * P.nb + 4 * own + lane] =
-                lane == 0 ? bn_last[0] : (lane == 1 ? bn_last[1] : (lane == 2 ? bn_last[2] : bn_last[3]));
+        P.dvar[own_i] = s_dual[0][lane];
+        P.ybar[own_i] = s_dual[1][lane];
+        P.pbar[own_i] = s_dual[2][lane];
+        P.dprev[own_i] = s_dual[3][lane];
+        if (lane < 4) P.bnorm[((P.it0 + done_iters - 1) & 1) * 4 * P.nb + 4 * own + lane] = s_bn[lane];
     }
     if (wg == 0 && tid == 0) {
         const long long itf = P.it0 + done_iters;
@@ -829,39 +849,38 @@ int gl_tile_prepare(gl_logdeg *s) {
         w.J = bulk[(size_t)f].second;
         w.a0 = (q % per_tile) * U;
     }
-    // fringe: the 32 row pairs of diagonal tile (B, B) go, in groups, to waves whose chunk already works on block B
-    // (then the workgroup's block list does not grow and the partials fold into the chunk's vectors), else to
-    // waves without a chunk
-    const int t0 = nchunks > 0 ? std::max(1, std::min(FRMAX, (SLOTS * nb) / nchunks)) : FRMAX;
-    for (int B = 0; B < nb; ++B) {
-        bool placed = false;
-        for (int cap = t0; cap <= FRMAX && !placed; ++cap) {
-            std::vector<std::pair<int, int>> plan;  // (wave, count)
-            int need = SLOTS;
-            for (int pass = 0; pass < 2 && need > 0; ++pass)
-                for (int v = 0; v < nwaves && need > 0; ++v) {
-                    const WaveDesc &w = wd[(size_t)v];
-                    if (w.fcnt != 0) continue;
-                    const bool works_on_b = w.tile >= 0 && (w.I == B || w.J == B);
-                    const bool idle = w.tile < 0;
-                    if (pass == 0 ? !works_on_b : !idle) continue;
-                    const int take = std::min(pass == 0 ? cap : FRMAX, need);
-                    plan.push_back({v, take});
-                    need -= take;
+    // fringe: the 32 row pairs of diagonal tile (B, B) go, in groups of <= FRMAX, to waves whose chunk already works on
+    // block B as its row or column block (then the workgroup's block list does not grow and the partials fold into
+    // the chunk's vectors), else to waves without a chunk.  A chunk of tile (I, J) can serve I or J: it prefers one of
+    // them by parity, so that every block finds takers among its row and its column; what is left goes to any taker.
+    {
+        std::vector<int> need((size_t)nb, SLOTS);
+        const int cap = nchunks > 0 ? std::max(1, std::min(FRMAX, (SLOTS * nb + nchunks - 1) / nchunks)) : FRMAX;
+        auto give = [&](WaveDesc &w, int B, int most) {
+            const int take = std::min(most, need[(size_t)B]);
+            if (take <= 0 || w.fcnt != 0) return;
+            w.fB = B;
+            w.fa0 = SLOTS - need[(size_t)B];
+            w.fcnt = take;
+            w.ftgt = (w.tile >= 0 && w.I != B) ? 2 : 0;  // my column vectors when B is my column block
+            need[(size_t)B] -= take;
+        };
+        for (int pass = 0; pass < 3; ++pass)
+            for (int v = 0; v < nwaves; ++v) {
+                WaveDesc &w = wd[(size_t)v];
+                if (w.fcnt != 0) continue;
+                if (w.tile >= 0 && pass < 2) {
+                    const bool odd = ((w.I + w.J + w.a0 / U) & 1) != 0;
+                    give(w, (odd != (pass == 1)) ? w.J : w.I, pass == 0 ? cap : FRMAX);
+                } else if (w.tile < 0 && pass == 2) {
+                    int B = 0;
+                    for (int b = 1; b < nb; ++b)
+                        if (need[(size_t)b] > need[(size_t)B]) B = b;
+                    give(w, B, FRMAX);
                 }
-            if (need > 0) continue;
-            int a = 0;
-            for (auto &pr : plan) {
-                WaveDesc &w = wd[(size_t)pr.first];
-                w.fB = B;
-                w.fa0 = a;
-                w.fcnt = pr.second;
-                w.ftgt = (w.tile >= 0 && w.I != B) ? 2 : 0;  // my column vectors when B is my column block
-                a += pr.second;
             }
-            placed = true;
-        }
-        if (!placed) return GL_OK;  // (cannot happen with the room reserved above; the other engines would serve)
+        for (int B = 0; B < nb; ++B)
+            if (need[(size_t)B] > 0) return GL_OK;  // (tiny lattices on few workgroups: the other engines serve them)
     }
     // block lists, records, masks
     std::vector<WgDesc> gd((size_t)NWG);
