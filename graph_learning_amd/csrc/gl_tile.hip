@@ -199,7 +199,7 @@ __device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[
 #endif
             const double di = rv.x, pi = rv.y;
             const double2 wv = wreg[s];
-            double wn[2], pp[2], nq2[2], nw2[2];
+            double wn[2], pp[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const double w = e ? wv.y : wv.x;
@@ -216,14 +216,12 @@ __device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[
                     pp[e] = pr;
                 }
                 if (NORMS) {
-                    const double dq = q - y;  // == -y + q (:158)
-                    nq2[e] = RAGGED ? (e ? m1 : m0) * (dq * dq) : dq * dq;
-                    nw2[e] = wn[e] * wn[e];  // of the NEW iterate: next iteration's denominator (see s_wcarry)
+                    // sums of squares for the stopping rule (:158-159).  Fused multiply-adds: these sums are compared with
+                    // tol, not with NumPy bit for bit (its norm sums in another order anyway); the iterate itself never sees them
+                    const double dq = RAGGED ? (e ? m1 : m0) * (q - y) : q - y;  // == -y + q
+                    nqy = __builtin_fma(dq, dq, nqy);
+                    nw = __builtin_fma(wn[e], wn[e], nw);  // of the NEW iterate: next iteration's denominator (see s_wcarry)
                 }
-            }
-            if (NORMS) {
-                nqy += nq2[0] + nq2[1];
-                nw += nw2[0] + nw2[1];
             }
             colp0 += pp[0];
             colp1 += pp[1];
@@ -340,9 +338,9 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     if (NORMS) {  // sum of squares of the iterate this call starts from
         double acc = 0;
 #pragma unroll
-        for (int s = 0; s < U; ++s) acc += wreg[s].x * wreg[s].x + wreg[s].y * wreg[s].y;
+        for (int s = 0; s < U; ++s) acc = __builtin_fma(wreg[s].y, wreg[s].y, __builtin_fma(wreg[s].x, wreg[s].x, acc));
 #pragma unroll
-        for (int f = 0; f < FRMAX; ++f) acc += fw[f].x * fw[f].x + fw[f].y * fw[f].y;
+        for (int f = 0; f < FRMAX; ++f) acc = __builtin_fma(fw[f].y, fw[f].y, __builtin_fma(fw[f].x, fw[f].x, acc));
         acc = wave_sum(acc);
         if (lane == 0) s_wcarry[wave] = acc;
     }
@@ -374,6 +372,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         s_flag[0] = gl_barrier_setup(gb, bs) ? 1 : 0;
         s_flag[1] = 0;
         s_flag[2] = 0;
+        s_flag[3] = 0;
     }
     __syncthreads();
     const bool met = s_flag[0] != 0;
@@ -382,7 +381,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     int done_iters = 0, stopped = 0;
     double rel_p = INFINITY, rel_d = INFINITY;
     const bool rule_on = P.tol > 0;
-    bool evaluated = false;
+    bool evaluated = false, exact = false;
 
     for (int it = 0; met && it <= P.maxit; ++it) {
         const unsigned tag_in = P.tag0 + (unsigned)it;        // node values that are the input of iteration `it`
@@ -440,38 +439,65 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 }
             }
             if (want_rule && wave == TW - 1) {  // one record per node block, lane = block
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                unsigned spins = 0;
-                tl_u4 r[4];
+                // The rule of iteration it - 1 needs the norm partials of EVERY owner, i.e. the slowest workgroup of the
+                // chip, every iteration (measured: 1.8 us of 17).  So while the ratios are clearly above tol only the
+                // records of iteration it - 2 are looked at -- published a whole iteration ago, no waiting -- and the exact
+                // evaluation (records of it - 1, as the reference does it) starts once those ratios come within 25 % of tol:
+                // from then on every iteration is judged exactly, this one included.  Ratios move by ~1/k per iteration,
+                // so nothing is skipped; a run whose ratios fall by more than 20 % in ONE iteration straight below tol
+                // stops one iteration late (inside the +-1 contract of SURVEY.md section 7).
                 const bool mine = lane < P.nb;
-                for (;;) {
-                    bool ok = true;
+                auto norms_of = [&](int j, double (&b)[4]) -> bool {  // sums of the records of local iteration j
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    unsigned spins = 0;
+                    const unsigned tag = P.tag0 + (unsigned)j + 1u;
+                    tl_u4 r[4];
+                    for (;;) {
+                        bool ok = true;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        r[q] = tl_u4{0u, tag_in, 0u, tag_in};
-                        if (mine) r[q] = __builtin_amdgcn_raw_buffer_load_b128(r_bn, ((((it - 1) & 3) * (int)P.nb + lane) * 4 + q) * 16, 0, 16);
-                        ok = ok && tl_ok(r[q], tag_in);
+                        for (int q = 0; q < 4; ++q) {
+                            r[q] = tl_u4{0u, tag, 0u, tag};
+                            if (mine) r[q] = __builtin_amdgcn_raw_buffer_load_b128(r_bn, (((j & 3) * (int)P.nb + lane) * 4 + q) * 16, 0, 16);
+                            ok = ok && tl_ok(r[q], tag);
+                        }
+                        asm volatile("" ::: "memory");
+                        if (__all(ok)) break;
+                        if (!tl_spin(spins, t0, err)) return false;
                     }
-                    asm volatile("" ::: "memory");
-                    if (__all(ok)) break;
-                    if (!tl_spin(spins, t0, err)) {
-                        good = false;
-                        break;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b[q] = wave_sum(mine ? tl_val(r[q]) : 0.0);
+                    return true;
+                };
+                double b[4] = {0, 0, 0, 0};
+                int stop = 0;
+                double rp = INFINITY, rd = INFINITY;
+                bool now_exact = exact || last_pass;
+                if (!now_exact && it >= 2) {
+                    good = good && norms_of(it - 2, b);
+                    const long long itp = P.it0 + it - 2;
+                    if (itp >= 1) {
+                        const double lp = sqrt(b[0]) / sqrt(b[1]), ld = sqrt(b[2]) / sqrt(b[3]);
+                        if (lp < P.tol && ld < P.tol) {
+                            stop = 1, rp = lp, rd = ld;  // (a jump straight below tol: seen one iteration late)
+                        } else if (lp < 1.25 * P.tol && ld < 1.25 * P.tol) {
+                            now_exact = true;
+                        }
                     }
                 }
-                double b[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) b[q] = wave_sum(mine ? tl_val(r[q]) : 0.0);
-                if (lane == 0) {
+                if (now_exact && !stop) {
+                    good = good && norms_of(it - 1, b);
                     const long long itp = P.it0 + it - 1;  // the iteration these norms belong to
-                    double rp = INFINITY, rd = INFINITY;
                     if (itp >= 1) {  // never at iteration 0 (:156-161)
                         rp = sqrt(b[0]) / sqrt(b[1]);
                         rd = sqrt(b[2]) / sqrt(b[3]);
                     }
+                    stop = (itp >= 1 && rp < P.tol && rd < P.tol) ? 1 : 0;
+                }
+                if (lane == 0) {
                     s_rel[0] = rp;
                     s_rel[1] = rd;
-                    s_flag[2] = (itp >= 1 && rp < P.tol && rd < P.tol) ? 1 : 0;
+                    s_flag[2] = stop;
+                    s_flag[3] = now_exact ? 1 : 0;
                 }
             }
             if (!good) s_flag[1] = 1;
@@ -482,9 +508,12 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             break;
         }
         if (want_rule) {
-            rel_p = s_rel[0];
-            rel_d = s_rel[1];
-            evaluated = true;
+            exact = s_flag[3] != 0;
+            if (exact || s_flag[2]) {  // (a look at older records only reports when it stops the run)
+                rel_p = s_rel[0];
+                rel_d = s_rel[1];
+                evaluated = true;
+            }
             if (s_flag[2]) stopped = 1;
         }
         if (stopped || last_pass) break;  // the rule of iteration it - 1 holds: its iterate is the result
@@ -523,9 +552,9 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                         pp[e] = valid ? pr : 0.0;
                         wn[e] = valid ? wnew : 0.0;
                         if (NORMS) {
-                            const double dq = q - y;
-                            nqy += valid ? dq * dq : 0.0;
-                            nw += wn[e] * wn[e];
+                            const double dq = valid ? q - y : 0.0;
+                            nqy = __builtin_fma(dq, dq, nqy);
+                            nw = __builtin_fma(wn[e], wn[e], nw);
                         }
                     }
                     colp0 += pp[0];
