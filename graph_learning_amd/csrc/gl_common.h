@@ -28,7 +28,14 @@ struct gl_ctx {
     size_t pinned_bytes = 0;  // status area only (the staging area follows it)
     bool stage_busy = false;  // an asynchronous staged upload may still be reading the staging area
     bool small_attrs_set = false;  // dynamic-LDS limit of the small-engine kernels raised on this device
+    // device scratch for the batched entry points (grown on demand, kept: no hipMalloc / hipFree per call)
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
 };
+
+// At least `bytes` of device scratch, valid until the next gl_ctx_scratch call on this context (the stream is in
+// order and the batched entry points return synchronised, so consecutive calls may reuse it).
+int gl_ctx_scratch(gl_ctx *ctx, size_t bytes, void **out);
 
 int gl_set_error(gl_ctx *ctx, int code, const char *fmt, ...);
 

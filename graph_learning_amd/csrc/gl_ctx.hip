@@ -80,6 +80,7 @@ GL_API int gl_ctx_destroy(gl_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -100,6 +101,22 @@ GL_API int gl_ctx_sync(gl_ctx *ctx) {
     if (!ctx) return GL_E_INVALID;
     GL_HIP(ctx, hipSetDevice(ctx->device));
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GL_OK;
+}
+
+int gl_ctx_scratch(gl_ctx *ctx, size_t bytes, void **out) {
+    if (ctx->scratch_bytes < bytes) {
+        if (ctx->scratch) {
+            GL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // somebody may still be using the old one
+            (void)hipFree(ctx->scratch);
+        }
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        const size_t want = (bytes + ((size_t)1 << 20) - 1) >> 20 << 20;
+        GL_HIP(ctx, hipMalloc(&ctx->scratch, want));
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->scratch;
     return GL_OK;
 }
 

@@ -1245,7 +1245,7 @@ GL_API int gl_logdeg_batch_get_weights(gl_logdeg **sessions, int B, double edge_
     }
     GL_HIP(ctx, hipSetDevice(ctx->device));
     double *buf = nullptr;
-    GL_HIP(ctx, hipMalloc((void **)&buf, (size_t)B * E * 8));
+    GL_TRY(gl_ctx_scratch(ctx, (size_t)B * E * 8, (void **)&buf));
     int rc = GL_OK;
     for (int a = 0; a < B && rc == GL_OK; ++a) {
         gl_logdeg *s = sessions[a];
@@ -1257,7 +1257,6 @@ GL_API int gl_logdeg_batch_get_weights(gl_logdeg **sessions, int B, double edge_
     if (rc == GL_OK && hipGetLastError() != hipSuccess) rc = gl_set_error(ctx, GL_E_HIP, "k_to_condensed launch failed");
     if (rc == GL_OK) rc = gl_d2h(ctx, w_out, buf, (size_t)B * E * 8);
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(buf);
     return rc;
 }
 
@@ -1337,7 +1336,7 @@ GL_API int gl_logdeg_batch_gram(gl_logdeg **sessions, int B, double *out) {
     const int blocks = (int)std::min<int64_t>(512, (n_tiled + 255) / 256);
     const int npairs = B * (B + 1) / 2;
     double *part = nullptr;
-    GL_HIP(ctx, hipMalloc((void **)&part, (size_t)npairs * blocks * 4 * 8));
+    GL_TRY(gl_ctx_scratch(ctx, (size_t)npairs * blocks * 4 * 8, (void **)&part));
     int pi = 0;
     for (int a = 0; a < B; ++a)
         for (int b = a; b < B; ++b, ++pi) {
@@ -1352,7 +1351,6 @@ GL_API int gl_logdeg_batch_gram(gl_logdeg **sessions, int B, double *out) {
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(host.data(), part, host.size() * 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(part);
     if (e != hipSuccess) return gl_set_error(ctx, GL_E_HIP, "batch_gram: %s", hipGetErrorString(e));
     pi = 0;
     for (int a = 0; a < B; ++a)
@@ -1447,22 +1445,30 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
             const LogdegDev &D = sessions[a]->dev;
             ptrs[(size_t)par * B + a] = BatchPtrs{D.w[par], D.w[par ^ 1], D.dvar, D.dprev};
         }
+    // one carve-up of the context's scratch (kept across calls: no hipMalloc / hipFree here)
     struct Scratch {
-        void *pairs = nullptr, *ptrs = nullptr, *part = nullptr, *out = nullptr, *devs = nullptr;
-        ~Scratch() {
-            for (void *p : {pairs, ptrs, part, out, devs})
-                if (p) (void)hipFree(p);
-        }
+        void *pairs = nullptr, *ptrs = nullptr, *part = nullptr, *out = nullptr, *devs = nullptr, *small = nullptr;
     } sc;
-    GL_HIP(ctx, hipMalloc(&sc.pairs, pairs.size() * sizeof(int2)));
-    GL_HIP(ctx, hipMalloc(&sc.ptrs, ptrs.size() * sizeof(BatchPtrs)));
-    GL_HIP(ctx, hipMalloc(&sc.part, (size_t)npairs * blocks * 4 * 8));
-    GL_HIP(ctx, hipMalloc(&sc.out, (size_t)npairs * 4 * 8));
+    {
+        auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+        const bool small_path = maxit >= 8 && gl_small_applicable(sessions[0]) && B <= ctx->prop.multiProcessorCount;
+        const size_t b_pairs = up((size_t)npairs * sizeof(int2)), b_ptrs = up((size_t)2 * B * sizeof(BatchPtrs));
+        const size_t b_part = up((size_t)npairs * blocks * 4 * 8), b_out = up((size_t)npairs * 4 * 8);
+        const size_t b_devs = up((size_t)B * sizeof(LogdegDev));
+        const size_t b_small = small_path ? up(gl_small_batch_scratch_bytes(B, (int)sessions[0]->n)) : 0;
+        char *at = nullptr;
+        GL_TRY(gl_ctx_scratch(ctx, b_pairs + b_ptrs + b_part + b_out + b_devs + b_small, (void **)&at));
+        sc.pairs = at, at += b_pairs;
+        sc.ptrs = at, at += b_ptrs;
+        sc.part = at, at += b_part;
+        sc.out = at, at += b_out;
+        sc.devs = at, at += b_devs;
+        sc.small = at;
+    }
     GL_HIP(ctx, hipMemcpyAsync(sc.pairs, pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
     GL_HIP(ctx, hipMemcpyAsync(sc.ptrs, ptrs.data(), ptrs.size() * sizeof(BatchPtrs), hipMemcpyHostToDevice, ctx->stream));
     std::vector<LogdegDev> devs((size_t)B);  // the problems' device descriptors, for the batched launches
     for (int a = 0; a < B; ++a) devs[(size_t)a] = sessions[a]->dev;
-    GL_HIP(ctx, hipMalloc(&sc.devs, devs.size() * sizeof(LogdegDev)));
     GL_HIP(ctx, hipMemcpyAsync(sc.devs, devs.data(), devs.size() * sizeof(LogdegDev), hipMemcpyHostToDevice, ctx->stream));
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<double> host((size_t)npairs * 4);
@@ -1494,12 +1500,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
     // Small graphs (n <= 128): one persistent launch, one workgroup per graph, the norm bounds evaluated
     // on the device (gl_small.hip); the host only steps in when the exact spectral norms are needed.
     if (maxit >= 8 && gl_small_applicable(sessions[0]) && B <= ctx->prop.multiProcessorCount) {
-        void *small_scratch = nullptr;
-        GL_HIP(ctx, hipMalloc(&small_scratch, gl_small_batch_scratch_bytes(B, (int)sessions[0]->n)));
-        struct Free {
-            void *p;
-            ~Free() { (void)hipFree(p); }
-        } guard{small_scratch};
+        void *small_scratch = sc.small;
         double rp = std::numeric_limits<double>::infinity(), rd = rp;
         bool have_exact = false, converged = false, small_failed = false;
         int64_t n_iter = 0;

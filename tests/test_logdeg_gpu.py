@@ -84,7 +84,8 @@ def test_logmodel_fit_defaults(golden, case):
     m = LogModel(avg_degree=int(g["deg"])).fit(g["x"])
     ref = g["weights_default"]
     assert m.weights_.shape == ref.shape and m.weights_.dtype == np.float64
-    assert abs(m.n_iter_ - int(g["n_iter_default"])) <= 1
+    # SURVEY section 7 allows +-1 iteration; every engine has been observed to stop exactly where the reference does
+    assert m.n_iter_ == int(g["n_iter_default"])
     assert m.theta_ == pytest.approx(float(g[f"theta_deg{int(g['deg'])}"]), rel=1e-10)
     # (ii): entries may only differ where the reference value sits at the threshold
     o = old.LogModelOracle(avg_degree=int(g["deg"])).fit(g["x"])
@@ -100,7 +101,7 @@ def test_converge_mode_stops_like_reference(golden, case):
     zt = g["z"] * float(g[f"theta_deg{int(g['deg'])}"])
     w, info = gsp_learn_graph_log_degrees(zt, 1, 1, maxit=20000, tol=1e-5, edge_tol=-np.inf, return_info=True)
     assert info["converged"]
-    assert abs(info["n_iter"] - int(g["n_iter_converged"])) <= 1
+    assert info["n_iter"] == int(g["n_iter_converged"])   # (contract: +-1; observed offset: 0 on every engine)
     np.testing.assert_allclose(squareform(w, checks=False), g["raw_w_converged"], rtol=0, atol=1e-6)
     if info["n_iter"] == int(g["n_iter_converged"]):
         np.testing.assert_allclose(squareform(w, checks=False), g["raw_w_converged"], rtol=0, atol=ATOL)

@@ -42,7 +42,7 @@ def test_log_degrees_fit_one_shot(golden, case):
     # run to the reference's stopping iteration
     ctx.check(lib.gl_log_degrees_fit(ctx.handle, _p(z), n, 1.0, 1.0, None, 100000, 1e-5, 0.5, -np.inf, _p(w), C.byref(it), rel),
               "log_degrees_fit")
-    assert abs(it.value - int(g["n_iter_converged"])) <= 1
+    assert it.value == int(g["n_iter_converged"])   # (contract: +-1 iteration; observed offset: 0)
     if it.value == int(g["n_iter_converged"]):
         np.testing.assert_allclose(w, g["raw_w_converged"], rtol=0, atol=1e-10)
     assert rel[0] < 1e-5 and rel[1] < 1e-5
@@ -61,7 +61,7 @@ def test_logmodel_fit_signals_one_shot(golden, case):
     ctx.check(lib.gl_logmodel_fit_signals(ctx.handle, _p(x), d, n, deg, None, 1000, 1e-5, 0.5, 1e-3, _p(big_w),
                                           C.byref(th), C.byref(it), rel), "logmodel_fit_signals")
     assert th.value == pytest.approx(float(g[f"theta_deg{deg}"]), rel=1e-10)
-    assert abs(it.value - int(g["n_iter_default"])) <= 1
+    assert it.value == int(g["n_iter_default"])
     ref = g["weights_default"]
     assert np.array_equal(big_w, big_w.T) and np.all(np.diag(big_w) == 0)
     near = np.abs(squareform(g["raw_w_converged"], checks=False) - 1e-3) < 1e-6 if g["raw_w_converged"].ndim == 1 else False
