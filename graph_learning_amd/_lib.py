@@ -88,6 +88,7 @@ SIGNATURES = {
     "gl_graphdict_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gl_graphdict_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gl_graphdict_set_params": (C.c_int, [C.c_void_p] + [C.c_double] * 8),
+    "gl_graphdict_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "gl_graphdict_get_steps": (C.c_int, [C.c_void_p, _c_double_p]),
     "gl_graphdict_engine": (C.c_int, [C.c_void_p]),
     "gl_graphdict_fit": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_void_p, _c_int64_p, _c_int64_p,
@@ -383,6 +384,10 @@ class GraphDictSession:
                    step_dual=1.0):
         self.ctx.check(self._lib.gl_graphdict_set_params(self._h, *[float(v) for v in (
             l1_w, ortho_w, l1_c, log_c, l1_diff_c, step_c, step_w, step_dual)]), "graphdict_set_params")
+
+    def set_precision(self, bits: int):
+        """32: the two O(K T E) contractions of a step run in packed fp32 (folds and state stay fp64); 64: default."""
+        self.ctx.check(self._lib.gl_graphdict_set_precision(self._h, int(bits)), "graphdict_set_precision")
 
     def steps(self):
         out = (C.c_double * 3)()

@@ -49,6 +49,9 @@ struct gl_graphdict {
     double *stage = nullptr;  // device staging for host <-> device transfers of W (K x E) / x (T x n)
     size_t stage_elems = 0;
     bool have_x = false, have_state = false;
+    // fp32 form of the two gradient contractions (gl_graphdict_set_precision): fp32 copies of their operands
+    bool f32 = false;
+    float *Xf = nullptr, *XTf = nullptr, *WSf = nullptr, *CTf = nullptr;
     // one step (memset + 14 kernels + copy of the status words) captured per parity of the degree
     // ping-pong and replayed: one graph launch per step instead of 16 enqueues (matters below ~1 ms/step)
     hipGraphExec_t step_graph[4] = {nullptr, nullptr, nullptr, nullptr};  // [2 * fit_mode + parity]

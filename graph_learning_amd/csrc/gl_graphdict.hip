@@ -38,19 +38,29 @@ __device__ __forceinline__ double gd_wave_max(double v) { return wave_max(v); } 
 // ------------------------------------------------------------------------------------------
 // coefficient gradient: SC[g][k][t] = sum over the pairs of strip group g of W[k,(i,j)] (x_ti - x_tj)^2
 // (base_model.py:375 `self.weights_ @ sq_pdiffs.T`).  grid (Tp / 128, NG), one wave per workgroup.
-template <int KP, int RC>
-__global__ __launch_bounds__(64) void k_gd_grad_c(const double *__restrict__ XT, const double *__restrict__ WS,
+// T = double, or float for the fp32 form of BASELINE configs[4] (gl_graphdict_set_precision): operands and the
+// running sums of a (strip group, sample) cell in fp32 -- the compiler packs the K-loop into v_pk_fma_f32, two
+// fused multiply-adds per lane and instruction -- the cell's result leaves as fp64 and every fold after it is fp64.
+template <typename T>
+__device__ __forceinline__ T gd_fma(T a, T b, T c);
+template <>
+__device__ __forceinline__ double gd_fma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <>
+__device__ __forceinline__ float gd_fma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+template <typename T, int KP, int RC>
+__global__ __launch_bounds__(64) void k_gd_grad_c(const T *__restrict__ XT, const T *__restrict__ WS,
                                                   double *__restrict__ SC, int n, int n_pad, int Tp, int NG,
                                                   const double *__restrict__ done) {
     if (done[0] != 0.0) return;  // the stopping rule was met earlier in this chunk of steps
     const int lane = threadIdx.x;
     const int g = blockIdx.y;
     const int64_t t0 = (int64_t)blockIdx.x * GD_SB + lane;  // this lane's samples: t0 + 64 q, q < GD_SPL
-    double acc[GD_SPL][KP];
+    T acc[GD_SPL][KP];
 #pragma unroll
     for (int q = 0; q < GD_SPL; ++q)
 #pragma unroll
-        for (int k = 0; k < KP; ++k) acc[q][k] = 0.0;
+        for (int k = 0; k < KP; ++k) acc[q][k] = (T)0;
     const int nstrips = (n + RC - 1) / RC;
     // strip s has n - RC s - 1 columns to walk: dealing the strips out in serpentine order
     // (g, 2 NG - 1 - g, 2 NG + g, ...) gives every group the same amount of work
@@ -59,34 +69,34 @@ __global__ __launch_bounds__(64) void k_gd_grad_c(const double *__restrict__ XT,
         if (s >= nstrips) continue;
         const int i0 = RC * s;
         if (i0 + 1 >= n) continue;
-        double xi[RC][GD_SPL];
+        T xi[RC][GD_SPL];
 #pragma unroll
         for (int a = 0; a < RC; ++a)
 #pragma unroll
             for (int q = 0; q < GD_SPL; ++q) xi[a][q] = XT[(int64_t)(i0 + a) * Tp + t0 + 64 * q];
         // software pipeline over the columns j, two operand sets (see k_gd_grad_w); rows i0 + a >= j
         // carry zeros in WS (lower triangle): no branch needed
-        double wA[RC][KP], xjA[GD_SPL], wB[RC][KP], xjB[GD_SPL];
-        auto request = [&](int j, double (&w)[RC][KP], double (&xj)[GD_SPL]) {
+        T wA[RC][KP], xjA[GD_SPL], wB[RC][KP], xjB[GD_SPL];
+        auto request = [&](int j, T (&w)[RC][KP], T (&xj)[GD_SPL]) {
             const int jc = j < n ? j : n - 1;
 #pragma unroll
             for (int a = 0; a < RC; ++a) {
-                const double *__restrict__ wp = WS + ((int64_t)(i0 + a) * n_pad + jc) * KP;  // wave-uniform
+                const T *__restrict__ wp = WS + ((int64_t)(i0 + a) * n_pad + jc) * KP;  // wave-uniform
 #pragma unroll
                 for (int k = 0; k < KP; ++k) w[a][k] = wp[k];
             }
 #pragma unroll
             for (int q = 0; q < GD_SPL; ++q) xj[q] = XT[(int64_t)jc * Tp + t0 + 64 * q];
         };
-        auto accumulate = [&](const double (&w)[RC][KP], const double (&xj)[GD_SPL]) {
+        auto accumulate = [&](const T (&w)[RC][KP], const T (&xj)[GD_SPL]) {
 #pragma unroll
             for (int a = 0; a < RC; ++a)
 #pragma unroll
                 for (int q = 0; q < GD_SPL; ++q) {
-                    const double d = xi[a][q] - xj[q];
-                    const double sq = d * d;
+                    const T d = xi[a][q] - xj[q];
+                    const T sq = d * d;
 #pragma unroll
-                    for (int k = 0; k < KP; ++k) acc[q][k] = __builtin_fma(w[a][k], sq, acc[q][k]);
+                    for (int k = 0; k < KP; ++k) acc[q][k] = gd_fma<T>(w[a][k], sq, acc[q][k]);
                 }
         };
         int j = i0 + 1;
@@ -108,7 +118,7 @@ __global__ __launch_bounds__(64) void k_gd_grad_c(const double *__restrict__ XT,
 #pragma unroll
     for (int q = 0; q < GD_SPL; ++q)
 #pragma unroll
-        for (int k = 0; k < KP; ++k) SC[((int64_t)g * KP + k) * Tp + t0 + 64 * q] = acc[q][k];
+        for (int k = 0; k < KP; ++k) SC[((int64_t)g * KP + k) * Tp + t0 + 64 * q] = (double)acc[q][k];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -117,8 +127,8 @@ __global__ __launch_bounds__(64) void k_gd_grad_c(const double *__restrict__ XT,
 // (row strip, column block) tasks that contain a pair i < j, times TS sample splits: workgroup ids
 // go round-robin to the 8 XCDs, so a 3-D grid with the dead below-diagonal blocks left in gives
 // XCD 7 2.4x the work of XCD 0 (measured: the kernel then runs as long as its slowest XCD).
-template <int KP, int SW>
-__global__ __launch_bounds__(256, 3) void k_gd_grad_w(const double *__restrict__ X, const double *__restrict__ CT,
+template <typename T, int KP, int SW>
+__global__ __launch_bounds__(256, 3) void k_gd_grad_w(const T *__restrict__ X, const T *__restrict__ CT,
                                                    double *__restrict__ GS, const int2 *__restrict__ tasks, int ntasks,
                                                    int n_pad, int Tp, int tchunk, double *dbg,
                                                    const double *__restrict__ done) {
@@ -131,11 +141,11 @@ __global__ __launch_bounds__(256, 3) void k_gd_grad_w(const double *__restrict__
     const int2 task = tasks[blockIdx.x % ntasks];
     const int jb = task.y, i0 = task.x * SW, ts = blockIdx.x / ntasks;
     const int j = jb * 64 + lane;
-    double acc[SW][KP];
+    T acc[SW][KP];
 #pragma unroll
     for (int a = 0; a < SW; ++a)
 #pragma unroll
-        for (int k = 0; k < KP; ++k) acc[a][k] = 0.0;
+        for (int k = 0; k < KP; ++k) acc[a][k] = (T)0;
     const int tA0 = ts * tchunk, tB0 = min(Tp, tA0 + tchunk);
     const int sub = (max(tB0 - tA0, 0) + 3) / 4;
     const int tA = tA0 + wave * sub, tB = min(tB0, tA + sub);
@@ -146,24 +156,24 @@ __global__ __launch_bounds__(256, 3) void k_gd_grad_w(const double *__restrict__
     // Two operand sets alternate (no register copies); sched_barrier keeps the requests ahead of
     // the arithmetic (left alone, the scheduler sinks them into the middle of the FMA block).
     if (tA < tB) {
-        double xiA[SW], cfA[KP], xjA, xiB[SW], cfB[KP], xjB;
-        auto request = [&](int t, double (&xi)[SW], double (&cf)[KP], double &xj) {
+        T xiA[SW], cfA[KP], xjA, xiB[SW], cfB[KP], xjB;
+        auto request = [&](int t, T (&xi)[SW], T (&cf)[KP], T &xj) {
             const int tc = t < tB ? t : tB - 1;
-            const double *__restrict__ xr = X + (int64_t)tc * n_pad + i0;  // wave-uniform
-            const double *__restrict__ cr = CT + (int64_t)tc * KP;         // wave-uniform
+            const T *__restrict__ xr = X + (int64_t)tc * n_pad + i0;  // wave-uniform
+            const T *__restrict__ cr = CT + (int64_t)tc * KP;         // wave-uniform
 #pragma unroll
             for (int a = 0; a < SW; ++a) xi[a] = xr[a];
 #pragma unroll
             for (int k = 0; k < KP; ++k) cf[k] = cr[k];
             xj = X[(int64_t)tc * n_pad + j];
         };
-        auto accumulate = [&](const double (&xi)[SW], const double (&cf)[KP], const double xj) {
+        auto accumulate = [&](const T (&xi)[SW], const T (&cf)[KP], const T xj) {
 #pragma unroll
             for (int a = 0; a < SW; ++a) {
-                const double d = xi[a] - xj;
-                const double sq = d * d;
+                const T d = xi[a] - xj;
+                const T sq = d * d;
 #pragma unroll
-                for (int k = 0; k < KP; ++k) acc[a][k] = __builtin_fma(cf[k], sq, acc[a][k]);
+                for (int k = 0; k < KP; ++k) acc[a][k] = gd_fma<T>(cf[k], sq, acc[a][k]);
             }
         };
         request(tA, xiA, cfA, xjA);
@@ -190,26 +200,29 @@ __global__ __launch_bounds__(256, 3) void k_gd_grad_w(const double *__restrict__
         dbg[4 * w + 2] = (double)__builtin_amdgcn_s_getreg(63492);          // HW_REG_HW_ID
         dbg[4 * w + 3] = (double)(__builtin_amdgcn_s_getreg(63508) & 15u);  // XCC_ID
     }
-    // ((wave 0 + wave 1) + wave 2) + wave 3, one row of the strip at a time (12 KB of LDS)
+    // ((wave 0 + wave 1) + wave 2) + wave 3 in fp64, one row of the strip at a time (12 KB of LDS)
 #pragma unroll
     for (int a = 0; a < SW; ++a) {
         if (wave > 0) {
 #pragma unroll
-            for (int k = 0; k < KP; k += 2) s_red[wave - 1][k / 2][lane] = double2{acc[a][k], acc[a][k + 1]};
+            for (int k = 0; k < KP; k += 2) s_red[wave - 1][k / 2][lane] = double2{(double)acc[a][k], (double)acc[a][k + 1]};
         }
         __syncthreads();
         if (wave == 0) {
+            double fold[KP];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) fold[k] = (double)acc[a][k];
 #pragma unroll
             for (int v = 0; v < 3; ++v)
 #pragma unroll
                 for (int k = 0; k < KP; k += 2) {
                     const double2 p = s_red[v][k / 2][lane];
-                    acc[a][k] += p.x;
-                    acc[a][k + 1] += p.y;
+                    fold[k] += p.x;
+                    fold[k + 1] += p.y;
                 }
             double *dst = GS + (((int64_t)ts * n_pad + (i0 + a)) * n_pad + j) * KP;
 #pragma unroll
-            for (int k = 0; k < KP; k += 2) *reinterpret_cast<double2 *>(dst + k) = double2{acc[a][k], acc[a][k + 1]};
+            for (int k = 0; k < KP; k += 2) *reinterpret_cast<double2 *>(dst + k) = double2{fold[k], fold[k + 1]};
         }
         __syncthreads();
     }
@@ -581,6 +594,12 @@ __global__ __launch_bounds__(64) void k_gd_coef_stat(GdDev P, int nblocks, int f
     }
 }
 
+// fp32 copies of the gradient kernels' operands (gl_graphdict_set_precision(s, 32))
+__global__ void k_gd_to_f32(const double *__restrict__ src, float *__restrict__ dst, int64_t count, const double *__restrict__ done) {
+    if (done && done[0] != 0.0) return;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (int64_t)gridDim.x * blockDim.x) dst[q] = (float)src[q];
+}
+
 // ---- layout kernels --------------------------------------------------------------------------
 __global__ void k_gd_pack_x(const double *__restrict__ x, GdDev P) {  // x: T x n row-major
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -645,10 +664,21 @@ int gd_launch_grad_c(gl_graphdict *s) {
     const GdDev &P = s->dev;
     dim3 grid((unsigned)(P.Tp / GD_SB), (unsigned)P.NG);
     hipStream_t st = s->ctx->stream;
+    if (s->f32) {  // the weights changed in the last step: refresh their fp32 copy
+        const int64_t cnt = (int64_t)P.n_pad * P.n_pad * P.KP;
+        k_gd_to_f32<<<dim3((unsigned)std::min<int64_t>(4096, (cnt + 255) / 256)), 256, 0, st>>>(P.WS, s->WSf, cnt, P.stat + 5);
+        switch (P.KP) {
+            case 4: k_gd_grad_c<float, 4, 2><<<grid, 64, 0, st>>>(s->XTf, s->WSf, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5); break;
+            case 8: k_gd_grad_c<float, 8, 2><<<grid, 64, 0, st>>>(s->XTf, s->WSf, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5); break;
+            default: k_gd_grad_c<float, 16, 1><<<grid, 64, 0, st>>>(s->XTf, s->WSf, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5); break;
+        }
+        GL_HIP(s->ctx, hipGetLastError());
+        return GL_OK;
+    }
     switch (P.KP) {
-        case 4: k_gd_grad_c<4, 2><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5); break;
-        case 8: k_gd_grad_c<8, 2><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5); break;
-        default: k_gd_grad_c<16, 1><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5); break;
+        case 4: k_gd_grad_c<double, 4, 2><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5); break;
+        case 8: k_gd_grad_c<double, 8, 2><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5); break;
+        default: k_gd_grad_c<double, 16, 1><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5); break;
     }
     GL_HIP(s->ctx, hipGetLastError());
     return GL_OK;
@@ -677,10 +707,21 @@ int gd_launch_grad_w(gl_graphdict *s) {
     const int tchunk = (P.Tp + P.TS - 1) / P.TS;
     hipStream_t st = s->ctx->stream;
     dim3 grid((unsigned)(P.nwtasks * P.TS));
+    if (s->f32) {  // the coefficients changed in the last step: refresh their fp32 copy
+        const int64_t cnt = (int64_t)P.Tp * P.KP;
+        k_gd_to_f32<<<dim3((unsigned)std::min<int64_t>(1024, (cnt + 255) / 256)), 256, 0, st>>>(P.CT, s->CTf, cnt, P.stat + 5);
+        switch (P.KP) {
+            case 4: k_gd_grad_w<float, 4, 8><<<grid, 256, 0, st>>>(s->Xf, s->CTf, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, s->dbgbuf, P.stat + 5); break;
+            case 8: k_gd_grad_w<float, 8, 8><<<grid, 256, 0, st>>>(s->Xf, s->CTf, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, s->dbgbuf, P.stat + 5); break;
+            default: k_gd_grad_w<float, 16, 4><<<grid, 256, 0, st>>>(s->Xf, s->CTf, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, s->dbgbuf, P.stat + 5); break;
+        }
+        GL_HIP(s->ctx, hipGetLastError());
+        return GL_OK;
+    }
     switch (P.KP) {
-        case 4: k_gd_grad_w<4, 8><<<grid, 256, 0, st>>>(P.X, P.CT, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, s->dbgbuf, P.stat + 5); break;
-        case 8: k_gd_grad_w<8, 8><<<grid, 256, 0, st>>>(P.X, P.CT, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, s->dbgbuf, P.stat + 5); break;
-        default: k_gd_grad_w<16, 4><<<grid, 256, 0, st>>>(P.X, P.CT, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, s->dbgbuf, P.stat + 5); break;
+        case 4: k_gd_grad_w<double, 4, 8><<<grid, 256, 0, st>>>(P.X, P.CT, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, s->dbgbuf, P.stat + 5); break;
+        case 8: k_gd_grad_w<double, 8, 8><<<grid, 256, 0, st>>>(P.X, P.CT, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, s->dbgbuf, P.stat + 5); break;
+        default: k_gd_grad_w<double, 16, 4><<<grid, 256, 0, st>>>(P.X, P.CT, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, s->dbgbuf, P.stat + 5); break;
     }
     GL_HIP(s->ctx, hipGetLastError());
     return GL_OK;
@@ -859,6 +900,11 @@ GL_API int gl_graphdict_set_signals(gl_graphdict *s, const double *x) {
         if (!std::isfinite(x[q])) return gl_set_error(ctx, GL_E_NONFINITE, "x contains NaN or Inf");
     GL_TRY(gl_h2d(ctx, s->stage, x, cnt * 8));
     k_gd_pack_x<<<dim3((unsigned)((cnt + 255) / 256)), 256, 0, ctx->stream>>>(s->stage, P);
+    if (s->f32) {
+        const int64_t pc = (int64_t)P.Tp * P.n_pad;
+        k_gd_to_f32<<<dim3(2048), 256, 0, ctx->stream>>>(P.X, s->Xf, pc, nullptr);
+        k_gd_to_f32<<<dim3(2048), 256, 0, ctx->stream>>>(P.XT, s->XTf, pc, nullptr);
+    }
     GL_HIP(ctx, hipGetLastError());
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     s->have_x = true;
@@ -919,6 +965,33 @@ GL_API int gl_graphdict_set_params(gl_graphdict *s, double l1_w, double ortho_w,
     P.l1_w = l1_w, P.ortho_w = ortho_w, P.l1_c = l1_c, P.log_c = log_c, P.l1_diff_c = l1_diff_c;
     P.step_c = step_c, P.step_w = step_w, P.step_dual = step_dual;
     if (!same) gd_drop_graphs(s);  // the captured steps carry the old values in their kernel arguments
+    return GL_OK;
+}
+
+// Precision of the two O(K T E) contractions of a step (base_model.py:375, :447): 64 (default: what the reference
+// computes) or 32 (BASELINE configs[4] as written: fp32 operands and cell sums, packed two per instruction; every fold,
+// the projections, the dual prox and the state itself stay fp64).  The single-workgroup engine of small problems
+// ignores it (fp64).
+GL_API int gl_graphdict_set_precision(gl_graphdict *s, int bits) {
+    GL_TRY(gd_check(s));
+    gl_ctx *ctx = s->ctx;
+    if (bits != 32 && bits != 64) return gl_set_error(ctx, GL_E_INVALID, "precision must be 32 or 64, got %d", bits);
+    GdDev &P = s->dev;
+    GL_HIP(ctx, hipSetDevice(ctx->device));
+    if (bits == 32 && !s->Xf) {
+        GL_TRY(gd_alloc(s, &s->Xf, (size_t)P.Tp * P.n_pad));
+        GL_TRY(gd_alloc(s, &s->XTf, (size_t)P.n_pad * P.Tp));
+        GL_TRY(gd_alloc(s, &s->WSf, (size_t)P.n_pad * P.n_pad * P.KP));
+        GL_TRY(gd_alloc(s, &s->CTf, (size_t)P.Tp * P.KP));
+    }
+    if (bits == 32 && s->have_x) {
+        const int64_t cnt = (int64_t)P.Tp * P.n_pad;
+        k_gd_to_f32<<<dim3(2048), 256, 0, ctx->stream>>>(P.X, s->Xf, cnt, nullptr);
+        k_gd_to_f32<<<dim3(2048), 256, 0, ctx->stream>>>(P.XT, s->XTf, cnt, nullptr);
+        GL_HIP(ctx, hipGetLastError());
+    }
+    if (s->f32 != (bits == 32)) gd_drop_graphs(s);  // the captured steps launch the other instantiations
+    s->f32 = bits == 32;
     return GL_OK;
 }
 
@@ -1104,8 +1177,8 @@ GL_API int gl_graphdict_time_gradients(gl_graphdict *s, int reps, double *grad_c
             for (size_t w = 0; w < nw; ++w)
                 if (d[4 * w + 1] > 0) t0 = std::min(t0, d[4 * w]), t1 = std::max(t1, d[4 * w + 1]), dur += d[4 * w + 1] - d[4 * w], ++cnt;
             int nb8 = 0, nbc8 = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb8, k_gd_grad_w<8, 8>, 256, 0);
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbc8, k_gd_grad_c<8, 2>, 64, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb8, k_gd_grad_w<double, 8, 8>, 256, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbc8, k_gd_grad_c<double, 8, 2>, 64, 0);
             fprintf(stderr, "[grad_w probe] runtime occupancy: grad_w<8,8> %d workgroups/CU, grad_c<8> %d\n", nb8, nbc8);
             fprintf(stderr, "[grad_w probe] %zu waves, span %.1f us, mean wave %.1f us\n", cnt, (t1 - t0) / 100, dur / cnt / 100);
             // concurrency over time (20 buckets) and waves per (xcc, cu, simd) slot

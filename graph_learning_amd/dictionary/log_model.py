@@ -55,8 +55,13 @@ class GraphDictLog(BaseEstimator):
                  step_w: float = None, step_dual: float = None, tol: float = 1e-3, reduce_step_on_plateau: bool = False,
                  random_state: RandomState = None, init_strategy: str = "uniform", init_strategy_c: str = None,
                  init_strategy_w: str = None, n_init: int = 1, weight_prior=None, coefficient_prior=None,
-                 early_stop_keyboard: bool = False) -> None:
+                 early_stop_keyboard: bool = False, compute_dtype: str = "float64") -> None:
         super().__init__()
+        # extra to the reference's signature (additive): "float32" runs the two O(K T E) contractions of a step in
+        # packed fp32 on the device (BASELINE configs[4]); the state, every fold and the prox stay float64
+        if compute_dtype not in ("float64", "float32"):
+            raise ValueError(f"compute_dtype must be 'float64' or 'float32', got {compute_dtype!r}")
+        self.compute_dtype = compute_dtype
         self.n_atoms = n_atoms
         self.window_size = window_size
         self.ortho_w = ortho_w
@@ -187,6 +192,8 @@ class GraphDictLog(BaseEstimator):
         loop is driven step by step from here so that the callback sees every iterate."""
         self._initialize(x)
         with _lib.GraphDictSession(self.n_nodes_, x.shape[0], self.n_atoms, self.window_size, ctx) as s:
+            if self.compute_dtype == "float32":
+                s.set_precision(32)
             s.set_signals(x)
             s.set_params(**self._params())
             s.set_state(self.coefficients_, self.weights_, self.dual_)
@@ -269,6 +276,8 @@ class GraphDictLog(BaseEstimator):
             raise ValueError("predict: n_samples must be a multiple of window_size")  # the reference's reshape fails
         c0 = self._init_coefficients(x)
         with _lib.GraphDictSession(n_nodes, n_samples, self.n_atoms, self.window_size, ctx) as s:
+            if self.compute_dtype == "float32":
+                s.set_precision(32)
             s.set_signals(x)
             s.set_params(**self._params())
             s.set_state(c0, self.weights_, None)

@@ -235,6 +235,10 @@ int gl_graphdict_get_state(gl_graphdict *s, double *coefficients, double *weight
 /* l1_w, ortho_w, l1_c, log_c, l1_diff_c, step_c, step_w, step_dual (base_model.py:95-117). */
 int gl_graphdict_set_params(gl_graphdict *s, double l1_w, double ortho_w, double l1_c, double log_c,
                             double l1_diff_c, double step_c, double step_w, double step_dual);
+/* Precision of the two O(K T E) contractions of a step (`self.weights_ @ sq_pdiffs.T`, base_model.py:375, and
+ * `self.coefficients_ @ sq_pdiffs`, :447): 64 (default, what the reference computes) or 32 (BASELINE configs[4]:
+ * fp32 operands and partial sums, packed two per instruction; folds, projections, dual prox and state stay fp64). */
+int gl_graphdict_set_precision(gl_graphdict *s, int bits);
 /* current (step_c, step_w, step_dual): reduce_step_on_plateau shrinks them (base_model.py:571-573) */
 int gl_graphdict_get_steps(gl_graphdict *s, double *steps3_out);
 /* Which form fit / predict will take for this session: 1 = the whole loop in one launch of one workgroup

@@ -10,7 +10,9 @@ x = rng.standard_normal((t, n)) * 0.3
 e = n * (n - 1) // 2
 rs = np.random.RandomState(0)
 c0, w0 = rs.uniform(size=(k, t)), rs.uniform(size=(k, e))
+bits = int(os.environ.get("GD_BITS", "64"))
 with _lib.GraphDictSession(n, t, k) as s:
+    s.set_precision(bits)
     s.set_signals(x)
     s.set_params(l1_w=0.01, step_c=0.5, step_w=0.5, step_dual=0.5)
     s.set_state(c0, w0)
@@ -19,7 +21,7 @@ with _lib.GraphDictSession(n, t, k) as s:
     gc, gw = s.time_gradients(5)
     pair_samples = t * e
     lane_ops = pair_samples * (2 + 2 * k)
-    print(f"n={n} T={t} K={k}: {dt*1e3:.3f} ms/step ({1/dt:.1f} steps/s); grad_c {gc/1e3:.3f} ms, grad_w {gw/1e3:.3f} ms; "
+    print(f"fp{bits} n={n} T={t} K={k}: {dt*1e3:.3f} ms/step ({1/dt:.1f} steps/s); grad_c {gc/1e3:.3f} ms, grad_w {gw/1e3:.3f} ms; "
           f"fp64 vector rate grad_c {lane_ops/gc/1e6:.2f} TFLOP/s-equivalent (fma=2: {2*pair_samples*k/gc/1e6:.2f}), "
           f"grad_w {2*pair_samples*k/gw/1e6:.2f} TFLOP/s (fma only)")
     print("history tail", hist[-1])
