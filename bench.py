@@ -65,6 +65,72 @@ def cpu_baseline(z_scaled: np.ndarray, budget_its=(3, 13)):
             "sample": f"same n={n} problem, ({hi}-{lo}) iterations of the NumPy/SciPy-CSR oracle, single thread"}
 
 
+def other_configs(ctx):
+    """Bounded measurements of the other BASELINE configs on this GPU (rank 0, N = 1 only; ~3 s together).
+    They are reported under config.other_configs and are NOT the graded `value`.
+
+    lgmrf      BASELINE configs[2]: LGMRF n=2048, d=512 (S = X'X/d, X ~ N(0, (L+I)^-1)): 64 node updates of the
+               block-coordinate descent (lgmrf.py:175-219), timed through the C ABI with the fit capped by
+               GRAPHLEARN_AMD_LGMRF_MAX_NODES; every QP runs its 100 ADMM steps on this input.
+    graphdict  BASELINE configs[4]: GraphDictLog K=8, n=1024, T=4096: ms per primal-dual step, fp64 (what the reference
+               computes) and fp32 contractions (what the config names)."""
+    import numpy as np
+    from graph_learning_amd import _lib
+    out = {}
+    try:
+        n, t, k = 1024, 4096, 8
+        rng = np.random.default_rng(0)
+        x = rng.standard_normal((t, n)) * 0.3
+        rs = np.random.RandomState(0)
+        c0, w0 = rs.uniform(size=(k, t)), rs.uniform(size=(k, n * (n - 1) // 2))
+        for bits in (64, 32):
+            with _lib.GraphDictSession(n, t, k, ctx=ctx) as s:
+                s.set_precision(bits)
+                s.set_signals(x)
+                s.set_params(l1_w=0.01, step_c=0.5, step_w=0.5, step_dual=0.5)
+                s.set_state(c0, w0)
+                s.fit(2, 0.0)
+                t0 = time.perf_counter()
+                s.fit(10, 0.0)
+                dt = (time.perf_counter() - t0) / 10
+                gc, gw = s.time_gradients(5)
+            out[f"graphdict_fp{bits}"] = {"workload": "GraphDictLog K=8 n=1024 T=4096 (BASELINE configs[4])", "ms_per_step": dt * 1e3,
+                                         "steps_per_s": 1 / dt, "grad_c_us": gc, "grad_w_us": gw,
+                                         "dtype": "f64" if bits == 64 else "f32 contractions, f64 folds and state",
+                                         "contraction_tflops_fma_only": 2.0 * t * (n * (n - 1) // 2) * k / (gw * 1e-6) / 1e12}
+    except Exception as exc:  # a leg that cannot run is reported, never silently dropped
+        out["graphdict_error"] = repr(exc)
+    try:
+        from scipy.linalg import solve_triangular
+        from graph_learning_amd import LGMRF
+        from graph_learning_amd.synth import er_laplacian
+        n, d, nodes = 2048, 512, 64
+        rng = np.random.default_rng(7)
+        lap = er_laplacian(n, 6.0 / n, 0.3, 2.0, seed=rng)
+        xs = solve_triangular(np.linalg.cholesky(lap + np.eye(n)), rng.standard_normal((n, d)), lower=True, trans="T").T
+        cov = xs.T @ xs / d
+        os.environ["GRAPHLEARN_AMD_LGMRF_MAX_NODES"] = "0"
+        t0 = time.perf_counter()
+        LGMRF(max_cycle=1).fit(cov, ctx=ctx)            # transfers, set-up and the cycle's inverse only
+        base = time.perf_counter() - t0
+        os.environ["GRAPHLEARN_AMD_LGMRF_MAX_NODES"] = str(nodes)
+        t0 = time.perf_counter()
+        LGMRF(max_cycle=1).fit(cov, ctx=ctx)
+        dt = time.perf_counter() - t0 - base
+        del os.environ["GRAPHLEARN_AMD_LGMRF_MAX_NODES"]
+        m = n - 1
+        out["lgmrf"] = {"workload": "LGMRF n=2048 d=512 (BASELINE configs[2]), block-coordinate node updates, fast path",
+                        "node_updates_timed": nodes, "ms_per_node_update": dt * 1e3 / nodes, "node_updates_per_s": nodes / dt,
+                        "ms_per_cycle_projected": dt * 1e3 / nodes * n, "admm_steps_per_node_update": 100,
+                        # SURVEY 8d: bytes >= 3 x 8 m^2 per node update (read C, write it back, read the ADMM matrix once)
+                        "byte_floor_frac_of_hbm_peak": 3 * 8 * m * m / (dt / nodes) / 1e9 / HBM_PEAK_GBS,
+                        "bound": "latency: 100 dependent ADMM steps per node update (DESIGN.md section 5)", "dtype": "f64"}
+    except Exception as exc:
+        out["lgmrf_error"] = repr(exc)
+        os.environ.pop("GRAPHLEARN_AMD_LGMRF_MAX_NODES", None)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +143,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-converge", action="store_true")
     ap.add_argument("--converge-maxit", type=int, default=200000)
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the LGMRF / GraphDictLog legs (config.other_configs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -240,6 +307,8 @@ def main():
                                   "(`streamed_bytes_per_iteration`) against the same 8 TB/s; the kernel is bound by fp64 "
                                   "issue and hand-off latency, not by memory (DESIGN.md section 3a)") if engine == "resident" else None},
         }
+        if not args.no_other_configs and world == 1:
+            out["config"]["other_configs"] = other_configs(ctx)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
             z = sess.get_distances() * theta
             out["cpu_baseline"] = cpu_baseline(z)

@@ -2013,7 +2013,11 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
             k_lg_shift<<<g2, 256, 0, ctx->stream>>>(D.Th, D.G, n, D.rho);
             GL_TRY(invert_spd_inplace(ctx, D.G, n, pivrow));
         }
-        for (int64_t u = 0; u < n; ++u) {
+        // measurement facility (bench.py's lgmrf leg): GRAPHLEARN_AMD_LGMRF_MAX_NODES caps the node updates of a cycle,
+        // so that a bounded sample of a BASELINE-size cycle can be timed; the result is then NOT a fit
+        int64_t u_end = n;
+        if (const char *e = getenv("GRAPHLEARN_AMD_LGMRF_MAX_NODES")) u_end = std::max<int64_t>(0, std::min<int64_t>(n, atoll(e)));
+        for (int64_t u = 0; u < u_end; ++u) {
             k_lg_qp_setup<<<1, VT, 0, ctx->stream>>>(D, u);
             const bool fused_winv = fast && (ares.wave || ares.quad || (ares.on && ares.tagged));  // the ADMM kernel forms its rows of the inverse itself
             if (fused_winv) {
