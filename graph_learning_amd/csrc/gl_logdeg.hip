@@ -1121,7 +1121,8 @@ GL_API int gl_logdeg_iterate_async(gl_logdeg *s, int64_t n_iter) {
             GL_HIP(ctx, hipMemcpyAsync(s->dev.w[itf & 1], s->dev.w[s->it & 1], bytes, hipMemcpyDeviceToDevice,
                                        ctx->stream));
         }
-        GL_HIP(ctx, hipMemsetAsync(s->dev.ctr, 0, 2 * 8, ctx->stream));
+        // (the tile engine leaves ctr[0] = 0 itself after a tol = 0 call: its launch is alone on the stream)
+        if (!s->tile) GL_HIP(ctx, hipMemsetAsync(s->dev.ctr, 0, 2 * 8, ctx->stream));
         s->it = itf;
         s->res_pending = (s->res_unchecked ? s->res_pending : 0) + n_iter;
         s->res_unchecked = true;

@@ -107,7 +107,7 @@ struct TileDev {
     long long it0;
     int maxit;
     unsigned tag0;
-    int rendezvous;
+    unsigned rendezvous;  // value the arrival counter reaches when every workgroup of this launch has arrived
 };
 
 __device__ __forceinline__ double tl_val(tl_u4 g) {
@@ -365,11 +365,13 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     const auto r_wn = __builtin_amdgcn_make_buffer_rsrc((void *)P.wnorm, 0, (int)(4 * P.NWG * 2 * 16), 0x00020000);
     const auto r_bn = __builtin_amdgcn_make_buffer_rsrc((void *)P.bnrm, 0, (int)(4 * P.nb * 4 * 16), 0x00020000);
 
-    // ---- start-up rendezvous: every workgroup of the grid is on the chip, or nobody touches anything
+    // ---- start-up rendezvous: every workgroup of the grid is on the chip, or nobody touches anything.  The arrival
+    //      counter is monotonic over the launches of the session (target = arrivals so far + grid), so nothing has to be
+    //      reset between launches: the launch is the only thing on the stream.
     if (tid == 0) {
-        const GlGridBar gb{P.bar, P.rendezvous};
-        GlBarState bs{};
-        s_flag[0] = gl_barrier_setup(gb, bs) ? 1 : 0;
+        const GlGridBar gb{P.bar, 0};
+        __hip_atomic_fetch_add(P.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_flag[0] = gl_spin_until(gb, P.bar, P.rendezvous) ? 1 : 0;
         s_flag[1] = 0;
         s_flag[2] = 0;
         s_flag[3] = 0;
@@ -808,6 +810,7 @@ struct gl_tile {
     size_t gran_off = 0, gran_bytes = 0;  // the record buffers inside it
     unsigned long long *dbg = nullptr;
     unsigned next_tag = 1u;     // first tag of the next launch (a launch uses maxit + 2 consecutive ones, never 0)
+    unsigned arrivals = 0;      // workgroups that have arrived at the start-up rendezvous over all launches so far
 };
 
 void gl_tile_free(gl_logdeg *s) {
@@ -1040,8 +1043,12 @@ int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms) {
     }
     P.tag0 = t->next_tag;
     t->next_tag += (unsigned)P.maxit + 2u;
-    P.rendezvous = P.NWG + (getenv("GRAPHLEARN_AMD_RES_TEST_NOT_RESIDENT") ? 1 : 0);
-    GL_HIP(ctx, hipMemsetAsync(P.bar, 0, GL_BAR_WORDS * 4, ctx->stream));
+    if (t->arrivals > 0xF0000000u - (unsigned)P.NWG) {  // (after ~16 million launches)
+        GL_HIP(ctx, hipMemsetAsync(P.bar, 0, GL_BAR_WORDS * 4, ctx->stream));
+        t->arrivals = 0;
+    }
+    t->arrivals += (unsigned)P.NWG;
+    P.rendezvous = t->arrivals + (getenv("GRAPHLEARN_AMD_RES_TEST_NOT_RESIDENT") ? 1u : 0u);
     const bool ragged = D.n % TB != 0;
     const dim3 grid((unsigned)P.NWG), block(TT);
     auto go = [&](auto kern) { kern<<<grid, block, 0, ctx->stream>>>(P); };
