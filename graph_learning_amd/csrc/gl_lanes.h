@@ -12,8 +12,10 @@
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
     const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    // bound_ctrl with full row / bank masks: every lane has a valid source for the controls used here, and the
+    // compiler does not have to materialise the "old" operand (a v_mov 0 per half otherwise)
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 constexpr int DPP_ROW_ROR8 = 0x128;     // lane i <- lane i ^ 8 (rows of 16 lanes)

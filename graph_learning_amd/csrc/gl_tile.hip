@@ -44,6 +44,9 @@
 #ifndef GL_TILE_LDS_PREFETCH
 #define GL_TILE_LDS_PREFETCH 1  // request the LDS operands of row pair s + 1 before row pair s is computed
 #endif
+#ifndef GL_TILE_PRIO_EIGHTHS
+#define GL_TILE_PRIO_EIGHTHS 4  // the younger wave of a SIMD runs this many eighths of its pass at priority 1
+#endif
 #ifndef GL_TILE_PIN
 #define GL_TILE_PIN 2  // row pairs between two scheduling boundaries of the pass (independent work for the fp64 pipe)
 #endif
@@ -171,7 +174,7 @@ __device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[
 #pragma unroll
     for (int gq = 0; gq < U / 4; ++gq) {
         double rowp[4], roww[4];
-        if (gq == U / 8) __builtin_amdgcn_s_setprio(0);
+        if (gq == (U / 4) * GL_TILE_PRIO_EIGHTHS / 8) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int s = 4 * gq + k;
@@ -897,14 +900,17 @@ int gl_tile_prepare(gl_logdeg *s) {
             w.ftgt = (w.tile >= 0 && w.I != B) ? 2 : 0;  // my column vectors when B is my column block
             need[(size_t)B] -= take;
         };
-        for (int pass = 0; pass < 3; ++pass)
+        // (passes 0, 1: the older half of every workgroup's waves -- waves 0..3 win the issue arbitration of their SIMD
+        //  and finish their pass first --, preferred block then the other one; passes 2, 3: the younger half)
+        for (int pass = 0; pass < 5; ++pass)
             for (int v = 0; v < nwaves; ++v) {
                 WaveDesc &w = wd[(size_t)v];
                 if (w.fcnt != 0) continue;
-                if (w.tile >= 0 && pass < 2) {
+                if (w.tile >= 0 && pass < 4) {
+                    if (((v % TW) < TW / 2) != (pass < 2)) continue;
                     const bool odd = ((w.I + w.J + w.a0 / U) & 1) != 0;
-                    give(w, (odd != (pass == 1)) ? w.J : w.I, pass == 0 ? cap : FRMAX);
-                } else if (w.tile < 0 && pass == 2) {
+                    give(w, (odd != ((pass & 1) == 1)) ? w.J : w.I, (pass & 1) == 0 ? cap : FRMAX);
+                } else if (w.tile < 0 && pass == 4) {
                     int B = 0;
                     for (int b = 1; b < nb; ++b)
                         if (need[(size_t)b] > need[(size_t)B]) B = b;
