@@ -362,3 +362,59 @@ def test_set_distances_after_deferred_theta_resets_theta():
         assert s.set_signals(x, 3, deferred=True) is None
         s.set_distances(np.ones(190))
         assert s.theta() == 1.0
+
+
+def test_just_past_the_register_files_n4160_against_oracle(engine):
+    """n = 4160 (65 node blocks, 2080 bulk tiles): one block past what the tile engine's register files hold, so
+    every engine choice ends on the streaming engine; 18 iterations in one call against the oracle."""
+    if engine not in ("stream", "resident"):
+        pytest.skip("once forced to the streaming engine, once through the automatic fallback of the resident family")
+    n = 4160
+    rng = np.random.default_rng(n)
+    e = n * (n - 1) // 2
+    z = rng.uniform(0.05, 3.0, size=e)
+    with _lib.LogDegreeSession(n) as s:
+        s.set_distances(z)
+        s.init(1.1, 0.9, 0.5, None)
+        assert s.engine == "stream" and s.engine_kernel == "k_edge"
+        n_it, conv, rel = s.iterate(18, 0.0)
+        w, d = s.weights_condensed(), s.dual()
+    _, info = old.learn_log_degrees(z, 1.1, 0.9, maxit=18, tol=0.0, edge_tol=-np.inf, return_info=True)
+    np.testing.assert_allclose(w, info["raw"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(d, info["dual"], rtol=0, atol=ATOL)
+    assert rel[0] == pytest.approx(info["rel"][0], rel=1e-9) and rel[1] == pytest.approx(info["rel"][1], rel=1e-9)
+
+
+def test_large_lattice_n8192_against_dense_restatement(engine):
+    """n = 8192 (beyond the Infinity Cache: 3 x 268 MB): three iterations of the streaming engine against a dense
+    NumPy restatement of :146-167 (S w = row sums of the symmetric matrix, S'd = d_i + d_j), which needs no sparse
+    operator at this size."""
+    if engine != "stream":
+        pytest.skip("the streaming engine is the only one at this size")
+    n = 8192
+    rng = np.random.default_rng(5)
+    iu = np.triu_indices(n, 1)
+    zsq = np.zeros((n, n))
+    zsq[iu] = rng.uniform(0.05, 3.0, size=iu[0].size)
+    zsq = zsq + zsq.T
+    alpha, beta, step = 1.0, 1.0, 0.5
+    g = step / (2 * beta + np.sqrt(2 * (n - 1)))
+    wm = np.zeros((n, n))
+    d = np.zeros(n)
+    off = ~np.eye(n, dtype=bool)
+    for _ in range(3):
+        y = (1 - 2 * g * beta) * wm - g * (d[:, None] + d[None, :])
+        yb = d + g * wm.sum(1)
+        p = np.where(y - 2 * g * zsq > 0, y - 2 * g * zsq, 0) * off
+        pb = (yb - np.sqrt(yb**2 + 4 * alpha * g)) / 2
+        q = (1 - 2 * g * beta) * p - g * (pb[:, None] + pb[None, :])
+        qb = pb + g * p.sum(1)
+        wm = (wm - y + q) * off
+        d = d - yb + qb
+    with _lib.LogDegreeSession(n) as s:
+        s.set_distances(np.ascontiguousarray(zsq[iu]))
+        s.init(alpha, beta, step, None)
+        s.iterate(3, 0.0)
+        w, dd = s.weights_condensed(), s.dual()
+    np.testing.assert_allclose(w, wm[iu], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(dd, d, rtol=0, atol=1e-11)
