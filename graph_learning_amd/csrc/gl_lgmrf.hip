@@ -527,6 +527,11 @@ __global__ __launch_bounds__(256) void k_lg_admm_res(LgDev D, GlGridBar gb, int 
 //     when waited for, hides behind a whole step), by every workgroup from the same values in the same
 //     order, and three generations of the row state stay in registers to return the one of step s.
 //     Partials live in a ring of four slots: a writer is never more than three steps ahead of a reader.
+// Measured and rejected (round 2): a two-level hand-off -- one workgroup per XCD (elected per launch, XCD from
+// HW_REG_XCC_ID) polls the records and republishes them with plain stores into a per-XCD copy that stays in that XCD's
+// L2, the others poll the copy -- cuts the fabric traffic of a poll round from 8 MB to 256 KB at n = 2048 and is
+// correct, but the extra hop costs more than the traffic did: 0.747 against 0.679 ms per node update at n = 2048,
+// 0.504 against 0.455 at n = 1024.  A step is bound by hand-off latency, not by the bytes polled.
 // Needs all workgroups co-resident like the barrier form; there is no rendezvous: the first poll is one (a
 // workgroup that is not on the chip never publishes tag 0), every spin is bounded by the wall clock, and a
 // run that gives up has written nothing but records.
@@ -536,17 +541,11 @@ __device__ __forceinline__ double lg_pack(unsigned lo, unsigned hi) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-// Two-level hand-off (xbuf != nullptr; large n): with 256 workgroups every poll round moves n x 16 B x 256 = 8 MB through
-// the fabric (write-through records are not kept in any L2), which is what a step costs.  So ONE workgroup per XCD --
-// the first of the launch to arrive on it, elected with an atomic max of the launch's first tag, its XCD read from
-// HW_REG_XCC_ID -- polls the records and republishes them, same granules, with PLAIN stores into a buffer of its XCD:
-// those lines stay in that XCD's L2, where the other workgroups of the XCD poll them (L1 bypassed).  Fabric traffic per
-// round: 8 x 32 KB.  Correctness never depends on placement: a workgroup only ever reads the buffer of the XCD it runs on.
 __global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u4 *gran, unsigned tag0, int R, int max_iter,
-                                                     int64_t u_fast, int test_missing, lg_u4 *xbuf, unsigned *xlead) {
+                                                     int64_t u_fast, int test_missing) {
     extern __shared__ double s_W[];  // R rows of W, row-major (R * n doubles)
     __shared__ double s_acc[2][4][ADMM_RES_MAXR];
-    __shared__ int s_fail, s_stop[2], s_xcc, s_lead;
+    __shared__ int s_fail, s_stop[2];
     if (D.scal[8] != 0.0) return;  // an earlier QP could not run (workgroups not co-resident): the host redoes the cycle
     const int64_t n = D.n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -572,16 +571,8 @@ __global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, unsigned *err, lg_
     } else {
         for (int64_t q = tid; q < (int64_t)nrows * n; q += 256) s_W[q] = D.W[r0 * n + q];
     }
-    if (tid == 0) {
-        s_fail = 0;
-        s_xcc = (int)(__builtin_amdgcn_s_getreg(63508) & 7u);  // hwreg(HW_REG_XCC_ID, 0, 32)
-        s_lead = 1;
-        if (xbuf) s_lead = __hip_atomic_fetch_max(xlead + 32 * s_xcc, tag0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < tag0 ? 1 : 0;
-    }
+    if (tid == 0) s_fail = 0;
     __syncthreads();
-    const bool two_level = xbuf != nullptr, leader = s_lead != 0;
-    lg_u4 *xb = two_level ? xbuf + (int64_t)s_xcc * 2 * n : nullptr;  // my XCD's copy: [2][n] records
-    const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(two_level ? xb : gran), 0, (int)(2 * n * 16), 0x00020000);
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)gran, 0, (int)(2 * n * 16), 0x00020000);
     const auto prsrc = __builtin_amdgcn_make_buffer_rsrc((void *)D.part, 0, (int)(4 * nblk * 48), 0x00020000);
     auto publish = [&](int parity, int64_t i, double v, unsigned tag) {
@@ -619,24 +610,12 @@ __global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, unsigned *err, lg_
                 for (int c = 0; c < ADMM_RES_MAXR; ++c) {
                     const int64_t j = tid + 256 * (int64_t)c;
                     lg_u4 g = {0u, tag, 0u, tag};
-                    if (j < n) g = __builtin_amdgcn_raw_buffer_load_b128(leader ? rsrc : xrsrc, (int)((((it & 1) * n) + j) * 16), 0, 16);
+                    if (j < n) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((((it & 1) * n) + j) * 16), 0, 16);
                     ok = ok && g.y == tag && g.w == tag;
                     vj[c] = lg_pack(g.x, g.z);
                 }
                 asm volatile("" ::: "memory");  // the loads stay in the loop
-                if (__all(ok)) {
-                    if (two_level && leader) {  // republish for my XCD: plain stores, the lines stay in its L2
-#pragma unroll
-                        for (int c = 0; c < ADMM_RES_MAXR; ++c) {
-                            const int64_t j = tid + 256 * (int64_t)c;
-                            if (j < n) {
-                                const unsigned long long b = (unsigned long long)__double_as_longlong(vj[c]);
-                                xb[(it & 1) * n + j] = lg_u4{(unsigned)b, tag, (unsigned)(b >> 32), tag};
-                            }
-                        }
-                    }
-                    break;
-                }
+                if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(4);  // ~0.1 us: leave the fabric to the stores we wait for
                 if ((spins & 63u) == 63u &&
                     (gl_ld_u32(err) != 0u || __builtin_amdgcn_s_memrealtime() - t_start > 100000000ull)) {
@@ -1423,8 +1402,6 @@ struct AdmmRes {
     // "tagged" form (k_lg_admm_tag): v travels as self-validating records, no grid barrier
     bool tagged = false;
     lg_u4 *gran = nullptr;  // [2][n] records of 16 bytes
-    lg_u4 *xbuf = nullptr;  // two-level hand-off: [8 XCDs][2][n] records, republished by one workgroup per XCD (null: off)
-    unsigned *xlead = nullptr;  // ... and its election words (one per XCD, 128 bytes apart)
     unsigned next_tag = 0;  // first tag of the next launch (a launch uses max_iter + 1 consecutive ones)
 };
 
@@ -1433,20 +1410,6 @@ struct AdmmRes {
 // 100 steps), launch / grid-barrier / tagged:  n = 128: 0.66 / 0.61 / 0.38 ms,  256: 0.67 / 0.72 / 0.39,
 // 500: 0.90 / 0.81 / 0.46,  1024: 0.96 / 0.89 / 0.56,  2048: 1.62 / 1.20 / 0.80;  single workgroup
 // against tagged at n = 32: 0.26 / 0.20, n = 64: 0.48 / 0.30.  To n = 64 the default is the single-wave form.
-
-// record area of the tagged form: [2][n] records, then -- two-level hand-off -- [8][2][n] per-XCD copies and the 8 election words
-size_t admm_gran_bytes(int64_t n) { return ((size_t)2 * n + (size_t)16 * n) * 16 + 8 * 128; }
-void admm_gran_attach(AdmmRes &A, void *base, int64_t n) {
-    A.gran = (lg_u4 *)base;
-    A.xbuf = nullptr;
-    A.xlead = nullptr;
-    const char *e = getenv("GRAPHLEARN_AMD_LGMRF_XCD");
-    // from 64 workgroups on (n >= 256 with 4 rows each) a poll round of everybody costs more than the extra hop
-    if (A.on && A.tagged && A.nwg >= 64 && !(e && !strcmp(e, "0"))) {
-        A.xbuf = A.gran + 2 * n;
-        A.xlead = (unsigned *)(A.xbuf + 16 * n);
-    }
-}
 
 int admm_res_plan(gl_ctx *ctx, int64_t n, AdmmRes &A) {
     A.on = A.one = A.wave = A.quad = A.tagged = false;
@@ -1519,14 +1482,14 @@ int run_admm_res(gl_ctx *ctx, const LgDev &D, AdmmRes &A, int max_iter, int64_t 
         // tags of this launch: next_tag .. next_tag + max_iter (never 0, never one a record may still carry)
         if (max_iter >= (1 << 28)) return gl_set_error(ctx, GL_E_INVALID, "ADMM: max_iter too large");
         if (A.next_tag == 0u || A.next_tag > 0xE0000000u) {  // first use, or the tags would wrap into old ones
-            GL_HIP(ctx, hipMemsetAsync(A.gran, 0, admm_gran_bytes(D.n), ctx->stream));
+            GL_HIP(ctx, hipMemsetAsync(A.gran, 0, (size_t)2 * D.n * 16, ctx->stream));
             A.next_tag = 1u;
         }
         const unsigned tag0 = A.next_tag;
         A.next_tag += (unsigned)max_iter + 2u;
         // error word: bar[32], zero since the allocation (a failure ends the use of this form)
         k_lg_admm_tag<<<dim3((unsigned)A.nwg), 256, A.lds, ctx->stream>>>(D, A.bar + 32, A.gran, tag0, A.R, max_iter, u_fast,
-                                                                           test_not_resident ? 1 : 0, A.xbuf, A.xlead);
+                                                                           test_not_resident ? 1 : 0);
         GL_HIP(ctx, hipGetLastError());
         return GL_OK;
     }
@@ -1856,7 +1819,7 @@ GL_API int gl_nonneg_qp_solve(gl_ctx *ctx, const double *mat, const double *vec,
     {
         auto up = [](size_t b) { return (b + 255) / 256 * 256; };
         const size_t bW = up((size_t)m * m * 8), bPart = up((size_t)4 * m * 6 * 8), bBar = up(GL_BAR_WORDS * 4),
-                     bGran = up(admm_gran_bytes(m)), bVec = up((size_t)16 * m * 8), bScal = up(16 * 8);
+                     bGran = up((size_t)2 * m * 16), bVec = up((size_t)16 * m * 8), bScal = up(16 * 8);
         GL_HIP(ctx, hipMalloc(&arena.p, bW + bPart + bBar + bGran + bVec + bScal));
         char *at = (char *)arena.p;
         W.p = at, at += bW;
@@ -1870,7 +1833,7 @@ GL_API int gl_nonneg_qp_solve(gl_ctx *ctx, const double *mat, const double *vec,
     AdmmRes ares;
     GL_TRY(admm_res_plan(ctx, m, ares));
     ares.bar = (unsigned *)bar.p;
-    admm_gran_attach(ares, gran.p, m);
+    ares.gran = (lg_u4 *)gran.p;
     double *V = (double *)vecs.p;
     LgDev D{};
     D.n = m;
@@ -1959,12 +1922,12 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
     GL_HIP(ctx, hipMalloc(&bAdmm.p, (size_t)4 * n * 6 * 8));  // one entry per workgroup and ring slot, any ADMM form
     GL_HIP(ctx, hipMalloc(&bBar.p, GL_BAR_WORDS * 4));
     GL_HIP(ctx, hipMemsetAsync(bBar.p, 0, GL_BAR_WORDS * 4, ctx->stream));
-    GL_HIP(ctx, hipMalloc(&bGran.p, admm_gran_bytes(n)));
-    GL_HIP(ctx, hipMemsetAsync(bGran.p, 0, admm_gran_bytes(n), ctx->stream));
+    GL_HIP(ctx, hipMalloc(&bGran.p, (size_t)2 * n * 16));
+    GL_HIP(ctx, hipMemsetAsync(bGran.p, 0, (size_t)2 * n * 16, ctx->stream));
     AdmmRes ares;
     GL_TRY(admm_res_plan(ctx, n, ares));
     ares.bar = (unsigned *)bBar.p;
-    admm_gran_attach(ares, bGran.p, n);
+    ares.gran = (lg_u4 *)bGran.p;
     if (ares.on) GL_HIP(ctx, hipMalloc(&bCprev.p, (size_t)n * n * 8));
     GL_HIP(ctx, hipMemsetAsync(bVec.p, 0, (size_t)16 * n * 8, ctx->stream));
     GL_HIP(ctx, hipMemsetAsync(bScal.p, 0, 16 * 8, ctx->stream));
