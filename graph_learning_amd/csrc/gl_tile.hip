@@ -661,7 +661,15 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             {
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 unsigned spins = 0;
-                for (int eb = own_e0 + wave; eb < own_e1 && good; eb += TW * RND) {  // rounds of up to RND records per wave
+                // wave TW - 1 also reads my slice of the workgroups' norm records (workgroups own, own + nb, ...): a workgroup
+                // publishes them right behind its degree records, so they ride in the same poll round (a poll of their
+                // own behind the records cost the owner a second round trip: 0.7 us per iteration in converge mode)
+                const bool slicer = NORMS && wave == TW - 1;
+                const int nsrc = own + lane * (int)P.nb;
+                const bool nmine = slicer && nsrc < P.NWG && ((slice_mask >> lane) & 1ull);
+                tl_u4 na = tl_u4{0u, tag_out, 0u, tag_out}, nb2 = na;
+                bool nok = !slicer;
+                for (int eb = own_e0 + wave; (eb < own_e1 || !nok) && good; eb += TW * RND) {  // rounds of up to RND records per wave
                     tl_u4 g[RND][2];
                     for (;;) {
                         bool ok = true;
@@ -676,8 +684,19 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                             }
                             ok = ok && tl_ok(g[u][0], tag_out) && tl_ok(g[u][1], tag_out);
                         }
+                        if (!nok) {
+                            if (nmine) {
+                                const int off = (((it & 3) * P.NWG + nsrc) * 2) * 16;
+                                na = __builtin_amdgcn_raw_buffer_load_b128(r_wn, off, 0, 16);
+                                nb2 = __builtin_amdgcn_raw_buffer_load_b128(r_wn, off + 16, 0, 16);
+                            }
+                            ok = ok && tl_ok(na, tag_out) && tl_ok(nb2, tag_out);
+                        }
                         asm volatile("" ::: "memory");
-                        if (__all(ok)) break;
+                        if (__all(ok)) {
+                            nok = true;
+                            break;
+                        }
                         if (!tl_spin(spins, t0, err)) {
                             good = false;
                             break;
@@ -692,21 +711,8 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 }
                 s_own[wave][0][lane] = sp;
                 s_own[wave][1][lane] = sw;
-                if (wave == TW - 1) {  // my slice of the workgroups' norm records: workgroups own, own + nb, ...
-                    tl_u4 a = tl_u4{0u, tag_out, 0u, tag_out}, b = a;
-                    const int src = own + lane * (int)P.nb;
-                    const bool mine = src < P.NWG && ((slice_mask >> lane) & 1ull);
-                    for (; good;) {
-                        if (mine) {
-                            const int off = (((it & 3) * P.NWG + src) * 2) * 16;
-                            a = __builtin_amdgcn_raw_buffer_load_b128(r_wn, off, 0, 16);
-                            b = __builtin_amdgcn_raw_buffer_load_b128(r_wn, off + 16, 0, 16);
-                        }
-                        asm volatile("" ::: "memory");
-                        if (__all(tl_ok(a, tag_out) && tl_ok(b, tag_out))) break;
-                        if (!tl_spin(spins, t0, err)) good = false;
-                    }
-                    const double n0 = wave_sum(mine ? tl_val(a) : 0.0), n1 = wave_sum(mine ? tl_val(b) : 0.0);
+                if (slicer) {
+                    const double n0 = wave_sum(nmine ? tl_val(na) : 0.0), n1 = wave_sum(nmine ? tl_val(nb2) : 0.0);
                     if (lane == 0) {
                         s_ns[0] = n0;
                         s_ns[1] = n1;
