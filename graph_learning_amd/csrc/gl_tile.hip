@@ -76,7 +76,11 @@ struct WaveDesc {  // 16 ints
     int fcnt;      // fringe group: row pairs fa0 .. fa0 + fcnt - 1 of diagonal tile (fB, fB); 0: none
     int fa0, fB, fs;  // ... its first row pair, node block, slot of that block in the workgroup's list
     int ftgt;      // where its degree partials are folded: 0 = my row vectors (fB == I, or no chunk), 2 = my column vectors (fB == J)
-    int pad[5];
+    // n > 4096 ("rounds", see k_tile): the wave works on tiles (I + r, J), r = 0 .. nr - 1, one per round; the first one
+    // is resident (tile >= 0) when it is not a diagonal tile, the others stream
+    int nr;        // rounds this wave takes part in
+    int rs;        // slot of node block I + r in the workgroup's block list: 4 bits per round
+    int pad[3];
 };
 struct WgDesc {  // 128 ints
     int nblk;
@@ -85,7 +89,9 @@ struct WgDesc {  // 128 ints
     int blk[NBW], ent[NBW], rowmask[NBW], colmask[NBW];
     unsigned slice_lo, slice_hi;  // owners: bit r set = workgroup own + r nb takes part (publishes norm records)
     int active;                   // this workgroup has edges or owns a block (the others leave after the rendezvous)
-    int pad[128 - 7 - 4 * NBW];
+    int nrnd;                     // rounds of this workgroup (n > 4096; rowmask holds 8 bits per round, rowmask2 rounds 4 .. 7)
+    int rowmask2[NBW];
+    int pad[128 - 8 - 5 * NBW];
 };
 static_assert(sizeof(WaveDesc) == 64 && sizeof(WgDesc) == 512, "descriptor sizes");
 
@@ -150,23 +156,26 @@ __device__ __forceinline__ double2 tl_ldz(const double *base, unsigned byte_off)
 // The LDS operands of row pair s + 1 are requested before row pair s is computed: the empty asm after every
 // row pair (it pins the running sums, which LLVM otherwise sinks to the end of the unrolled body, spilling every
 // addend on the way) is a scheduling boundary.
-template <int U, bool RAGGED, bool NORMS>
+// WRAP = false (rounds): the ring is filled by the caller right before the pass and is dead after it.
+template <int U, bool RAGGED, bool NORMS, bool WRAP = true>
 __device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[U], double2 (&zr)[RING], const double2 *zl,
                                               const unsigned zb, const double2 *s_rows, const double dj0, const double dj1,
                                               const double pj0, const double pj1, const double m0, const double m1,
-                                              double *s_row, double *s_col, const int lane, const bool younger, double &nqy,
+                                              double *s_row, double (&col)[4], const int lane, const bool younger, double &nqy,
                                               double &nw) {
     constexpr int NS = U == SLOTS ? SLOTS / 2 : 0;  // streamed row pairs
-    const int half = lane >> 5, c0 = 2 * (lane & 31);
+    const int half = lane >> 5;
     const double c = P.c, g = P.gamma, g2 = P.g2;
-    double colp0 = 0, colp1 = 0, colw0 = 0, colw1 = 0;
+    double colp0 = col[0], colp1 = col[1], colw0 = col[2], colw1 = col[3];
     // not loop-invariant for the compiler: otherwise it hoists one 64-bit address per streamed row pair (and the
     // LDS addresses) out of the iteration loop, for each instantiation of this pass, and spills them all
     unsigned zbv = zb;
     asm volatile("" : "+v"(zbv));
-    double2 rv_n = s_rows[half];
-    double2 zl_n = double2{0.0, 0.0};
-    if (NS == 0) zl_n = zl[0];  // (U = 32: row pair 0 streams)
+    double2 rv_n = double2{0.0, 0.0}, zl_n = double2{0.0, 0.0};
+    if (GL_TILE_LDS_PREFETCH && WRAP) {
+        rv_n = s_rows[half];
+        if (NS == 0) zl_n = zl[0];  // (U = 32: row pair 0 streams)
+    }
     // Two waves share a SIMD (waves v and v + 4); both at priority 0 the older one takes the issue slots it wants and
     // the younger the rest, then finishes alone at half the fp64 rate (measured: 5.8 against 8.1 us at n = 4096).  The
     // younger half therefore runs the first half of its pass at priority 1: both end together.
@@ -185,21 +194,22 @@ __device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[
                 const int pos = (s / 2) % RING;
                 gz = double2{g2 * zr[pos].x, g2 * zr[pos].y};
                 // refill with the RING-th next streamed row pair (2 RING row pairs ahead; wraps into the next iteration)
-                zr[pos] = tl_ldz(P.z, zbv + (unsigned)(((s + 2 * RING) % SLOTS) * (2 * TB) * 8));
+                if (WRAP || s + 2 * RING < SLOTS) zr[pos] = tl_ldz(P.z, zbv + (unsigned)(((s + 2 * RING) % SLOTS) * (2 * TB) * 8));
             } else {
                 gz = zl_n;
             }
-#if GL_TILE_LDS_PREFETCH
-            const double2 rv = rv_n;  // {d_i, pbar_i}: one address per half-wave (broadcast)
-            if (s + 1 < U) {
-                rv_n = s_rows[2 * (s + 1) + half];
-                if (!STREAMS) zl_n = zl[(s + 1) * 64];
-                else if (((s + 1) & 1) == 1) zl_n = zl[((s + 1) / 2) * 64];
+            double2 rv;
+            if (GL_TILE_LDS_PREFETCH && WRAP) {
+                rv = rv_n;  // {d_i, pbar_i}: one address per half-wave (broadcast)
+                if (s + 1 < U) {
+                    rv_n = s_rows[2 * (s + 1) + half];
+                    if (!STREAMS) zl_n = zl[(s + 1) * 64];
+                    else if (((s + 1) & 1) == 1) zl_n = zl[((s + 1) / 2) * 64];
+                }
+            } else {  // (rounds: the registers of the look-ahead are worth more than its 5 %)
+                rv = s_rows[2 * s + half];
+                if (!streamed) gz = zl[(STREAMS ? s / 2 : s) * 64];
             }
-#else
-            const double2 rv = s_rows[2 * s + half];
-            if (!streamed) gz = zl[(STREAMS ? s / 2 : s) * 64];
-#endif
             const double di = rv.x, pi = rv.y;
             const double2 wv = wreg[s];
             double wn[2], pp[2];
@@ -248,10 +258,13 @@ __device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[
             s_row[TB + row] = rw;
         }
     }
-    colp0 = add_xor32(colp0);
-    colp1 = add_xor32(colp1);
-    colw0 = add_xor32(colw0);
-    colw1 = add_xor32(colw1);
+    col[0] = colp0, col[1] = colp1, col[2] = colw0, col[3] = colw1;
+}
+
+// column sums of a wave (each lane: its two columns over the rows of its half) -> the wave's column vectors in LDS
+__device__ __forceinline__ void tl_put_cols(const double (&col)[4], double *s_col, const int lane) {
+    const int half = lane >> 5, c0 = 2 * (lane & 31);
+    const double colp0 = add_xor32(col[0]), colp1 = add_xor32(col[1]), colw0 = add_xor32(col[2]), colw1 = add_xor32(col[3]);
     if (half == 0) {
         s_col[c0] = colp0;
         s_col[c0 + 1] = colp1;
@@ -260,11 +273,115 @@ __device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[
     }
 }
 
+// One STREAMED tile (n > 4096: what the register files do not hold): w and z come from memory through two
+// 4-deep register rings (row pair s + 4 is requested while row pair s is computed; the last four requests of a
+// tile are the first row pairs of the wave's next streamed tile), the new w goes straight back.  Same per-edge
+// arithmetic as the chunk pass; validity (i < j < n: diagonal tiles, ragged last block column) by selects.
+#ifndef GL_TILE_STREAM_RING
+#define GL_TILE_STREAM_RING 4
+#endif
+constexpr int RS = GL_TILE_STREAM_RING;  // 4 or 8
+#ifndef GL_TILE_STAGGER
+#define GL_TILE_STAGGER 1
+#endif
+#ifndef GL_TILE_STREAM_SCHED
+#define GL_TILE_STREAM_SCHED 1
+#endif
+template <bool NORMS, bool MASKED>
+__device__ __forceinline__ void tl_stream_pass(const TileDev &P, double2 (&wq)[RS], double2 (&zq)[RS], const unsigned tb,
+                                               const unsigned nxt, const double2 *s_rows, const double dj0, const double dj1,
+                                               const double pj0, const double pj1, const bool diag, const bool jv0, const bool jv1,
+                                               double *s_row, double (&col)[4], const int lane, double &nqy, double &nw,
+                                               const int g0) {
+    const int half = lane >> 5, c0 = 2 * (lane & 31);
+    const double c = P.c, g = P.gamma, g2 = P.g2;
+    char *wbase = reinterpret_cast<char *>(P.w);
+    const char *zbase = reinterpret_cast<const char *>(P.z);
+    double colp0 = col[0], colp1 = col[1], colw0 = col[2], colw1 = col[3];
+#pragma unroll 1
+    for (int gi = 0; gi < SLOTS / RS; ++gi) {
+        // the waves of the chip start their tiles at different row pairs (g0): tiles are 32 KiB apart, and waves that walk
+        // them in step would all be on the same few memory channels
+        const int gr = (gi + g0) & (SLOTS / RS - 1);
+        // what the ring requests next: the following group of this tile, at the end the first group of the next tile
+        // (`nxt`; the caller passes this tile again when there is none: a harmless re-read keeps the loop free of branches)
+        const unsigned nbase = gi < SLOTS / RS - 1 ? tb + (unsigned)((((gr + 1) & (SLOTS / RS - 1)) * RS) * (2 * TB) * 8)
+                                                   : nxt + (unsigned)((g0 * RS) * (2 * TB) * 8);
+#pragma unroll
+        for (int gh = 0; gh < RS / 4; ++gh) {
+            const int gq = gr * (RS / 4) + gh;
+            double rowp[4], roww[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int s = 4 * gq + k, pos = 4 * gh + k;
+                const double2 wv = wq[pos], zv = zq[pos];
+                const double2 rv = s_rows[2 * s + half];
+                const double di = rv.x, pi = rv.y;
+                double wn[2], pp[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const double w = e ? wv.y : wv.x;
+                    const double y = c * w - g * (di + (e ? dj1 : dj0));   // :147
+                    const double tt = y - g2 * (e ? zv.y : zv.x);          // :150
+                    const double pr = tt > 0 ? tt : 0.0;
+                    const double q = c * pr - g * (pi + (e ? pj1 : pj0));  // :153
+                    double dq = q - y;
+                    wn[e] = (w - y) + q;  // :163
+                    pp[e] = pr;
+                    if (MASKED) {  // (entries outside i < j < n hold w = z = 0: everything above is finite)
+                        const double m = ((e ? jv1 : jv0) && (!diag || 2 * s + half < c0 + e)) ? 1.0 : 0.0;
+                        wn[e] *= m;
+                        pp[e] *= m;
+                        dq *= m;
+                    }
+                    if (NORMS) {
+                        nqy = __builtin_fma(dq, dq, nqy);
+                        nw = __builtin_fma(wn[e], wn[e], nw);
+                    }
+                }
+                *reinterpret_cast<double2 *>(wbase + tb + (unsigned)(s * (2 * TB) * 8)) = double2{wn[0], wn[1]};
+                // the ring's registers are requested again only now that their values have been used (requested earlier, the
+                // compiler copies the whole ring aside and waits for all of it at the top of the loop)
+                asm volatile("" ::: "memory");
+                wq[pos] = *reinterpret_cast<const double2 *>(wbase + nbase + (unsigned)(pos * (2 * TB) * 8));
+                zq[pos] = *reinterpret_cast<const double2 *>(zbase + nbase + (unsigned)(pos * (2 * TB) * 8));
+                colp0 += pp[0];
+                colp1 += pp[1];
+                colw0 += wn[0];
+                colw1 += wn[1];
+                rowp[k] = pp[0] + pp[1];
+                roww[k] = wn[0] + wn[1];
+#if GL_TILE_STREAM_SCHED
+                __builtin_amdgcn_sched_barrier(0);  // one row pair at a time: the registers belong to the resident tile
+#endif
+            }
+            const double rw = halfwave_rows4(roww, lane);
+            const double rp = halfwave_rows4(rowp, lane);
+            if ((lane & 7) == 0) {
+                const int row = 2 * (4 * gq + ((lane >> 3) & 3)) + half;
+                s_row[row] = rp;
+                s_row[TB + row] = rw;
+            }
+        }
+    }
+    col[0] = colp0, col[1] = colp1, col[2] = colw0, col[3] = colw1;
+}
+
 // NORMS: the norms of the stopping rule are formed every iteration (calls with tol > 0, and synchronous calls, which
 // report the ratios of their last iteration); without, the pass is a fifth shorter (asynchronous fixed-iteration calls).
 // One instantiation of the pass per kernel: two of them inside one loop cost 150 registers (measured).
-template <int U, bool RAGGED, bool NORMS>
+//
+// BIG (4096 < n <= ~8700, U = 32): the lattice no longer fits the register files.  A workgroup takes a rectangle of
+// tiles, 8 block columns (one per wave) x up to 5 block rows, and works through it in ROUNDS: in round r wave v
+// handles tile (I0 + r, J0 + v) -- the first one from its registers as before, the others streamed (tl_stream_pass);
+// diagonal tiles are streamed tiles with the validity mask i < j.  A wave's tiles share their block column, so its
+// column sums stay in registers over the rounds; its row vectors are folded after every round (two workgroup
+// barriers) into the accumulators of the waves that publish the records.  Everything else -- records, owners, rule --
+// is unchanged.  Streamed tiles are updated in place: a launch that fails after the rendezvous is an error as before,
+// one whose workgroups never met has still written nothing.
+template <int U, bool RAGGED, bool NORMS, bool BIG = false>
 __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
+    static_assert(!BIG || U == SLOTS, "rounds work on whole tiles");
     constexpr int ZRES = U == SLOTS ? SLOTS / 2 : U;  // LDS-resident row pairs of z per chunk
     constexpr int NS = U - ZRES;                      // streamed ones
     __shared__ double2 s_z[TW][ZRES][64];             // up to 128 KiB
@@ -288,7 +405,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     const int gdw0 = reinterpret_cast<const int *>(P.gd + wg)[lane], gdw1 = reinterpret_cast<const int *>(P.gd + wg)[64 + lane];
     auto gd_int = [&](int idx) { return idx < 64 ? __builtin_amdgcn_readlane(gdw0, idx) : __builtin_amdgcn_readlane(gdw1, idx - 64); };
     constexpr int GD_BLK = 4, GD_ENT = GD_BLK + NBW, GD_ROW = GD_ENT + NBW, GD_COL = GD_ROW + NBW;
-    constexpr int GD_SLICE = GD_COL + NBW, GD_ACTIVE = GD_SLICE + 2;
+    constexpr int GD_SLICE = GD_COL + NBW, GD_ACTIVE = GD_SLICE + 2, GD_NRND = GD_ACTIVE + 1, GD_ROW2 = GD_NRND + 1;
     const int nblk = gd_int(0), own = gd_int(1), own_e0 = gd_int(2), own_e1 = gd_int(3);
     const unsigned long long slice_mask = ((unsigned long long)(unsigned)gd_int(GD_SLICE + 1) << 32) | (unsigned)gd_int(GD_SLICE);
     const bool active = gd_int(GD_ACTIVE) != 0;
@@ -315,7 +432,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             const double2 zv = *reinterpret_cast<const double2 *>(P.z + tb + s * (2 * TB));
             s_z[wave][NS > 0 ? s / 2 : s][lane] = double2{P.g2 * zv.x, P.g2 * zv.y};
         }
-        if (NS > 0) {
+        if (NS > 0 && !BIG) {
 #pragma unroll
             for (int k = 0; k < RING; ++k) zr[k] = tl_ldz(P.z, zb + (unsigned)(2 * k * (2 * TB) * 8));
         }
@@ -325,7 +442,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         s_part[wave][1][lane] = 0.0;
     }
     // fringe group: row pairs fa0 .. fa0 + fcnt - 1 of diagonal tile (fB, fB), w and 2 gamma z in registers
-    const int fcnt = wdv.fcnt, fa0 = wdv.fa0, fB = wdv.fB, fs = wdv.fs, ftgt = wdv.ftgt;
+    const int fcnt = BIG ? 0 : wdv.fcnt, fa0 = wdv.fa0, fB = wdv.fB, fs = wdv.fs, ftgt = wdv.ftgt;
     double2 fw[FRMAX], fgz[FRMAX];
     int64_t ftb = 0;
     if (fcnt > 0) ftb = gl_tile_id(fB, fB, P.nb) * GL_TILE_ELEMS + lofs;
@@ -338,8 +455,36 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             fgz[f] = double2{P.g2 * zv.x, P.g2 * zv.y};
         }
     }
+    // rounds (BIG): my tiles are (I + r, J), r < my_nr; round 0 is the resident one when `has`
+    const int my_nr = BIG ? wdv.nr : 0, my_rs = wdv.rs;
+    const int r_str = has ? 1 : 0;  // my first streamed round
+    int lane_s = lane;  // the lane number as the streamed rounds see it (see below: not loop-invariant for the compiler)
+    auto tile_off = [&](int r) -> unsigned {  // byte offset of this lane's first pair of tile (I + r, J)
+        return (unsigned)((gl_tile_id(wdv.I + r, wdv.J, P.nb) * GL_TILE_ELEMS + (lane_s >> 5) * TB + 2 * (lane_s & 31)) * 8);
+    };
+    const bool jv0 = (int64_t)wdv.J * TB + c0 < P.n, jv1 = (int64_t)wdv.J * TB + c0 + 1 < P.n;
+    // where this wave starts its streamed tiles
+    const int g0 = GL_TILE_STAGGER ? (int)(((unsigned)(wg * TW + wave) * 5u) & (unsigned)(SLOTS / RS - 1)) : 0;
+    auto ring_load = [&](double2 (&wq)[RS], double2 (&zq)[RS], unsigned base) {
+#pragma unroll
+        for (int k = 0; k < RS; ++k) {
+            wq[k] = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(P.w) + base + (unsigned)((g0 * RS + k) * (2 * TB) * 8));
+            zq[k] = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(P.z) + base + (unsigned)((g0 * RS + k) * (2 * TB) * 8));
+        }
+    };
     if (NORMS) {  // sum of squares of the iterate this call starts from
         double acc = 0;
+        if (BIG) {
+#pragma unroll 1
+            for (int r = r_str; r < my_nr; ++r) {
+                const char *b = reinterpret_cast<const char *>(P.w) + tile_off(r);
+#pragma unroll 4
+                for (int s2 = 0; s2 < SLOTS; ++s2) {
+                    const double2 v = *reinterpret_cast<const double2 *>(b + s2 * (2 * TB) * 8);
+                    acc = __builtin_fma(v.y, v.y, __builtin_fma(v.x, v.x, acc));
+                }
+            }
+        }
 #pragma unroll
         for (int s = 0; s < U; ++s) acc = __builtin_fma(wreg[s].y, wreg[s].y, __builtin_fma(wreg[s].x, wreg[s].x, acc));
 #pragma unroll
@@ -451,26 +596,32 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 // from then on every iteration is judged exactly, this one included.  Ratios move by ~1/k per iteration,
                 // so nothing is skipped; a run whose ratios fall by more than 20 % in ONE iteration straight below tol
                 // stops one iteration late (inside the +-1 contract of SURVEY.md section 7).
-                const bool mine = lane < P.nb;
                 auto norms_of = [&](int j, double (&b)[4]) -> bool {  // sums of the records of local iteration j
                     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                     unsigned spins = 0;
                     const unsigned tag = P.tag0 + (unsigned)j + 1u;
-                    tl_u4 r[4];
-                    for (;;) {
-                        bool ok = true;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            r[q] = tl_u4{0u, tag, 0u, tag};
-                            if (mine) r[q] = __builtin_amdgcn_raw_buffer_load_b128(r_bn, (((j & 3) * (int)P.nb + lane) * 4 + q) * 16, 0, 16);
-                            ok = ok && tl_ok(r[q], tag);
+                    for (int q = 0; q < 4; ++q) b[q] = 0.0;
+#pragma unroll 1
+                    for (int b0 = 0; b0 < (BIG ? (int)P.nb : 1); b0 += 64) {  // (nb <= 64 unless BIG)
+                        const bool mine = b0 + lane < P.nb;
+                        tl_u4 r[4];
+                        for (;;) {
+                            bool ok = true;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                r[q] = tl_u4{0u, tag, 0u, tag};
+                                if (mine)
+                                    r[q] = __builtin_amdgcn_raw_buffer_load_b128(r_bn, (((j & 3) * (int)P.nb + b0 + lane) * 4 + q) * 16, 0, 16);
+                                ok = ok && tl_ok(r[q], tag);
+                            }
+                            asm volatile("" ::: "memory");
+                            if (__all(ok)) break;
+                            if (!tl_spin(spins, t0, err)) return false;
                         }
-                        asm volatile("" ::: "memory");
-                        if (__all(ok)) break;
-                        if (!tl_spin(spins, t0, err)) return false;
-                    }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) b[q] = wave_sum(mine ? tl_val(r[q]) : 0.0);
+                        for (int q = 0; q < 4; ++q) b[q] += wave_sum(mine ? tl_val(r[q]) : 0.0);
+                    }
                     return true;
                 };
                 double b[4] = {0, 0, 0, 0};
@@ -526,10 +677,80 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         // ================= edge phase =================
         if (stamp) ts[1] = __builtin_amdgcn_s_memrealtime();
         double nqy = 0, nw = 0;
-        if (has) {
-            const double2 cv0 = s_node[wdv.sj][c0], cv1 = s_node[wdv.sj][c0 + 1];
-            tl_chunk_pass<U, RAGGED, NORMS>(P, wreg, zr, &s_z[wave][0][lane], zb, &s_node[wdv.si][2 * a0], cv0.x, cv1.x, cv0.y, cv1.y,
-                                            m0, m1, &s_part[wave][0][2 * a0], &s_part[wave][2][0], lane, wave >= TW / 2, nqy, nw);
+        double accp[NACQ], accw[NACQ];  // BIG: what the rounds before the last one add to the records I publish
+#pragma unroll
+        for (int j = 0; j < NACQ; ++j) accp[j] = accw[j] = 0.0;
+        if (!BIG) {
+            if (has) {
+                const double2 cv0 = s_node[wdv.sj][c0], cv1 = s_node[wdv.sj][c0 + 1];
+                double col[4] = {0.0, 0.0, 0.0, 0.0};
+                tl_chunk_pass<U, RAGGED, NORMS>(P, wreg, zr, &s_z[wave][0][lane], zb, &s_node[wdv.si][2 * a0], cv0.x, cv1.x, cv0.y,
+                                                cv1.y, m0, m1, &s_part[wave][0][2 * a0], col, lane, wave >= TW / 2, nqy, nw);
+                tl_put_cols(col, &s_part[wave][2][0], lane);
+            }
+        } else {
+            // Round 0 stands apart from the loop over the later rounds so that the rings of the streamed pass are not live
+            // while the resident pass runs (its 256 registers are spoken for).
+            const int nrw = gd_int(GD_NRND);
+            double col[4] = {0.0, 0.0, 0.0, 0.0};
+            double2 cv0 = double2{0.0, 0.0}, cv1 = cv0;
+            if (my_nr > 0) cv0 = s_node[wdv.sj][c0], cv1 = s_node[wdv.sj][c0 + 1];
+            auto fold = [&](int r) {  // row vectors of round r -> the records I publish
+#pragma unroll
+                for (int j = 0; j < NACQ; ++j) {
+                    const int k = wave + TW * j;
+                    if (k < nblk) {
+                        const int rm = ((r < 4 ? gd_int(GD_ROW + k) : gd_int(GD_ROW2 + k)) >> (8 * (r & 3))) & 255;
+#pragma unroll
+                        for (int cs = 0; cs < TW; ++cs)
+                            if ((rm >> cs) & 1) {
+                                accp[j] += s_part[cs][0][lane];
+                                accw[j] += s_part[cs][1][lane];
+                            }
+                    }
+                }
+            };
+            if (my_nr > 0) {
+                const double2 *rows = &s_node[my_rs & 15][0];
+                if (has) {
+#pragma unroll
+                    for (int k = 0; k < RING; ++k) zr[k] = tl_ldz(P.z, zb + (unsigned)(2 * k * (2 * TB) * 8));
+                    tl_chunk_pass<U, RAGGED, NORMS, false>(P, wreg, zr, &s_z[wave][0][lane], zb, rows, cv0.x, cv1.x, cv0.y, cv1.y, m0, m1,
+                                                           &s_part[wave][0][0], col, lane, wave >= TW / 2, nqy, nw);
+                } else {  // (a column whose first tile here is its diagonal tile)
+                    asm volatile("" : "+v"(lane_s));  // (as below)
+                    double2 wq[RS], zq[RS];
+                    ring_load(wq, zq, tile_off(0));
+                    tl_stream_pass<NORMS, true>(P, wq, zq, tile_off(0), tile_off(0), rows, cv0.x, cv1.x, cv0.y, cv1.y, wdv.I == wdv.J, jv0, jv1,
+                                                &s_part[wave][0][0], col, lane_s, nqy, nw, g0);
+                }
+            }
+            if (nrw > 1) {
+                __syncthreads();
+                fold(0);
+                __syncthreads();
+                // what the streamed rounds derive from the lane number (offsets, masks) is recomputed here every iteration:
+                // hoisted out of the iteration loop it would live through the resident pass, which has no register to spare
+                asm volatile("" : "+v"(lane_s));
+                double2 wq[RS], zq[RS];
+#pragma unroll
+                for (int k = 0; k < RS; ++k) wq[k] = zq[k] = double2{0.0, 0.0};
+                if (my_nr > 1) ring_load(wq, zq, tile_off(1));
+#pragma unroll 1
+                for (int r = 1; r < nrw; ++r) {
+                    if (r < my_nr) {
+                        const unsigned tb = tile_off(r), nxt = r + 1 < my_nr ? tile_off(r + 1) : tb;
+                        const double2 *rows = &s_node[(my_rs >> (4 * r)) & 15][0];
+                        tl_stream_pass<NORMS, true>(P, wq, zq, tb, nxt, rows, cv0.x, cv1.x, cv0.y, cv1.y, wdv.I + r == wdv.J, jv0, jv1,
+                                                    &s_part[wave][0][0], col, lane_s, nqy, nw, g0);
+                    }
+                    if (r == nrw - 1) break;  // (the barrier and the last fold are those of the publish phase below)
+                    __syncthreads();
+                    fold(r);
+                    __syncthreads();
+                }
+            }
+            if (my_nr > 0) tl_put_cols(col, &s_part[wave][2][0], lane);
         }
         if (fcnt > 0) {  // my fringe row pairs (diagonal tile: entries i < j < n only)
             const double c = P.c, g = P.gamma;
@@ -619,10 +840,17 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         __syncthreads();
 
         // ================= publish: one record per node block I touch =================
-#pragma unroll 1
-        for (int k = wave; k < nblk; k += TW) {
-            double sp = 0, sw = 0;
-            const int rm = gd_int(GD_ROW + k), cm = gd_int(GD_COL + k);
+#pragma unroll
+        for (int j = 0; j < NACQ; ++j) {
+            const int k = wave + TW * j;
+            if (k >= nblk) break;
+            double sp = accp[j], sw = accw[j];
+            int rm = gd_int(GD_ROW + k);
+            const int cm = gd_int(GD_COL + k);
+            if (BIG) {  // the row vectors of the last round
+                const int r = gd_int(GD_NRND) - 1;
+                rm = ((r < 4 ? rm : gd_int(GD_ROW2 + k)) >> (8 * (r & 3))) & 255;
+            }
 #pragma unroll
             for (int cs = 0; cs < TW; ++cs) {
                 if ((rm >> cs) & 1) {
@@ -815,6 +1043,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
 struct gl_tile {
     TileDev dev{};
     int U = SLOTS;              // row pairs per chunk: 32, 16 or 8
+    bool big = false;           // rounds (n > 4096)
     void *arena = nullptr;      // descriptors, record buffers, rendezvous words: one allocation
     size_t gran_off = 0, gran_bytes = 0;  // the record buffers inside it
     unsigned long long *dbg = nullptr;
@@ -830,6 +1059,185 @@ void gl_tile_free(gl_logdeg *s) {
     s->tile = nullptr;
 }
 
+// slices, record entries, device arena: common to both decompositions
+static int tile_finish(gl_logdeg *s, std::vector<WaveDesc> &wd, std::vector<WgDesc> &gd, const int NWG, const int U, const bool big) {
+    gl_ctx *ctx = s->ctx;
+    const LogdegDev &D = s->dev;
+    const int nb = (int)D.nb;
+    const int F = nb * (nb - 1) / 2;
+    std::vector<std::vector<int>> touch((size_t)nb);  // block -> workgroups (ascending)
+    for (int g = 0; g < NWG; ++g)
+        for (int k = 0; k < gd[(size_t)g].nblk; ++k) touch[(size_t)gd[(size_t)g].blk[k]].push_back(g);
+    for (int B = 0; B < nb; ++B)
+        for (int r = 0; B + r * nb < NWG; ++r)
+            if (gd[(size_t)(B + r * nb)].active) (r < 32 ? gd[(size_t)B].slice_lo : gd[(size_t)B].slice_hi) |= 1u << (r & 31);
+    int n_entries = 0;
+    for (int B = 0; B < nb; ++B) {
+        gd[(size_t)B].own_e0 = n_entries;
+        for (int g : touch[(size_t)B]) {
+            WgDesc &G = gd[(size_t)g];
+            for (int k = 0; k < G.nblk; ++k)
+                if (G.blk[k] == B) G.ent[k] = n_entries;
+            ++n_entries;
+        }
+        gd[(size_t)B].own_e1 = n_entries;
+        if (touch[(size_t)B].empty()) return gl_set_error(ctx, GL_E_STATE, "internal: node block %d has no producer", B);
+    }
+
+    gl_tile *t = new (std::nothrow) gl_tile();
+    if (!t) return GL_E_NOMEM;
+    auto up256 = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b_wd = up256(wd.size() * sizeof(WaveDesc)), b_gd = up256(gd.size() * sizeof(WgDesc));
+    const size_t b_part = up256((size_t)n_entries * 2 * TB * 16), b_nval = up256((size_t)nb * 2 * TB * 16);
+    const size_t b_wn = up256((size_t)4 * NWG * 2 * 16), b_bn = up256((size_t)4 * nb * 4 * 16);
+    const size_t b_bar = up256((size_t)GL_BAR_WORDS * 4);
+    const size_t total = b_wd + b_gd + b_part + b_nval + b_wn + b_bn + b_bar;
+    if (hipMalloc(&t->arena, total) != hipSuccess) {
+        delete t;
+        return gl_set_error(ctx, GL_E_NOMEM, "tile engine: hipMalloc(%zu) failed", total);
+    }
+    char *at = (char *)t->arena;
+    TileDev &P = t->dev;
+    P.wd = (const WaveDesc *)at, at += b_wd;
+    P.gd = (const WgDesc *)at, at += b_gd;
+    t->gran_off = (size_t)(at - (char *)t->arena);
+    P.part = (tl_u4 *)at, at += b_part;
+    P.nval = (tl_u4 *)at, at += b_nval;
+    P.wnorm = (tl_u4 *)at, at += b_wn;
+    P.bnrm = (tl_u4 *)at, at += b_bn;
+    t->gran_bytes = (size_t)(at - (char *)t->arena) - t->gran_off;
+    P.bar = (unsigned *)at;
+    hipError_t e = hipMemsetAsync(t->arena, 0, total, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync((void *)P.wd, wd.data(), wd.size() * sizeof(WaveDesc), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync((void *)P.gd, gd.data(), gd.size() * sizeof(WgDesc), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // wd / gd are locals
+    if (e != hipSuccess) {
+        (void)hipFree(t->arena);
+        delete t;
+        return gl_set_error(ctx, GL_E_HIP, "tile engine set-up: %s", hipGetErrorString(e));
+    }
+    P.z = D.z;
+    P.dvar = D.dvar;
+    P.ybar = D.ybar;
+    P.pbar = D.pbar;
+    P.dprev = D.dprev;
+    P.bnorm = D.bnorm;
+    P.dstat = D.dstat;
+    P.ctr = D.ctr;
+    P.n = D.n;
+    P.nb = D.nb;
+    P.NWG = NWG;
+    P.n_entries = n_entries;
+    t->U = U;
+    t->big = big;
+    P.dbg = nullptr;
+    if (getenv("GRAPHLEARN_AMD_RES_STAMPS") && hipMalloc((void **)&t->dbg, (size_t)NWG * 16 * (6 + 2 * TW) * 8) == hipSuccess) {
+        (void)hipMemset(t->dbg, 0, (size_t)NWG * 16 * (6 + 2 * TW) * 8);
+        P.dbg = t->dbg;
+        int maxblk = 0;
+        for (const WgDesc &G : gd) maxblk = std::max(maxblk, G.nblk);
+        fprintf(stderr, "[tile] n %lld nb %d F %d U %d NWG %d records %d (%.1f per block) max blocks per workgroup %d\n", (long long)D.n, nb,
+                F, U, NWG, n_entries, (double)n_entries / nb, maxblk);
+    }
+    s->tile = t;
+    return GL_OK;
+}
+
+// n > 4096: rectangles of 8 block columns x R block rows, one per workgroup, worked through in rounds (k_tile, BIG).
+// Column strip t holds block columns 8 t .. 8 t + 7 and the block rows 0 .. its last column; it is cut into groups of
+// R rows, R the smallest number of rounds with which the chip's workgroups cover the lattice (R + 8 <= NBW node
+// blocks per workgroup).  Wave v of a workgroup takes column J = 8 t + v: tiles (I, J), I = I0 .. min(I0 + R - 1, J).
+static int tile_prepare_rounds(gl_logdeg *s) {
+    gl_ctx *ctx = s->ctx;
+    const LogdegDev &D = s->dev;
+    const int ncu = ctx->prop.multiProcessorCount, nb = (int)D.nb;
+    if ((int64_t)gl_num_tiles(D.n) * GL_TILE_ELEMS * 8 >= (int64_t)1 << 32) return GL_OK;  // (32-bit byte offsets in the streamed pass)
+    // strips: a narrow first one (nb mod 8 columns, at the short end of the lattice), then 8 columns each
+    std::vector<int> sc0, sc1;
+    for (int c = 0; c < nb;) {
+        const int wdt = (c == 0 && nb % TW != 0) ? nb % TW : TW;
+        sc0.push_back(c), sc1.push_back(c + wdt);
+        c += wdt;
+    }
+    const int nstrips = (int)sc0.size();
+    int R = 0, NWG = 0;
+    for (int r = 1; r <= NBW - TW && r <= 8; ++r) {
+        int cnt = 0;
+        for (int t = 0; t < nstrips; ++t) cnt += (sc1[(size_t)t] + r - 1) / r;
+        if (cnt <= ncu) {
+            R = r, NWG = cnt;
+            break;
+        }
+    }
+    if (R == 0) return GL_OK;  // too large for one rectangle per workgroup: the streaming engine serves it
+    // groups per strip; the workgroups left over go, one at a time, to the strip with the most rows per group (more
+    // tiles in registers, fewer streamed)
+    std::vector<int> grp((size_t)nstrips);
+    for (int t = 0; t < nstrips; ++t) grp[(size_t)t] = (sc1[(size_t)t] + R - 1) / R;
+    if (!getenv("GRAPHLEARN_AMD_TILE_NO_SPREAD"))
+        for (; NWG < ncu; ++NWG) {
+            int best = -1;
+            double most = 1.0;
+            for (int t = 0; t < nstrips; ++t) {
+                const double per = (double)sc1[(size_t)t] / grp[(size_t)t] * (sc1[(size_t)t] - sc0[(size_t)t]) / TW;
+                if (grp[(size_t)t] < sc1[(size_t)t] && per > most) most = per, best = t;
+            }
+            if (best < 0) break;
+            ++grp[(size_t)best];
+        }
+    NWG = std::max(NWG, nb);  // every node block needs an owner
+    if (NWG > ncu || NWG > 64 * nb) return GL_OK;
+    std::vector<WaveDesc> wd((size_t)NWG * TW);
+    std::vector<WgDesc> gd((size_t)NWG);
+    for (WaveDesc &w : wd) {
+        memset(&w, 0, sizeof w);
+        w.tile = -1;
+        w.fB = -1;
+    }
+    for (WgDesc &G : gd) memset(&G, 0, sizeof G);
+    int g = 0;
+    for (int t = 0; t < nstrips; ++t) {
+        const int h = sc1[(size_t)t], ng = grp[(size_t)t];
+        for (int q = 0; q < ng; ++q, ++g) {
+            const int I0 = (int)((int64_t)q * h / ng), I1 = (int)((int64_t)(q + 1) * h / ng);  // block rows [I0, I1)
+            WgDesc &G = gd[(size_t)g];
+            auto slot_of = [&](int B) -> int {
+                for (int k = 0; k < G.nblk; ++k)
+                    if (G.blk[k] == B) return k;
+                if (G.nblk >= NBW) return -1;
+                G.blk[G.nblk] = B;
+                return G.nblk++;
+            };
+            for (int v = 0; v < TW; ++v) {
+                const int J = sc0[(size_t)t] + v;
+                if (J >= sc1[(size_t)t] || J < I0) continue;  // (below the diagonal: nothing)
+                WaveDesc &w = wd[(size_t)(g * TW + v)];
+                w.I = I0;
+                w.J = J;
+                w.nr = std::min(I1 - I0, J - I0 + 1);
+                if (w.nr > 8) return GL_OK;
+                if (I0 < J) w.tile = (int)gl_tile_id(I0, J, nb);  // round 0 from the registers
+                w.sj = slot_of(J);
+                if (w.sj < 0) return GL_OK;
+                G.colmask[w.sj] |= 1 << v;
+                for (int r = 0; r < w.nr; ++r) {
+                    const int sl = slot_of(I0 + r);
+                    if (sl < 0) return GL_OK;
+                    if (r == 0) w.si = sl;
+                    w.rs |= sl << (4 * r);
+                    (r < 4 ? G.rowmask[sl] : G.rowmask2[sl]) |= (int)(1u << (8 * (r & 3) + v));
+                    G.nrnd = std::max(G.nrnd, r + 1);
+                }
+            }
+        }
+    }
+    for (int q = 0; q < NWG; ++q) {
+        gd[(size_t)q].own = q < nb ? q : -1;
+        gd[(size_t)q].active = (gd[(size_t)q].nblk > 0 || gd[(size_t)q].own >= 0) ? 1 : 0;
+    }
+    return tile_finish(s, wd, gd, NWG, SLOTS, true);
+}
+
 // Builds the static work decomposition.  GL_OK with s->tile == nullptr when the engine does not apply.
 int gl_tile_prepare(gl_logdeg *s) {
     gl_ctx *ctx = s->ctx;
@@ -842,9 +1250,8 @@ int gl_tile_prepare(gl_logdeg *s) {
     const LogdegDev &D = s->dev;
     const int ncu = ctx->prop.multiProcessorCount;
     const int nb = (int)D.nb;
-    if (nb > 64) return GL_OK;  // one norm record per lane in the rule's poll; larger lattices do not fit the register files anyway
     const int F = nb * (nb - 1) / 2;  // bulk (off-diagonal) tiles
-    if (F > TW * ncu) return GL_OK;   // does not fit the register files
+    if (nb > 64 || F > TW * ncu) return tile_prepare_rounds(s);  // does not fit the register files
     if (!forced && F < GL_TILE_MIN_BULK_TILES) return GL_OK;  // (n <= 128 belongs to the small engine)
     // chunk length: the finest split that still fits one chunk per wave of the chip (shorter edge phase)
     int U = F * 4 <= TW * ncu ? 8 : (F * 2 <= TW * ncu ? 16 : 32);
@@ -928,7 +1335,6 @@ int gl_tile_prepare(gl_logdeg *s) {
     }
     // block lists, records, masks
     std::vector<WgDesc> gd((size_t)NWG);
-    std::vector<std::vector<int>> touch((size_t)nb);  // block -> workgroups (ascending)
     for (int g = 0; g < NWG; ++g) {
         WgDesc &G = gd[(size_t)g];
         memset(&G, 0, sizeof G);
@@ -955,81 +1361,9 @@ int gl_tile_prepare(gl_logdeg *s) {
                 if (w.tile < 0) G.rowmask[w.fs] |= 1 << v;  // a wave without a chunk: its row vectors carry the group alone
             }
         }
-        for (int k = 0; k < G.nblk; ++k) touch[(size_t)G.blk[k]].push_back(g);
         G.active = (G.nblk > 0 || G.own >= 0) ? 1 : 0;
     }
-    for (int B = 0; B < nb; ++B)
-        for (int r = 0; B + r * nb < NWG; ++r)
-            if (gd[(size_t)(B + r * nb)].active) (r < 32 ? gd[(size_t)B].slice_lo : gd[(size_t)B].slice_hi) |= 1u << (r & 31);
-    int n_entries = 0;
-    for (int B = 0; B < nb; ++B) {
-        gd[(size_t)B].own_e0 = n_entries;
-        for (int g : touch[(size_t)B]) {
-            WgDesc &G = gd[(size_t)g];
-            for (int k = 0; k < G.nblk; ++k)
-                if (G.blk[k] == B) G.ent[k] = n_entries;
-            ++n_entries;
-        }
-        gd[(size_t)B].own_e1 = n_entries;
-        if (touch[(size_t)B].empty()) return gl_set_error(ctx, GL_E_STATE, "internal: node block %d has no producer", B);
-    }
-
-    gl_tile *t = new (std::nothrow) gl_tile();
-    if (!t) return GL_E_NOMEM;
-    auto up256 = [](size_t b) { return (b + 255) / 256 * 256; };
-    const size_t b_wd = up256(wd.size() * sizeof(WaveDesc)), b_gd = up256(gd.size() * sizeof(WgDesc));
-    const size_t b_part = up256((size_t)n_entries * 2 * TB * 16), b_nval = up256((size_t)nb * 2 * TB * 16);
-    const size_t b_wn = up256((size_t)4 * NWG * 2 * 16), b_bn = up256((size_t)4 * nb * 4 * 16);
-    const size_t b_bar = up256((size_t)GL_BAR_WORDS * 4);
-    const size_t total = b_wd + b_gd + b_part + b_nval + b_wn + b_bn + b_bar;
-    if (hipMalloc(&t->arena, total) != hipSuccess) {
-        delete t;
-        return gl_set_error(ctx, GL_E_NOMEM, "tile engine: hipMalloc(%zu) failed", total);
-    }
-    char *at = (char *)t->arena;
-    TileDev &P = t->dev;
-    P.wd = (const WaveDesc *)at, at += b_wd;
-    P.gd = (const WgDesc *)at, at += b_gd;
-    t->gran_off = (size_t)(at - (char *)t->arena);
-    P.part = (tl_u4 *)at, at += b_part;
-    P.nval = (tl_u4 *)at, at += b_nval;
-    P.wnorm = (tl_u4 *)at, at += b_wn;
-    P.bnrm = (tl_u4 *)at, at += b_bn;
-    t->gran_bytes = (size_t)(at - (char *)t->arena) - t->gran_off;
-    P.bar = (unsigned *)at;
-    hipError_t e = hipMemsetAsync(t->arena, 0, total, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync((void *)P.wd, wd.data(), wd.size() * sizeof(WaveDesc), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync((void *)P.gd, gd.data(), gd.size() * sizeof(WgDesc), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // wd / gd are locals
-    if (e != hipSuccess) {
-        (void)hipFree(t->arena);
-        delete t;
-        return gl_set_error(ctx, GL_E_HIP, "tile engine set-up: %s", hipGetErrorString(e));
-    }
-    P.z = D.z;
-    P.dvar = D.dvar;
-    P.ybar = D.ybar;
-    P.pbar = D.pbar;
-    P.dprev = D.dprev;
-    P.bnorm = D.bnorm;
-    P.dstat = D.dstat;
-    P.ctr = D.ctr;
-    P.n = D.n;
-    P.nb = D.nb;
-    P.NWG = NWG;
-    P.n_entries = n_entries;
-    t->U = U;
-    P.dbg = nullptr;
-    if (getenv("GRAPHLEARN_AMD_RES_STAMPS") && hipMalloc((void **)&t->dbg, (size_t)NWG * 16 * (6 + 2 * TW) * 8) == hipSuccess) {
-        (void)hipMemset(t->dbg, 0, (size_t)NWG * 16 * (6 + 2 * TW) * 8);
-        P.dbg = t->dbg;
-        int maxblk = 0;
-        for (const WgDesc &G : gd) maxblk = std::max(maxblk, G.nblk);
-        fprintf(stderr, "[tile] n %lld nb %d F %d U %d NWG %d records %d (%.1f per block) max blocks per workgroup %d\n", (long long)D.n, nb,
-                F, U, NWG, n_entries, (double)n_entries / nb, maxblk);
-    }
-    s->tile = t;
-    return GL_OK;
+    return tile_finish(s, wd, gd, NWG, U, false);
 }
 
 // Runs up to `iters` iterations in ONE launch (asynchronous).  The iterate stays in w[it0 & 1]; the caller fixes
@@ -1064,20 +1398,22 @@ int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms) {
     const bool ragged = D.n % TB != 0;
     const dim3 grid((unsigned)P.NWG), block(TT);
     auto go = [&](auto kern) { kern<<<grid, block, 0, ctx->stream>>>(P); };
-#define GL_TILE_GO(UU)                                                                       \
-    do {                                                                                     \
-        if (ragged) {                                                                        \
-            if (norms) go(k_tile<UU, true, true>); else go(k_tile<UU, true, false>);         \
-        } else {                                                                             \
-            if (norms) go(k_tile<UU, false, true>); else go(k_tile<UU, false, false>);       \
-        }                                                                                    \
+#define GL_TILE_GO(UU, BB)                                                                       \
+    do {                                                                                         \
+        if (ragged) {                                                                            \
+            if (norms) go(k_tile<UU, true, true, BB>); else go(k_tile<UU, true, false, BB>);     \
+        } else {                                                                                 \
+            if (norms) go(k_tile<UU, false, true, BB>); else go(k_tile<UU, false, false, BB>);   \
+        }                                                                                        \
     } while (0)
-    if (t->U == 32)
-        GL_TILE_GO(32);
+    if (t->big)
+        GL_TILE_GO(32, true);
+    else if (t->U == 32)
+        GL_TILE_GO(32, false);
     else if (t->U == 16)
-        GL_TILE_GO(16);
+        GL_TILE_GO(16, false);
     else
-        GL_TILE_GO(8);
+        GL_TILE_GO(8, false);
 #undef GL_TILE_GO
     GL_HIP(ctx, hipGetLastError());
     return GL_OK;
