@@ -364,19 +364,24 @@ def test_set_distances_after_deferred_theta_resets_theta():
         assert s.theta() == 1.0
 
 
-def test_just_past_the_register_files_n4160_against_oracle(engine):
-    """n = 4160 (65 node blocks, 2080 bulk tiles): one block past what the tile engine's register files hold, so
-    every engine choice ends on the streaming engine; 18 iterations in one call against the oracle."""
+@pytest.mark.parametrize("n", [4160, 4203])
+def test_just_past_the_register_files_against_oracle(engine, n):
+    """n = 4160 (65 node blocks, 2080 bulk tiles) and the ragged n = 4203: one block past what the register files
+    hold.  The tile engine works through such lattices in rounds (one tile per wave from registers, the others
+    streamed, diagonal tiles and the ragged last block column under a validity mask); the streaming engine is
+    forced once.  18 iterations in one call against the oracle."""
     if engine not in ("stream", "resident"):
-        pytest.skip("once forced to the streaming engine, once through the automatic fallback of the resident family")
-    n = 4160
+        pytest.skip("once forced to the streaming engine, once on the tile engine")
     rng = np.random.default_rng(n)
     e = n * (n - 1) // 2
     z = rng.uniform(0.05, 3.0, size=e)
     with _lib.LogDegreeSession(n) as s:
         s.set_distances(z)
         s.init(1.1, 0.9, 0.5, None)
-        assert s.engine == "stream" and s.engine_kernel == "k_edge"
+        if engine == "stream":
+            assert s.engine == "stream" and s.engine_kernel == "k_edge"
+        else:
+            assert s.engine == "resident" and s.engine_kernel == "k_tile"
         n_it, conv, rel = s.iterate(18, 0.0)
         w, d = s.weights_condensed(), s.dual()
     _, info = old.learn_log_degrees(z, 1.1, 0.9, maxit=18, tol=0.0, edge_tol=-np.inf, return_info=True)
@@ -385,12 +390,37 @@ def test_just_past_the_register_files_n4160_against_oracle(engine):
     assert rel[0] == pytest.approx(info["rel"][0], rel=1e-9) and rel[1] == pytest.approx(info["rel"][1], rel=1e-9)
 
 
+def test_rounds_of_the_tile_engine_in_converge_mode_against_the_streaming_engine(engine, monkeypatch):
+    """n = 5000 (ragged, 3 rounds): run to tol on the tile engine and on the streaming engine (itself checked against
+    the oracle above): same stopping iteration, same ratios, same iterate; and a second call continues the first."""
+    if engine != "resident":
+        pytest.skip("compares the two engines itself")
+    n = 5000
+    z = np.random.default_rng(n).uniform(0.05, 3.0, size=n * (n - 1) // 2)
+    out = {}
+    for eng in ("stream", "resident"):
+        monkeypatch.setenv("GRAPHLEARN_AMD_ENGINE", eng)
+        with _lib.LogDegreeSession(n) as s:
+            s.set_distances(z)
+            s.init(1.0, 1.0, 0.5, None)
+            assert s.engine_kernel == ("k_edge" if eng == "stream" else "k_tile")
+            first = s.iterate(40, 0.0)
+            rest = s.iterate(100000, 1e-3)
+            out[eng] = (first, rest, s.weights_condensed(), s.dual())
+    a, b = out["stream"], out["resident"]
+    assert a[0][0] == b[0][0] == 40 and a[1][0] == b[1][0] and a[1][1] and b[1][1]
+    assert b[1][2][0] == pytest.approx(a[1][2][0], rel=1e-9) and b[1][2][1] == pytest.approx(a[1][2][1], rel=1e-9)
+    np.testing.assert_allclose(b[2], a[2], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(b[3], a[3], rtol=0, atol=1e-12)
+
+
 def test_large_lattice_n8192_against_dense_restatement(engine):
-    """n = 8192 (beyond the Infinity Cache: 3 x 268 MB): three iterations of the streaming engine against a dense
-    NumPy restatement of :146-167 (S w = row sums of the symmetric matrix, S'd = d_i + d_j), which needs no sparse
-    operator at this size."""
-    if engine != "stream":
-        pytest.skip("the streaming engine is the only one at this size")
+    """n = 8192 (beyond the Infinity Cache: 3 x 268 MB): the streaming engine (3 iterations) and the tile engine (5 rounds
+    per iteration; 16 iterations, its shortest call) against a dense NumPy restatement of :146-167 (S w = row sums of
+    the symmetric matrix, S'd = d_i + d_j), which needs no sparse operator at this size."""
+    if engine not in ("stream", "resident"):
+        pytest.skip("once on the streaming engine, once on the tile engine")
+    iters = 3 if engine == "stream" else 16
     n = 8192
     rng = np.random.default_rng(5)
     iu = np.triu_indices(n, 1)
@@ -402,7 +432,7 @@ def test_large_lattice_n8192_against_dense_restatement(engine):
     wm = np.zeros((n, n))
     d = np.zeros(n)
     off = ~np.eye(n, dtype=bool)
-    for _ in range(3):
+    for _ in range(iters):
         y = (1 - 2 * g * beta) * wm - g * (d[:, None] + d[None, :])
         yb = d + g * wm.sum(1)
         p = np.where(y - 2 * g * zsq > 0, y - 2 * g * zsq, 0) * off
@@ -414,7 +444,8 @@ def test_large_lattice_n8192_against_dense_restatement(engine):
     with _lib.LogDegreeSession(n) as s:
         s.set_distances(np.ascontiguousarray(zsq[iu]))
         s.init(alpha, beta, step, None)
-        s.iterate(3, 0.0)
+        assert s.engine_kernel == ("k_edge" if engine == "stream" else "k_tile")
+        s.iterate(iters, 0.0)
         w, dd = s.weights_condensed(), s.dual()
     np.testing.assert_allclose(w, wm[iu], rtol=0, atol=1e-12)
     np.testing.assert_allclose(dd, d, rtol=0, atol=1e-11)
