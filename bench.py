@@ -73,7 +73,9 @@ def other_configs(ctx):
                block-coordinate descent (lgmrf.py:175-219), timed through the C ABI as the difference of two fits capped
                by GRAPHLEARN_AMD_LGMRF_MAX_NODES; every QP runs its 100 ADMM steps on this input.
     graphdict  BASELINE configs[4]: GraphDictLog K=8, n=1024, T=4096: ms per primal-dual step, fp64 (what the reference
-               computes) and fp32 contractions (what the config names)."""
+               computes) and fp32 contractions (what the config names).
+    logmodel_n8192  the headline loop on a lattice four times as large (SURVEY section 8 row d quotes the roofline for
+               n >= 4096): time per iteration and its fraction of 24 E bytes / 8 TB/s."""
     import numpy as np
     from graph_learning_amd import _lib
     out = {}
@@ -130,6 +132,24 @@ def other_configs(ctx):
     except Exception as exc:
         out["lgmrf_error"] = repr(exc)
         os.environ.pop("GRAPHLEARN_AMD_LGMRF_MAX_NODES", None)
+    try:  # a lattice four times the headline's: what does not fit the register files streams (rounds)
+        n = 8192
+        e = n * (n - 1) // 2
+        z = np.random.default_rng(3).uniform(0.05, 3.0, size=e)
+        with _lib.LogDegreeSession(n, ctx) as s:
+            s.set_distances(z)
+            s.init(1.0, 1.0, 0.5, None)
+            kern = s.engine_kernel
+            s.iterate_async(16)
+            ctx.sync()
+            ctx.timer_start()
+            s.iterate_async(200)
+            us = ctx.timer_stop() * 1e3 / 200
+        out["logmodel_n8192"] = {"workload": "LogModel loop n=8192 (E = 33.5 M edges), one 200-iteration call", "engine_kernel": kern,
+                                 "us_per_iteration": us, "iterations_per_s": 1e6 / us, "dtype": "f64",
+                                 "frac_of_24E_over_hbm_peak": 24.0 * e / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    except Exception as exc:
+        out["logmodel_n8192_error"] = repr(exc)
     return out
 
 
