@@ -394,6 +394,8 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     __shared__ double s_ns[2];
     __shared__ int s_flag[4];                         // {rendezvous ok, failed, stop, -}
     __shared__ double s_rel[2];
+    __shared__ double s_lag[2];                       // the rule's early look: ratios of the iteration before the last one
+    __shared__ int s_lagok;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wg = blockIdx.x;
@@ -533,6 +535,35 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     const bool rule_on = P.tol > 0;
     bool evaluated = false, exact = false;
 
+    // (wave TW - 1) one norm record per node block, lane = block
+    auto norms_of = [&](int j, double (&b)[4]) -> bool {  // sums of the records of local iteration j
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned spins = 0;
+        const unsigned tag = P.tag0 + (unsigned)j + 1u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q] = 0.0;
+#pragma unroll 1
+        for (int b0 = 0; b0 < (BIG ? (int)P.nb : 1); b0 += 64) {  // (nb <= 64 unless BIG)
+            const bool mine = b0 + lane < P.nb;
+            tl_u4 r[4];
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    r[q] = tl_u4{0u, tag, 0u, tag};
+                    if (mine)
+                        r[q] = __builtin_amdgcn_raw_buffer_load_b128(r_bn, (((j & 3) * (int)P.nb + b0 + lane) * 4 + q) * 16, 0, 16);
+                    ok = ok && tl_ok(r[q], tag);
+                }
+                asm volatile("" ::: "memory");
+                if (__all(ok)) break;
+                if (!tl_spin(spins, t0, err)) return false;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b[q] += wave_sum(mine ? tl_val(r[q]) : 0.0);
+        }
+        return true;
+    };
     for (int it = 0; met && it <= P.maxit; ++it) {
         const unsigned tag_in = P.tag0 + (unsigned)it;        // node values that are the input of iteration `it`
         const unsigned tag_out = P.tag0 + (unsigned)it + 1u;  // what iteration `it` produces
@@ -588,7 +619,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     }
                 }
             }
-            if (want_rule && wave == TW - 1) {  // one record per node block, lane = block
+            if (want_rule && wave == TW - 1) {
                 // The rule of iteration it - 1 needs the norm partials of EVERY owner, i.e. the slowest workgroup of the
                 // chip, every iteration (measured: 1.8 us of 17).  So while the ratios are clearly above tol only the
                 // records of iteration it - 2 are looked at -- published a whole iteration ago, no waiting -- and the exact
@@ -596,49 +627,17 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 // from then on every iteration is judged exactly, this one included.  Ratios move by ~1/k per iteration,
                 // so nothing is skipped; a run whose ratios fall by more than 20 % in ONE iteration straight below tol
                 // stops one iteration late (inside the +-1 contract of SURVEY.md section 7).
-                auto norms_of = [&](int j, double (&b)[4]) -> bool {  // sums of the records of local iteration j
-                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                    unsigned spins = 0;
-                    const unsigned tag = P.tag0 + (unsigned)j + 1u;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) b[q] = 0.0;
-#pragma unroll 1
-                    for (int b0 = 0; b0 < (BIG ? (int)P.nb : 1); b0 += 64) {  // (nb <= 64 unless BIG)
-                        const bool mine = b0 + lane < P.nb;
-                        tl_u4 r[4];
-                        for (;;) {
-                            bool ok = true;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                r[q] = tl_u4{0u, tag, 0u, tag};
-                                if (mine)
-                                    r[q] = __builtin_amdgcn_raw_buffer_load_b128(r_bn, (((j & 3) * (int)P.nb + b0 + lane) * 4 + q) * 16, 0, 16);
-                                ok = ok && tl_ok(r[q], tag);
-                            }
-                            asm volatile("" ::: "memory");
-                            if (__all(ok)) break;
-                            if (!tl_spin(spins, t0, err)) return false;
-                        }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) b[q] += wave_sum(mine ? tl_val(r[q]) : 0.0);
-                    }
-                    return true;
-                };
+                // The sums of the older records were formed at the END of the previous iteration (below: while this
+                // workgroup would only wait for node values) and wait in LDS: the look costs the acquire nothing.
                 double b[4] = {0, 0, 0, 0};
                 int stop = 0;
                 double rp = INFINITY, rd = INFINITY;
                 bool now_exact = exact || last_pass;
-                if (!now_exact && it >= 2) {
-                    good = good && norms_of(it - 2, b);
-                    const long long itp = P.it0 + it - 2;
-                    if (itp >= 1) {
-                        const double lp = sqrt(b[0]) / sqrt(b[1]), ld = sqrt(b[2]) / sqrt(b[3]);
-                        if (lp < P.tol && ld < P.tol) {
-                            stop = 1, rp = lp, rd = ld;  // (a jump straight below tol: seen one iteration late)
-                        } else if (lp < 1.25 * P.tol && ld < 1.25 * P.tol) {
-                            now_exact = true;
-                        }
-                    }
+                if (!now_exact && it >= 2) {  // what the early look found: -1 failed, 1 below tol, 2 within 25 % of it
+                    const int look = s_lagok;
+                    good = good && look >= 0;
+                    if (look == 1) stop = 1, rp = s_lag[0], rd = s_lag[1];  // (a jump straight below tol: seen one iteration late)
+                    if (look == 2) now_exact = true;
                 }
                 if (now_exact && !stop) {
                     good = good && norms_of(it - 1, b);
@@ -831,6 +830,16 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             s_wn[wave][1] = NORMS ? s_wcarry[wave] : 0.0;
             if (NORMS) s_wcarry[wave] = nw;
         }
+        // (the rule's early look, after the publish phase: its records are requested now)
+        const bool look_on = NORMS && rule_on && !exact && wave == TW - 1 && it >= 1 && it + 1 < P.maxit;
+        tl_u4 lk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lk[q] = tl_u4{0u, P.tag0 + (unsigned)it, 0u, P.tag0 + (unsigned)it};
+        if (!BIG && look_on && lane < P.nb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                lk[q] = __builtin_amdgcn_raw_buffer_load_b128(r_bn, ((((it - 1) & 3) * (int)P.nb + lane) * 4 + q) * 16, 0, 16);
+        }
         if (stamp) ts[2] = __builtin_amdgcn_s_memrealtime();
         if (stamp && lane == 0) {  // per-wave duration of the pass (after the workgroup's stamps)
             unsigned long long *o = P.dbg + (size_t)P.NWG * 16 * 6 + (((size_t)wg * 16 + (it - 8)) * TW + wave) * 2;
@@ -879,6 +888,44 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         }
         done_iters = it + 1;
         if (stamp) ts[3] = __builtin_amdgcn_s_memrealtime();
+        // The rule's early look for the top of iteration it + 1: the records of iteration it - 1 (a whole iteration old).
+        // Their loads were issued before the publish phase (lk, below) and are only looked at now; the screen compares
+        // squares (no square root, no division: 0.4 us for a lone wave); the ratios themselves are formed only when the
+        // look stops the run.
+        auto early_look = [&]() {
+            if (!look_on) return;
+            double b[4];
+            bool have = false;
+            if (!BIG) {
+                const unsigned tag = P.tag0 + (unsigned)it;  // records of local iteration it - 1
+                bool ok = true;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ok = ok && tl_ok(lk[q], tag);
+                if (__all(ok)) {
+                    have = true;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b[q] = wave_sum(lane < P.nb ? tl_val(lk[q]) : 0.0);
+                }
+            }
+            int look = 0;
+            if (!have) look = norms_of(it - 1, b) ? 0 : -1;
+            double lp = INFINITY, ld = INFINITY;
+            if (look == 0 && P.it0 + it - 1 >= 1) {  // never for iteration 0 (:156-161)
+                const double t2 = P.tol * P.tol, u2 = (1.25 * P.tol) * (1.25 * P.tol);
+                if (b[0] < t2 * b[1] && b[2] < t2 * b[3]) {
+                    lp = sqrt(b[0]) / sqrt(b[1]), ld = sqrt(b[2]) / sqrt(b[3]);
+                    look = (lp < P.tol && ld < P.tol) ? 1 : 2;
+                } else if (b[0] < u2 * b[1] && b[2] < u2 * b[3]) {
+                    look = 2;
+                }
+            }
+            if (lane == 0) {
+                s_lag[0] = lp;
+                s_lag[1] = ld;
+                s_lagok = look;
+            }
+        };
+        if (own < 0) early_look();
 
         // ================= node phase: the owner of a block sums its records and updates the dual state =================
         if (own >= 0) {
@@ -887,6 +934,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             bool good = true;
             double sp = 0, sw = 0;
             {
+                early_look();  // (wave TW - 1: before its share of the poll, whose records are still on their way)
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 unsigned spins = 0;
                 // wave TW - 1 also reads my slice of the workgroups' norm records (workgroups own, own + nb, ...): a workgroup

@@ -15,5 +15,8 @@ for n in [int(a) for a in sys.argv[1:]] or [130, 2048, 4096]:
         s.iterate(100, 0.0)
         print(n, s.engine_kernel, flush=True)
         s.iterate(100, 0.0)      # stamps of this launch (with norms) are printed by the library
+        print("-- with the stopping rule (tol = 1e-30):", flush=True)
+        s.iterate(100, 1e-30)
+        print("-- without norms:", flush=True)
         s.iterate_async(100)     # ... and of the variant without norms, at the next synchronising call
         s.dual()
