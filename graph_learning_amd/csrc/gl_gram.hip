@@ -37,15 +37,21 @@ __global__ __launch_bounds__(256) void k_center_rows(const double *__restrict__ 
     for (int64_t j = threadIdx.x; j < n; j += 256) xc[t * n + j] = row[j] - mean;
 }
 
-// G[I*64.., J*64..] = sum_t x[t][i] x[t][j].  4 waves in a 2x2 arrangement, each
-// 32x32 outputs = 2x2 MFMA accumulators of 16x16.
+// G[I*64.., J*64..] = sum_t x[t][i] x[t][j] for the tile pairs I <= J only (G is symmetric: half the contraction);
+// the mirror image G[J*64.., I*64..] is written from the same accumulators, transposed 16 x 16 block by block
+// through a wave-private LDS patch so that its stores are row-contiguous too.  4 waves in a 2x2 arrangement,
+// each 32x32 outputs = 2x2 MFMA accumulators of 16x16.  Every element, mirrored or not, is the same sum over t in
+// the same order: G is bitwise symmetric and G_ii, G_jj, G_ij of coincident columns are equal bit for bit.
 __global__ __launch_bounds__(256) void k_gram(const double *__restrict__ x, int64_t d, int64_t n,
-                                             double *__restrict__ G) {
+                                             double *__restrict__ G, int64_t nb) {
     __shared__ double As[GK][GLD];
     __shared__ double Bs[GK][GLD];
+    __shared__ double Ts[4][16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int64_t i0 = (int64_t)blockIdx.y * GT, j0 = (int64_t)blockIdx.x * GT;
+    int I, J;
+    gl_tile_decode((int64_t)blockIdx.x, nb, I, J);
+    const int64_t i0 = (int64_t)I * GT, j0 = (int64_t)J * GT;
     const int lrow = tid >> 4;        // 0..15  sample within the stage
     const int lcol = (tid & 15) * 4;  // 0..60  node within the tile
 
@@ -55,15 +61,27 @@ __global__ __launch_bounds__(256) void k_gram(const double *__restrict__ x, int6
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    for (int64_t t0 = 0; t0 < d; t0 += GK) {
+    // the next stage's 16 x 64 + 16 x 64 signal values travel from memory into registers while the current stage is
+    // multiplied out of LDS (one stage = 16 MFMAs per wave = 1024 matrix-pipe cycles, about one memory round trip)
+    double ra[4], rb[4];
+    auto fetch = [&](int64_t t0) {
         const int64_t t = t0 + lrow;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int64_t ia = i0 + lcol + e, jb = j0 + lcol + e;
-            As[lrow][lcol + e] = (t < d && ia < n) ? x[t * n + ia] : 0.0;
-            Bs[lrow][lcol + e] = (t < d && jb < n) ? x[t * n + jb] : 0.0;
+            ra[e] = (t < d && ia < n) ? x[t * n + ia] : 0.0;
+            rb[e] = (t < d && jb < n) ? x[t * n + jb] : 0.0;
+        }
+    };
+    fetch(0);
+    for (int64_t t0 = 0; t0 < d; t0 += GK) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            As[lrow][lcol + e] = ra[e];
+            Bs[lrow][lcol + e] = rb[e];
         }
         __syncthreads();
+        if (t0 + GK < d) fetch(t0 + GK);
 #pragma unroll
         for (int kk = 0; kk < GK / 4; ++kk) {
             const int kr = kk * 4 + (lane >> 4);
@@ -93,6 +111,22 @@ __global__ __launch_bounds__(256) void k_gram(const double *__restrict__ x, int6
                 const int64_t j = j0 + wn * 32 + ni * 16 + (lane & 15);
                 if (i < n && j < n) G[i * n + j] = acc[mi][ni][r];
             }
+    if (I == J) return;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ts[wave][(lane >> 4) + 4 * r][lane & 15] = acc[mi][ni][r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // row of the mirror image = a column of the block, column = one of its rows
+                const int64_t j = j0 + wn * 32 + ni * 16 + (lane >> 4) + 4 * r;
+                const int64_t i = i0 + wm * 32 + mi * 16 + (lane & 15);
+                const double v = Ts[wave][lane & 15][(lane >> 4) + 4 * r];
+                if (i < n && j < n) G[j * n + i] = v;
+            }
+        }
 }
 
 __global__ void k_take_diag(const double *__restrict__ G, int64_t n, double *__restrict__ diag) {
@@ -132,7 +166,7 @@ int gl_gram_distances(gl_ctx *ctx, const double *x_dev, double *xc_dev, int64_t 
                       double *diag_dev) {
     k_center_rows<<<dim3((unsigned)d), dim3(256), 0, ctx->stream>>>(x_dev, xc_dev, d, n);
     const unsigned nb = (unsigned)((n + GT - 1) / GT);
-    k_gram<<<dim3(nb, nb), dim3(256), 0, ctx->stream>>>(xc_dev, d, n, zsq_dev);
+    k_gram<<<dim3(nb * (nb + 1) / 2), dim3(256), 0, ctx->stream>>>(xc_dev, d, n, zsq_dev, (int64_t)nb);
     k_take_diag<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(zsq_dev, n, diag_dev);
     k_gram_to_dist<<<dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, ctx->stream>>>(zsq_dev, n, diag_dev, x_dev,
                                                                                                   d);
