@@ -541,10 +541,17 @@ __device__ __forceinline__ double lg_pack(unsigned lo, unsigned hi) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-__global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u4 *gran, unsigned tag0, int R, int max_iter,
-                                                     int64_t u_fast, int test_missing) {
-    extern __shared__ double s_W[];  // R rows of W, row-major (R * n doubles)
-    __shared__ double s_acc[2][4][ADMM_RES_MAXR];
+// NT = 256, RREG = 0: up to 8 rows per workgroup, all in LDS.  NT = 512, RREG = 8 ("wide", n > 1024): up to 16 rows, the
+// first 8 in LDS and the others in the registers of the threads that multiply them (thread t: columns t, t + 512, ...) --
+// half as many workgroups poll the n records of a step and half as many publish: at n = 2048 a poll round moves 4 MB
+// through the fabric instead of 8.
+template <int NT, int RREG>
+__global__ __launch_bounds__(NT) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u4 *gran, unsigned tag0, int R, int max_iter,
+                                                    int64_t u_fast, int test_missing) {
+    constexpr int CPT = ADMM_RES_MAXR * 256 / NT;  // columns per thread (n <= 2048)
+    constexpr int NWV = NT / 64, RLDS = ADMM_RES_MAXR, RTOT = ADMM_RES_MAXR + RREG;
+    extern __shared__ double s_W[];  // the first min(R, 8) rows of W, row-major
+    __shared__ double s_acc[2][NWV][RTOT];
     __shared__ int s_fail, s_stop[2];
     if (D.scal[8] != 0.0) return;  // an earlier QP could not run (workgroups not co-resident): the host redoes the cycle
     const int64_t n = D.n;
@@ -558,18 +565,42 @@ __global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, unsigned *err, lg_
         // k_lg_build_winv:  inv(I + rho M) = I - rho (G_mm - g g'/G_uu),  g = G[:,u] (left in gcol by
         // k_lg_qp_setup), identity on row / column u -- W itself is never written or read
         const double guu = D.G[u_fast * n + u_fast];
-        for (int r = 0; r < nrows; ++r) {
+        for (int r = 0; r < min(nrows, RLDS); ++r) {
             const int64_t i = r0 + r;
             const double gi = D.gcol[i];
             const double *grow = D.G + i * n;
-            for (int j = tid; j < (int)n; j += 256) {
+            for (int j = tid; j < (int)n; j += NT) {
                 double w = (i == j) ? 1.0 : 0.0;
                 if (i != u_fast && j != u_fast) w -= D.rho * (grow[j] - (gi * D.gcol[j]) / guu);
                 s_W[r * (int)n + j] = w;
             }
         }
     } else {
-        for (int64_t q = tid; q < (int64_t)nrows * n; q += 256) s_W[q] = D.W[r0 * n + q];
+        for (int64_t q = tid; q < (int64_t)min(nrows, RLDS) * n; q += NT) s_W[q] = D.W[r0 * n + q];
+    }
+    double wr[RREG > 0 ? RREG : 1][CPT];  // rows 8 .. 15 of my workgroup: my columns of them
+    if (RREG > 0) {
+        const double guu = u_fast >= 0 ? D.G[u_fast * n + u_fast] : 1.0;
+#pragma unroll
+        for (int r = 0; r < RREG; ++r) {
+            const int64_t i = r0 + RLDS + r;
+            const bool row = RLDS + r < nrows;
+            const double gi = (row && u_fast >= 0) ? D.gcol[i] : 0.0;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                const int64_t j = tid + NT * (int64_t)c;
+                double w = 0.0;
+                if (row && j < n) {
+                    if (u_fast >= 0) {
+                        w = (i == j) ? 1.0 : 0.0;
+                        if (i != u_fast && j != u_fast) w -= D.rho * (D.G[i * n + j] - (gi * D.gcol[j]) / guu);
+                    } else {
+                        w = D.W[i * n + j];
+                    }
+                }
+                wr[r][c] = w;
+            }
+        }
     }
     if (tid == 0) s_fail = 0;
     __syncthreads();
@@ -600,15 +631,15 @@ __global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, unsigned *err, lg_
     for (int it = 0; it <= max_iter + 1; ++it) {
         // (1) my columns of v: thread t takes columns t, t + 256, ...; re-read until every record carries this step's tag
         const unsigned tag = tag0 + (unsigned)it;
-        double vj[ADMM_RES_MAXR];
+        double vj[CPT];
         if (it <= max_iter) {
             const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
             bool good = true;
             for (unsigned spins = 0;; ++spins) {
                 bool ok = true;
 #pragma unroll
-                for (int c = 0; c < ADMM_RES_MAXR; ++c) {
-                    const int64_t j = tid + 256 * (int64_t)c;
+                for (int c = 0; c < CPT; ++c) {
+                    const int64_t j = tid + NT * (int64_t)c;
                     lg_u4 g = {0u, tag, 0u, tag};
                     if (j < n) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((((it & 1) * n) + j) * 16), 0, 16);
                     ok = ok && g.y == tag && g.w == tag;
@@ -652,15 +683,15 @@ __global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, unsigned *err, lg_
         }
         // (3) my rows times v
         if (it < max_iter) {
-            double acc[ADMM_RES_MAXR];
+            double acc[RLDS];
 #pragma unroll
-            for (int r = 0; r < ADMM_RES_MAXR; ++r) acc[r] = 0.0;
+            for (int r = 0; r < RLDS; ++r) acc[r] = 0.0;
 #pragma unroll
-            for (int c = 0; c < ADMM_RES_MAXR; ++c) {
-                const int64_t j = tid + 256 * (int64_t)c;
+            for (int c = 0; c < CPT; ++c) {
+                const int64_t j = tid + NT * (int64_t)c;
                 if (j < n) {
 #pragma unroll
-                    for (int r = 0; r < ADMM_RES_MAXR; ++r)
+                    for (int r = 0; r < RLDS; ++r)
                         if (r < nrows) acc[r] += s_W[(int64_t)r * n + j] * vj[c];
                 }
             }
@@ -668,6 +699,18 @@ __global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, unsigned *err, lg_
             // lane 4 r holds row r
             const double rs = add_xor32(halfwave_rows8(acc, lane));
             if (lane < 32 && (lane & 3) == 0) s_acc[it & 1][wave][lane >> 2] = rs;
+#pragma unroll
+            for (int gr = 0; gr < RREG / 8; ++gr) {  // the rows kept in registers (zero where there is no row / column: wr is)
+                double acr[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    acr[r] = 0.0;
+#pragma unroll
+                    for (int c = 0; c < CPT; ++c) acr[r] += wr[RREG > 0 ? 8 * gr + r : 0][c] * vj[c];
+                }
+                const double rs2 = add_xor32(halfwave_rows8(acr, lane));
+                if (lane < 32 && (lane & 3) == 0) s_acc[it & 1][wave][RLDS + 8 * gr + (lane >> 2)] = rs2;
+            }
         }
         __syncthreads();
         if (s_fail) {
@@ -688,7 +731,9 @@ __global__ __launch_bounds__(256) void k_lg_admm_tag(LgDev D, unsigned *err, lg_
             if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my partials of step it-1 have left before tag it+1 does
             if (tid < nrows) {
                 const bool active = on != 0.0;
-                const double sx = ((s_acc[it & 1][0][tid] + s_acc[it & 1][1][tid]) + s_acc[it & 1][2][tid]) + s_acc[it & 1][3][tid];
+                double sx = ((s_acc[it & 1][0][tid] + s_acc[it & 1][1][tid]) + s_acc[it & 1][2][tid]) + s_acc[it & 1][3][tid];
+#pragma unroll
+                for (int v = 4; v < NWV; ++v) sx += s_acc[it & 1][v][tid];
                 const double xn = active ? sx : 0.0;
                 double zn = xn + uo;
                 zn = zn < 0 ? 0.0 : zn;
@@ -1401,6 +1446,7 @@ struct AdmmRes {
     unsigned *bar = nullptr;
     // "tagged" form (k_lg_admm_tag): v travels as self-validating records, no grid barrier
     bool tagged = false;
+    bool wide = false;      // tagged form with 512 threads and up to 16 rows per workgroup (8 of them in registers)
     lg_u4 *gran = nullptr;  // [2][n] records of 16 bytes
     unsigned next_tag = 0;  // first tag of the next launch (a launch uses max_iter + 1 consecutive ones)
 };
@@ -1436,13 +1482,25 @@ int admm_res_plan(gl_ctx *ctx, int64_t n, AdmmRes &A) {
     // (n = 256: 1 / 2 / 4 / 8 rows: 0.455 / 0.399 / 0.385 / 0.397 ms per node-update)
     R = std::max<int>(R, (int)std::min<int64_t>(4, (n + 63) / 64));
     if (const char *e = getenv("GRAPHLEARN_AMD_LGMRF_R")) R = std::max(R, std::min(ADMM_RES_MAXR, atoi(e)));  // tuning aid
-    const size_t lds = (size_t)R * n * 8;
+    size_t lds = (size_t)R * n * 8;
     if (R > ADMM_RES_MAXR || lds > 150 * 1024) return GL_OK;  // one launch per step
+    A.tagged = !is("resident");  // "resident" keeps the grid-barrier form (tests, comparison)
+    // wide form: twice the rows per workgroup, half the parties in the hand-off (default above n = 1024, where the poll of
+    // a step is what a step costs; GRAPHLEARN_AMD_LGMRF_WIDE = 0 | 1 forces)
+    // (ms per node update, narrow / wide: n = 512: 0.33 / 0.22-0.26, 1024: 0.42 / 0.37, 1536: 0.55 / 0.44, 2048: 0.64 / 0.49;
+    //  24 rows, 16 of them in registers, measured too: 0.29 / 0.42 / 0.56 -- the registers are gone)
+    A.wide = A.tagged && n >= 512;
+    if (const char *e = getenv("GRAPHLEARN_AMD_LGMRF_WIDE")) A.wide = A.tagged && n > 2 * ADMM_RES_MAXR && atoi(e) != 0;
+    if (A.wide) {
+        R = 2 * ADMM_RES_MAXR;
+        lds = (size_t)ADMM_RES_MAXR * n * 8;
+    }
     A.R = R;
     A.nwg = (int)((n + R - 1) / R);
     A.lds = lds;
-    A.tagged = !is("resident");  // "resident" keeps the grid-barrier form (tests, comparison)
-    GL_HIP(ctx, hipFuncSetAttribute(A.tagged ? (const void *)k_lg_admm_tag : (const void *)k_lg_admm_res,
+    GL_HIP(ctx, hipFuncSetAttribute(A.wide     ? (const void *)k_lg_admm_tag<512, 8>
+                                    : A.tagged ? (const void *)k_lg_admm_tag<256, 0>
+                                               : (const void *)k_lg_admm_res,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     A.on = true;
     return GL_OK;
@@ -1488,8 +1546,12 @@ int run_admm_res(gl_ctx *ctx, const LgDev &D, AdmmRes &A, int max_iter, int64_t 
         const unsigned tag0 = A.next_tag;
         A.next_tag += (unsigned)max_iter + 2u;
         // error word: bar[32], zero since the allocation (a failure ends the use of this form)
-        k_lg_admm_tag<<<dim3((unsigned)A.nwg), 256, A.lds, ctx->stream>>>(D, A.bar + 32, A.gran, tag0, A.R, max_iter, u_fast,
-                                                                           test_not_resident ? 1 : 0);
+        if (A.wide)
+            k_lg_admm_tag<512, 8><<<dim3((unsigned)A.nwg), 512, A.lds, ctx->stream>>>(D, A.bar + 32, A.gran, tag0, A.R, max_iter, u_fast,
+                                                                                      test_not_resident ? 1 : 0);
+        else
+            k_lg_admm_tag<256, 0><<<dim3((unsigned)A.nwg), 256, A.lds, ctx->stream>>>(D, A.bar + 32, A.gran, tag0, A.R, max_iter, u_fast,
+                                                                                      test_not_resident ? 1 : 0);
         GL_HIP(ctx, hipGetLastError());
         return GL_OK;
     }
@@ -1531,12 +1593,12 @@ __global__ __launch_bounds__(VT) void k_lg_node_update(LgDev D, int64_t u) {
     const double cuu = D.C[u * n + u], kuu = D.K[u * n + u];
     double part = 0;
     for (int64_t i = threadIdx.x; i < n; i += VT)
-        if (i != u) part += D.C[i * n + u] * D.beta[i];
+        if (i != u) part += D.h[i] * D.beta[i];  // h = column u of C (snapshot taken before: contiguous, not a strided walk)
     const double cb = block_sum(part, sh);
     double quad = 0;
     for (int64_t i = threadIdx.x; i < n; i += VT) {
         double ti = 0.0;
-        if (i != u) ti = D.t[i] - D.C[i * n + u] * cb / cuu;
+        if (i != u) ti = D.t[i] - D.h[i] * cb / cuu;
         D.t[i] = ti;  // (M beta)_i
         quad += D.beta[i] * ti;
     }

@@ -50,6 +50,12 @@
 #ifndef GL_TILE_PIN
 #define GL_TILE_PIN 2  // row pairs between two scheduling boundaries of the pass (independent work for the fp64 pipe)
 #endif
+#ifndef GL_TILE_PROBES
+#define GL_TILE_PROBES 1      // probes a consumer of node values keeps in flight (2: measured slower, see the acquire)
+#endif
+#ifndef GL_TILE_PROBE_GAP
+#define GL_TILE_PROBE_GAP 12  // s_sleep units (64 cycles) between the two: about half a round trip
+#endif
 #ifndef GL_TILE_MIN_BULK_TILES
 #define GL_TILE_MIN_BULK_TILES 3
 #endif
@@ -589,26 +595,48 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                         }
                     }
                 } else if (wave < nblk) {
+                    // GL_TILE_PROBES = 2 keeps two probes in flight, half a round trip apart (a probe that finds the values
+                    // missing costs a whole round trip, ~1 us, before the next one can see them).  Measured and rejected: 6.35
+                    // against 5.9 us per iteration at n = 1030, 12.4 against 10.4 at n = 4096 -- the second probe's registers
+                    // push the pass into scratch, and most first probes succeed anyway.
                     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                     unsigned spins = 0;
-                    tl_u4 g[NACQ][2];
-                    for (;;) {
-                        bool ok = true;
+                    tl_u4 g[NACQ][2], h[NACQ][2];
+                    auto probe = [&](tl_u4 (&q)[NACQ][2]) {
 #pragma unroll
                         for (int j = 0; j < NACQ; ++j) {
                             const int k = wave + TW * j;
-                            g[j][0] = g[j][1] = tl_u4{0u, tag_in, 0u, tag_in};
+                            q[j][0] = q[j][1] = tl_u4{0u, tag_in, 0u, tag_in};
                             if (k < nblk) {
                                 const int off = (gd_int(GD_BLK + k) * 2 * TB + lane) * 16;
-                                g[j][0] = __builtin_amdgcn_raw_buffer_load_b128(r_nval, off, 0, 16);
-                                g[j][1] = __builtin_amdgcn_raw_buffer_load_b128(r_nval, off + TB * 16, 0, 16);
+                                q[j][0] = __builtin_amdgcn_raw_buffer_load_b128(r_nval, off, 0, 16);
+                                q[j][1] = __builtin_amdgcn_raw_buffer_load_b128(r_nval, off + TB * 16, 0, 16);
                             }
-                            ok = ok && tl_ok(g[j][0], tag_in) && tl_ok(g[j][1], tag_in);
                         }
-                        asm volatile("" ::: "memory");
-                        if (__all(ok)) break;
+                    };
+                    auto all_ok = [&](const tl_u4 (&q)[NACQ][2]) {
+                        bool ok = true;
+#pragma unroll
+                        for (int j = 0; j < NACQ; ++j) ok = ok && tl_ok(q[j][0], tag_in) && tl_ok(q[j][1], tag_in);
+                        return __all(ok);
+                    };
+                    probe(g);
+                    for (;;) {
+                        if (GL_TILE_PROBES > 1) {
+                            __builtin_amdgcn_s_sleep(GL_TILE_PROBE_GAP);
+                            probe(h);
+                            asm volatile("" ::: "memory");
+                        }
+                        if (all_ok(g)) break;
                         if (!tl_spin(spins, t0, err)) {
                             good = false;
+                            break;
+                        }
+                        probe(g);
+                        asm volatile("" ::: "memory");
+                        if (GL_TILE_PROBES > 1 && all_ok(h)) {
+#pragma unroll
+                            for (int j = 0; j < NACQ; ++j) g[j][0] = h[j][0], g[j][1] = h[j][1];
                             break;
                         }
                     }

@@ -18,16 +18,21 @@ from oracle import lgmrf as olg
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["launch", "wave", "quad", "one", "resident", "tagged", "auto"])
+@pytest.fixture(autouse=True, params=["launch", "wave", "quad", "one", "resident", "tagged", "wide", "auto"])
 def admm_form(request, monkeypatch):
     """Every test runs with every form of the QP's ADMM loop: one launch per step, the single-wave kernel
     (n <= 64, rows of the inverse in registers), the single-workgroup kernel with four lanes per row
     (64 < n <= 160, rows in registers), the single-workgroup kernel with the inverse in LDS (n <= 64), the
     persistent multi-workgroup kernels (matrix rows resident in LDS; steps separated by grid barriers, or
-    the right-hand side handed over as self-validating tagged records) and the automatic choice (wave to
-    n = 64, quad to n = 160, tagged above)."""
+    the right-hand side handed over as self-validating tagged records -- "tagged": up to 8 rows per workgroup,
+    all in LDS; "wide": up to 16, half of them in registers) and the automatic choice (wave to n = 64, quad to
+    n = 160, tagged above, wide above n = 1024)."""
+    monkeypatch.delenv("GRAPHLEARN_AMD_LGMRF_WIDE", raising=False)
     if request.param == "auto":
         monkeypatch.delenv("GRAPHLEARN_AMD_LGMRF_ADMM", raising=False)
+    elif request.param in ("tagged", "wide"):
+        monkeypatch.setenv("GRAPHLEARN_AMD_LGMRF_ADMM", "tagged")
+        monkeypatch.setenv("GRAPHLEARN_AMD_LGMRF_WIDE", "1" if request.param == "wide" else "0")
     else:
         monkeypatch.setenv("GRAPHLEARN_AMD_LGMRF_ADMM", request.param)
     return request.param
@@ -121,7 +126,7 @@ def test_persistent_forms_fall_back_when_not_co_resident(golden, monkeypatch, ad
     """The persistent kernels need all their workgroups on the chip at once.  With the test hook the
     start-up rendezvous can never complete: the QP entry point reruns with one launch per step, the fit
     restores the start of the cycle and redoes it that way -- same results, about a second later."""
-    if admm_form not in ("resident", "tagged"):
+    if admm_form not in ("resident", "tagged", "wide"):
         pytest.skip("only the persistent forms have a rendezvous")
     monkeypatch.setenv("GRAPHLEARN_AMD_LGMRF_TEST_NOT_RESIDENT", "1")
     g = golden("lgmrf")
@@ -159,7 +164,7 @@ def test_qp_solver_mid_sizes(n):
 
 
 # ------------------------------------------------------------------ BASELINE configs[2] shape
-LARGE_FORMS = ("auto", "tagged", "resident", "launch")
+LARGE_FORMS = ("auto", "tagged", "wide", "resident", "launch")
 
 
 def triu_to_square(v, n):
@@ -231,7 +236,7 @@ def test_lgmrf_c3_full_size_one_cycle_properties(admm_form):
 
     from scipy.linalg import solve_triangular
 
-    if admm_form not in ("auto", "tagged"):
+    if admm_form not in ("auto", "tagged", "wide"):
         pytest.skip("the default (tagged) form; the others are covered at n = 512")
     n, d = 2048, 512
     rng = np.random.default_rng(7)
