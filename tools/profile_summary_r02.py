@@ -32,8 +32,12 @@ def bench_line(d):
     return None
 
 
+def headline(name):  # the headline's k_tile launches (not the rounds instantiation of bench.py's n = 8192 leg)
+    return short(name).startswith("k_tile") and not short(name).endswith(", true>")
+
+
 def launches(d, prefix):
-    rows = [r for r in csv.DictReader(open(one(d, "kernel_trace.csv"))) if short(r["Kernel_Name"]).startswith(prefix)]
+    rows = [r for r in csv.DictReader(open(one(d, "kernel_trace.csv"))) if headline(r["Kernel_Name"])]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     return [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows], rows
 
@@ -80,7 +84,7 @@ vals = {}
 for d, c in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     v = []
     for r in csv.DictReader(open(one(d, "counter_collection.csv"))):
-        if r["Counter_Name"] == c and short(r["Kernel_Name"]).startswith("k_tile"):
+        if r["Counter_Name"] == c and headline(r["Kernel_Name"]):
             v.append(float(r["Counter_Value"]))
     vals[c] = v
 f = st.median(sorted(vals["FETCH_SIZE"])[-2:])   # the two 2000-iteration launches are the largest
