@@ -74,8 +74,11 @@ by = table("lgmrf", lines, 10)
 adm = [k for k in by if k.startswith("k_lg_admm")]
 if adm:
     v = by[adm[0]]
+    per_cycle = sum(sum(x) for k, x in by.items() if k.startswith(("k_gj_", "k_lg_prepare", "k_lg_shift")))
+    per_node = sum(sum(x) for k, x in by.items() if k.startswith("k_") and not k.startswith(("k_gj_", "k_lg_prepare", "k_lg_shift")))
     lines += ["", f"`{adm[0]}`: {len(v)} launches (one per node update, all ADMM steps inside), average {st.mean(v):.1f} us, median {st.median(v):.1f} us; "
-              f"all kernels of a node update together {sum(sum(x) for x in by.values())/len(v):.1f} us.", ""]
+              f"the kernels of a node update together {per_node/len(v):.1f} us; once per cycle (Theta + rho I inverted from scratch, "
+              f"`k_gj_*`): {per_cycle/1e3:.1f} ms = {per_cycle/2048:.1f} us per node update of a full cycle.", ""]
 for bits in (64, 32):
     d = f"gd{bits}"
     shutil.copy(one(d, "kernel_stats.csv"), os.path.join(out_dir, f"r02_graphdict_fp{bits}_kernel_stats.csv"))
