@@ -123,6 +123,8 @@ struct TileDev {
     tl_u4 *nval;   // [nb][2][64] granules: {d, pbar} of a node block
     tl_u4 *wnorm;  // [4][NWG][2] granules: {sum (q-y)^2, sum w^2} of a workgroup (ring by iteration)
     tl_u4 *bnrm;   // [4][nb][4] granules: norm partials of a node block and of its slice of wnorm
+    tl_u4 *look;   // [4][4] granules: the rule's early look of one workgroup for all ({code, ratio, ratio, -}; ring by iteration)
+    int rule_wg;   // the workgroup that takes it (one without a node block of its own where there is one)
     unsigned *bar;  // rendezvous words (gl_gridbar.h layout)
     unsigned long long *dbg;  // development only (GRAPHLEARN_AMD_RES_STAMPS=1): per-workgroup phase stamps
     int64_t n, nb;
@@ -144,6 +146,11 @@ __device__ __forceinline__ tl_u4 tl_gran(double v, unsigned tag) {
     return g;
 }
 __device__ __forceinline__ bool tl_ok(tl_u4 g, unsigned tag) { return g.y == tag && g.w == tag; }
+__device__ __forceinline__ double lane_bcast(double v, int l) {  // lane l's value in every lane
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 
 // false: give up (error word raised by somebody, or one second without progress)
 __device__ __forceinline__ bool tl_spin(unsigned &spins, unsigned long long t0, unsigned *err) {
@@ -419,8 +426,6 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     __shared__ double s_ns[2];
     __shared__ int s_flag[4];                         // {rendezvous ok, failed, stop, -}
     __shared__ double s_rel[2];
-    __shared__ double s_lag[2];                       // the rule's early look: ratios of the iteration before the last one
-    __shared__ int s_lagok;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wg = blockIdx.x;
@@ -539,6 +544,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     const auto r_nval = __builtin_amdgcn_make_buffer_rsrc((void *)P.nval, 0, (int)(P.nb * 2 * TB * 16), 0x00020000);
     const auto r_wn = __builtin_amdgcn_make_buffer_rsrc((void *)P.wnorm, 0, (int)(4 * P.NWG * 2 * 16), 0x00020000);
     const auto r_bn = __builtin_amdgcn_make_buffer_rsrc((void *)P.bnrm, 0, (int)(4 * P.nb * 4 * 16), 0x00020000);
+    const auto r_lk = __builtin_amdgcn_make_buffer_rsrc((void *)P.look, 0, 4 * 4 * 16, 0x00020000);
 
     // ---- start-up rendezvous: every workgroup of the grid is on the chip, or nobody touches anything.  The arrival
     //      counter is monotonic over the launches of the session (target = arrivals so far + grid), so nothing has to be
@@ -681,10 +687,27 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 int stop = 0;
                 double rp = INFINITY, rd = INFINITY;
                 bool now_exact = exact || last_pass;
-                if (!now_exact && it >= 2) {  // what the early look found: -1 failed, 1 below tol, 2 within 25 % of it
-                    const int look = s_lagok;
+                if (!now_exact && it >= 2) {
+                    // what the early look of iteration it - 1 found (one workgroup takes it for all, below; its record has been
+                    // on its way for a whole hand-off): -1 failed, 1 below tol, 2 within 25 % of it
+                    const unsigned tag = P.tag0 + (unsigned)it;
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    unsigned spins = 0;
+                    tl_u4 r;
+                    for (;;) {
+                        r = tl_u4{0u, tag, 0u, tag};
+                        if (lane < 3) r = __builtin_amdgcn_raw_buffer_load_b128(r_lk, ((((it - 1) & 3) * 4) + lane) * 16, 0, 16);
+                        asm volatile("" ::: "memory");
+                        if (__all(tl_ok(r, tag))) break;
+                        if (!tl_spin(spins, t0, err)) {
+                            good = false;
+                            break;
+                        }
+                    }
+                    const double mine = tl_val(r);
+                    const int look = good ? (int)lane_bcast(mine, 0) : -1;
                     good = good && look >= 0;
-                    if (look == 1) stop = 1, rp = s_lag[0], rd = s_lag[1];  // (a jump straight below tol: seen one iteration late)
+                    if (look == 1) stop = 1, rp = lane_bcast(mine, 1), rd = lane_bcast(mine, 2);  // (a jump straight below tol: seen one iteration late)
                     if (look == 2) now_exact = true;
                 }
                 if (now_exact && !stop) {
@@ -879,7 +902,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             if (NORMS) s_wcarry[wave] = nw;
         }
         // (the rule's early look, after the publish phase: its records are requested now)
-        const bool look_on = NORMS && rule_on && !exact && wave == TW - 1 && it >= 1 && it + 1 < P.maxit;
+        const bool look_on = NORMS && rule_on && !exact && wg == P.rule_wg && wave == TW - 1 && it >= 1 && it + 1 < P.maxit;
         tl_u4 lk[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) lk[q] = tl_u4{0u, P.tag0 + (unsigned)it, 0u, P.tag0 + (unsigned)it};
@@ -937,9 +960,11 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         done_iters = it + 1;
         if (stamp) ts[3] = __builtin_amdgcn_s_memrealtime();
         // The rule's early look for the top of iteration it + 1: the records of iteration it - 1 (a whole iteration old).
-        // Their loads were issued before the publish phase (lk, below) and are only looked at now; the screen compares
-        // squares (no square root, no division: 0.4 us for a lone wave); the ratios themselves are formed only when the
-        // look stops the run.
+        // ONE workgroup takes it for all (P.rule_wg: no node block of its own, so it would only wait for node values now)
+        // and publishes what it found as a tagged record that every workgroup reads at its next top -- in the owners the
+        // look sat in front of the poll of the degree records (0.9 us per iteration).  Its loads were issued before the
+        // publish phase (lk, above) and are only looked at now; the screen compares squares (no square root, no
+        // division: 0.4 us for a lone wave); the ratios themselves are formed only when the look stops the run.
         auto early_look = [&]() {
             if (!look_on) return;
             double b[4];
@@ -967,10 +992,9 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     look = 2;
                 }
             }
-            if (lane == 0) {
-                s_lag[0] = lp;
-                s_lag[1] = ld;
-                s_lagok = look;
+            if (lane < 3) {  // for every workgroup's next top
+                const double v = lane == 0 ? (double)look : (lane == 1 ? lp : ld);
+                __builtin_amdgcn_raw_buffer_store_b128(tl_gran(v, tag_out), r_lk, (((it & 3) * 4) + lane) * 16, 0, 16);
             }
         };
         if (own < 0) early_look();
@@ -1185,9 +1209,9 @@ static int tile_finish(gl_logdeg *s, std::vector<WaveDesc> &wd, std::vector<WgDe
     auto up256 = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t b_wd = up256(wd.size() * sizeof(WaveDesc)), b_gd = up256(gd.size() * sizeof(WgDesc));
     const size_t b_part = up256((size_t)n_entries * 2 * TB * 16), b_nval = up256((size_t)nb * 2 * TB * 16);
-    const size_t b_wn = up256((size_t)4 * NWG * 2 * 16), b_bn = up256((size_t)4 * nb * 4 * 16);
+    const size_t b_wn = up256((size_t)4 * NWG * 2 * 16), b_bn = up256((size_t)4 * nb * 4 * 16), b_lk = up256((size_t)4 * 4 * 16);
     const size_t b_bar = up256((size_t)GL_BAR_WORDS * 4);
-    const size_t total = b_wd + b_gd + b_part + b_nval + b_wn + b_bn + b_bar;
+    const size_t total = b_wd + b_gd + b_part + b_nval + b_wn + b_bn + b_lk + b_bar;
     if (hipMalloc(&t->arena, total) != hipSuccess) {
         delete t;
         return gl_set_error(ctx, GL_E_NOMEM, "tile engine: hipMalloc(%zu) failed", total);
@@ -1201,6 +1225,7 @@ static int tile_finish(gl_logdeg *s, std::vector<WaveDesc> &wd, std::vector<WgDe
     P.nval = (tl_u4 *)at, at += b_nval;
     P.wnorm = (tl_u4 *)at, at += b_wn;
     P.bnrm = (tl_u4 *)at, at += b_bn;
+    P.look = (tl_u4 *)at, at += b_lk;
     t->gran_bytes = (size_t)(at - (char *)t->arena) - t->gran_off;
     P.bar = (unsigned *)at;
     hipError_t e = hipMemsetAsync(t->arena, 0, total, ctx->stream);
@@ -1224,6 +1249,13 @@ static int tile_finish(gl_logdeg *s, std::vector<WaveDesc> &wd, std::vector<WgDe
     P.nb = D.nb;
     P.NWG = NWG;
     P.n_entries = n_entries;
+    P.rule_wg = NWG - 1;  // the rule's early look: a workgroup that has edges but no node block of its own, if there is one
+    for (int g = NWG - 1; g >= 0; --g)
+        if (gd[(size_t)g].active && gd[(size_t)g].own < 0) {
+            P.rule_wg = g;
+            break;
+        }
+    if (!gd[(size_t)P.rule_wg].active) P.rule_wg = 0;  // (workgroup 0 owns block 0: always active)
     t->U = U;
     t->big = big;
     P.dbg = nullptr;
