@@ -423,7 +423,6 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     __shared__ double s_bn[4];                        // ... and the norm partials of its last update
     __shared__ double s_wn[TW][2];
     __shared__ double s_wcarry[TW];                   // per wave: sum of squares of its current w (the rule's denominator)
-    __shared__ double s_ns[2];
     __shared__ int s_flag[4];                         // {rendezvous ok, failed, stop, -}
     __shared__ double s_rel[2];
 
@@ -1009,15 +1008,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 early_look();  // (wave TW - 1: before its share of the poll, whose records are still on their way)
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 unsigned spins = 0;
-                // wave TW - 1 also reads my slice of the workgroups' norm records (workgroups own, own + nb, ...): a workgroup
-                // publishes them right behind its degree records, so they ride in the same poll round (a poll of their
-                // own behind the records cost the owner a second round trip: 0.7 us per iteration in converge mode)
-                const bool slicer = NORMS && wave == TW - 1;
-                const int nsrc = own + lane * (int)P.nb;
-                const bool nmine = slicer && nsrc < P.NWG && ((slice_mask >> lane) & 1ull);
-                tl_u4 na = tl_u4{0u, tag_out, 0u, tag_out}, nb2 = na;
-                bool nok = !slicer;
-                for (int eb = own_e0 + wave; (eb < own_e1 || !nok) && good; eb += TW * RND) {  // rounds of up to RND records per wave
+                for (int eb = own_e0 + wave; eb < own_e1 && good; eb += TW * RND) {  // rounds of up to RND records per wave
                     tl_u4 g[RND][2];
                     for (;;) {
                         bool ok = true;
@@ -1032,19 +1023,8 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                             }
                             ok = ok && tl_ok(g[u][0], tag_out) && tl_ok(g[u][1], tag_out);
                         }
-                        if (!nok) {
-                            if (nmine) {
-                                const int off = (((it & 3) * P.NWG + nsrc) * 2) * 16;
-                                na = __builtin_amdgcn_raw_buffer_load_b128(r_wn, off, 0, 16);
-                                nb2 = __builtin_amdgcn_raw_buffer_load_b128(r_wn, off + 16, 0, 16);
-                            }
-                            ok = ok && tl_ok(na, tag_out) && tl_ok(nb2, tag_out);
-                        }
                         asm volatile("" ::: "memory");
-                        if (__all(ok)) {
-                            nok = true;
-                            break;
-                        }
+                        if (__all(ok)) break;
                         if (!tl_spin(spins, t0, err)) {
                             good = false;
                             break;
@@ -1059,13 +1039,6 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 }
                 s_own[wave][0][lane] = sp;
                 s_own[wave][1][lane] = sw;
-                if (slicer) {
-                    const double n0 = wave_sum(nmine ? tl_val(na) : 0.0), n1 = wave_sum(nmine ? tl_val(nb2) : 0.0);
-                    if (lane == 0) {
-                        s_ns[0] = n0;
-                        s_ns[1] = n1;
-                    }
-                }
                 if (!good) s_flag[1] = 1;
             }
             if (stamp) ts[4] = __builtin_amdgcn_s_memrealtime();
@@ -1099,10 +1072,44 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 const int off = (own * 2 * TB + lane) * 16;
                 __builtin_amdgcn_raw_buffer_store_b128(tl_gran(nscale * d_new, tag_out), r_nval, off, 0, 16);
                 __builtin_amdgcn_raw_buffer_store_b128(tl_gran(nscale * pb_new, tag_out), r_nval, off + TB * 16, 0, 16);
-                dq2 = wave_sum(dq2);
-                d2 = wave_sum(d2);
-                if (lane < 4) {
-                    const double v = lane == 0 ? s_ns[0] : (lane == 1 ? s_ns[1] : (lane == 2 ? dq2 : d2));
+                if (NORMS) {  // my block's norm partials (the node values are out: nobody waits for these)
+                    dq2 = wave_sum(dq2);
+                    d2 = wave_sum(d2);
+                    if (lane == 2 || lane == 3) {
+                        const double v = lane == 2 ? dq2 : d2;
+                        s_bn[lane] = v;
+                        __builtin_amdgcn_raw_buffer_store_b128(tl_gran(v, tag_out), r_bn, ((((it & 3) * (int)P.nb + own) * 4) + lane) * 16, 0, 16);
+                    }
+                }
+            } else if (NORMS && wave == TW - 1) {
+                // my slice of the workgroups' norm records (workgroups own, own + nb, ...), beside wave 0's update and off the
+                // owner's critical path (in front of the barrier above it cost 0.5-1 us per iteration: the node values of
+                // the whole chip waited for it)
+                const int nsrc = own + lane * (int)P.nb;
+                const bool nmine = nsrc < P.NWG && ((slice_mask >> lane) & 1ull);
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                unsigned spins = 0;
+                tl_u4 na, nb2;
+                bool got = true;
+                for (;;) {
+                    na = nb2 = tl_u4{0u, tag_out, 0u, tag_out};
+                    if (nmine) {
+                        const int off = (((it & 3) * P.NWG + nsrc) * 2) * 16;
+                        na = __builtin_amdgcn_raw_buffer_load_b128(r_wn, off, 0, 16);
+                        nb2 = __builtin_amdgcn_raw_buffer_load_b128(r_wn, off + 16, 0, 16);
+                    }
+                    asm volatile("" ::: "memory");
+                    if (__all(tl_ok(na, tag_out) && tl_ok(nb2, tag_out))) break;
+                    if (!tl_spin(spins, t0, err)) {
+                        got = false;
+                        break;
+                    }
+                }
+                const double n0 = wave_sum(nmine ? tl_val(na) : 0.0), n1 = wave_sum(nmine ? tl_val(nb2) : 0.0);
+                if (!got) {
+                    if (lane == 0) s_flag[1] = 1;  // (seen at the next top)
+                } else if (lane < 2) {
+                    const double v = lane == 0 ? n0 : n1;
                     s_bn[lane] = v;
                     __builtin_amdgcn_raw_buffer_store_b128(tl_gran(v, tag_out), r_bn, ((((it & 3) * (int)P.nb + own) * 4) + lane) * 16, 0, 16);
                 }
