@@ -313,13 +313,33 @@ __device__ __forceinline__ void tl_put_cols(const double (&col)[4], double *s_co
 #define GL_TILE_STREAM_RING 4
 #endif
 constexpr int RS = GL_TILE_STREAM_RING;  // 4 or 8
+// NT: the streamed tiles pass through the caches with the non-temporal hint.  Worth it only when what streams per iteration
+// no longer fits the 256 MB Infinity Cache (n = 8192: 143 -> 137 us per iteration; n = 7000, 262 MB of reads: 89 -> 101).
+template <bool NT>
+__device__ __forceinline__ double2 tl_ld_stream(const char *p) {
+    if (NT) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p));
+        return double2{v.x, v.y};
+    }
+    return *reinterpret_cast<const double2 *>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void tl_st_stream(char *p, const double2 v) {
+    if (NT) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store((v2d){v.x, v.y}, reinterpret_cast<v2d *>(p));
+    } else {
+        *reinterpret_cast<double2 *>(p) = v;
+    }
+}
 #ifndef GL_TILE_STAGGER
 #define GL_TILE_STAGGER 1
 #endif
 #ifndef GL_TILE_STREAM_SCHED
 #define GL_TILE_STREAM_SCHED 1
 #endif
-template <bool NORMS, bool MASKED>
+template <bool NORMS, bool MASKED, bool NT>
 __device__ __forceinline__ void tl_stream_pass(const TileDev &P, double2 (&wq)[RS], double2 (&zq)[RS], const unsigned tb,
                                                const unsigned nxt, const double2 *s_rows, const double dj0, const double dj1,
                                                const double pj0, const double pj1, const bool diag, const bool jv0, const bool jv1,
@@ -371,12 +391,12 @@ __device__ __forceinline__ void tl_stream_pass(const TileDev &P, double2 (&wq)[R
                         nw = __builtin_fma(wn[e], wn[e], nw);
                     }
                 }
-                *reinterpret_cast<double2 *>(wbase + tb + (unsigned)(s * (2 * TB) * 8)) = double2{wn[0], wn[1]};
+                tl_st_stream<NT>(wbase + tb + (unsigned)(s * (2 * TB) * 8), double2{wn[0], wn[1]});
                 // the ring's registers are requested again only now that their values have been used (requested earlier, the
                 // compiler copies the whole ring aside and waits for all of it at the top of the loop)
                 asm volatile("" ::: "memory");
-                wq[pos] = *reinterpret_cast<const double2 *>(wbase + nbase + (unsigned)(pos * (2 * TB) * 8));
-                zq[pos] = *reinterpret_cast<const double2 *>(zbase + nbase + (unsigned)(pos * (2 * TB) * 8));
+                wq[pos] = tl_ld_stream<NT>(wbase + nbase + (unsigned)(pos * (2 * TB) * 8));
+                zq[pos] = tl_ld_stream<NT>(zbase + nbase + (unsigned)(pos * (2 * TB) * 8));
                 colp0 += pp[0];
                 colp1 += pp[1];
                 colw0 += wn[0];
@@ -411,8 +431,9 @@ __device__ __forceinline__ void tl_stream_pass(const TileDev &P, double2 (&wq)[R
 // barriers) into the accumulators of the waves that publish the records.  Everything else -- records, owners, rule --
 // is unchanged.  Streamed tiles are updated in place: a launch that fails after the rendezvous is an error as before,
 // one whose workgroups never met has still written nothing.
-template <int U, bool RAGGED, bool NORMS, bool BIG = false>
+template <int U, bool RAGGED, bool NORMS, int BIGV = 0>  // BIGV: 0, 1 = rounds, 2 = rounds with non-temporal streams
 __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
+    constexpr bool BIG = BIGV != 0, NT = BIGV == 2;
     static_assert(!BIG || U == SLOTS, "rounds work on whole tiles");
     constexpr int ZRES = U == SLOTS ? SLOTS / 2 : U;  // LDS-resident row pairs of z per chunk
     constexpr int NS = U - ZRES;                      // streamed ones
@@ -790,7 +811,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     asm volatile("" : "+v"(lane_s));  // (as below)
                     double2 wq[RS], zq[RS];
                     ring_load(wq, zq, tile_off(0));
-                    tl_stream_pass<NORMS, true>(P, wq, zq, tile_off(0), tile_off(0), rows, cv0.x, cv1.x, cv0.y, cv1.y, wdv.I == wdv.J, jv0, jv1,
+                    tl_stream_pass<NORMS, true, NT>(P, wq, zq, tile_off(0), tile_off(0), rows, cv0.x, cv1.x, cv0.y, cv1.y, wdv.I == wdv.J, jv0, jv1,
                                                 &s_part[wave][0][0], col, lane_s, nqy, nw, g0);
                 }
             }
@@ -810,7 +831,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     if (r < my_nr) {
                         const unsigned tb = tile_off(r), nxt = r + 1 < my_nr ? tile_off(r + 1) : tb;
                         const double2 *rows = &s_node[(my_rs >> (4 * r)) & 15][0];
-                        tl_stream_pass<NORMS, true>(P, wq, zq, tb, nxt, rows, cv0.x, cv1.x, cv0.y, cv1.y, wdv.I + r == wdv.J, jv0, jv1,
+                        tl_stream_pass<NORMS, true, NT>(P, wq, zq, tb, nxt, rows, cv0.x, cv1.x, cv0.y, cv1.y, wdv.I + r == wdv.J, jv0, jv1,
                                                     &s_part[wave][0][0], col, lane_s, nqy, nw, g0);
                     }
                     if (r == nrw - 1) break;  // (the barrier and the last fold are those of the publish phase below)
@@ -1171,6 +1192,7 @@ struct gl_tile {
     TileDev dev{};
     int U = SLOTS;              // row pairs per chunk: 32, 16 or 8
     bool big = false;           // rounds (n > 4096)
+    bool nt = false;            // ... whose streamed tiles no longer fit the Infinity Cache: non-temporal loads and stores
     void *arena = nullptr;      // descriptors, record buffers, rendezvous words: one allocation
     size_t gran_off = 0, gran_bytes = 0;  // the record buffers inside it
     unsigned long long *dbg = nullptr;
@@ -1265,6 +1287,14 @@ static int tile_finish(gl_logdeg *s, std::vector<WaveDesc> &wd, std::vector<WgDe
     if (!gd[(size_t)P.rule_wg].active) P.rule_wg = 0;  // (workgroup 0 owns block 0: always active)
     t->U = U;
     t->big = big;
+    if (big) {  // what streams per iteration: w and z of every tile no wave keeps in registers
+        int64_t streamed = 0;
+        for (const WaveDesc &w : wd) streamed += w.nr - (w.tile >= 0 ? 1 : 0);
+        // (measured, cached / non-temporal: n = 7500: 102.8 / 108.9 us per iteration, 7800: 116.3 / 118.9, 8000: 133.6 / 129.7,
+        //  8192: 141.4 / 136.9, 8704: 161 / 150: the switch sits where w + z of the streamed tiles reach ~360 MB)
+        t->nt = streamed * GL_TILE_ELEMS * 16 > ((int64_t)360 << 20);
+        if (const char *e = getenv("GRAPHLEARN_AMD_TILE_NT")) t->nt = atoi(e) != 0;
+    }
     P.dbg = nullptr;
     if (getenv("GRAPHLEARN_AMD_RES_STAMPS") && hipMalloc((void **)&t->dbg, (size_t)NWG * 16 * (6 + 2 * TW) * 8) == hipSuccess) {
         (void)hipMemset(t->dbg, 0, (size_t)NWG * 16 * (6 + 2 * TW) * 8);
@@ -1541,14 +1571,16 @@ int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms) {
             if (norms) go(k_tile<UU, false, true, BB>); else go(k_tile<UU, false, false, BB>);   \
         }                                                                                        \
     } while (0)
-    if (t->big)
-        GL_TILE_GO(32, true);
+    if (t->big && t->nt)
+        GL_TILE_GO(32, 2);
+    else if (t->big)
+        GL_TILE_GO(32, 1);
     else if (t->U == 32)
-        GL_TILE_GO(32, false);
+        GL_TILE_GO(32, 0);
     else if (t->U == 16)
-        GL_TILE_GO(16, false);
+        GL_TILE_GO(16, 0);
     else
-        GL_TILE_GO(8, false);
+        GL_TILE_GO(8, 0);
 #undef GL_TILE_GO
     GL_HIP(ctx, hipGetLastError());
     return GL_OK;
