@@ -313,8 +313,13 @@ __device__ __forceinline__ void tl_put_cols(const double (&col)[4], double *s_co
 #define GL_TILE_STREAM_RING 4
 #endif
 constexpr int RS = GL_TILE_STREAM_RING;  // 4 or 8
-// NT: the streamed tiles pass through the caches with the non-temporal hint.  Worth it only when what streams per iteration
-// no longer fits the 256 MB Infinity Cache (n = 8192: 143 -> 137 us per iteration; n = 7000, 262 MB of reads: 89 -> 101).
+#ifndef GL_TILE_NT_W
+#define GL_TILE_NT_W 0  // 1: w carries the hint too (measured slower: 137 against 114 us per iteration at n = 8192)
+#endif
+// NT: the streamed z passes through the caches with the non-temporal hint, so that it does not push the streamed w --
+// rewritten and re-read every iteration, 201 MB at n = 8192 -- out of the 256 MB Infinity Cache.  us per iteration
+// without / with: n = 5000: 32.8 / 38.2, 6144: 61.2 / 61.2, 7000: 88.9 / 82.7, 7800: 116.3 / 97.3, 8192: 141-143 / 114.0,
+// 8704: 161 / 127.4.  (The hint on w as well: 8192: 137, 8704: 150.)
 template <bool NT>
 __device__ __forceinline__ double2 tl_ld_stream(const char *p) {
     if (NT) {
@@ -391,11 +396,11 @@ __device__ __forceinline__ void tl_stream_pass(const TileDev &P, double2 (&wq)[R
                         nw = __builtin_fma(wn[e], wn[e], nw);
                     }
                 }
-                tl_st_stream<NT>(wbase + tb + (unsigned)(s * (2 * TB) * 8), double2{wn[0], wn[1]});
+                tl_st_stream<NT && GL_TILE_NT_W>(wbase + tb + (unsigned)(s * (2 * TB) * 8), double2{wn[0], wn[1]});
                 // the ring's registers are requested again only now that their values have been used (requested earlier, the
                 // compiler copies the whole ring aside and waits for all of it at the top of the loop)
                 asm volatile("" ::: "memory");
-                wq[pos] = tl_ld_stream<NT>(wbase + nbase + (unsigned)(pos * (2 * TB) * 8));
+                wq[pos] = tl_ld_stream<NT && GL_TILE_NT_W>(wbase + nbase + (unsigned)(pos * (2 * TB) * 8));
                 zq[pos] = tl_ld_stream<NT>(zbase + nbase + (unsigned)(pos * (2 * TB) * 8));
                 colp0 += pp[0];
                 colp1 += pp[1];
@@ -1290,9 +1295,8 @@ static int tile_finish(gl_logdeg *s, std::vector<WaveDesc> &wd, std::vector<WgDe
     if (big) {  // what streams per iteration: w and z of every tile no wave keeps in registers
         int64_t streamed = 0;
         for (const WaveDesc &w : wd) streamed += w.nr - (w.tile >= 0 ? 1 : 0);
-        // (measured, cached / non-temporal: n = 7500: 102.8 / 108.9 us per iteration, 7800: 116.3 / 118.9, 8000: 133.6 / 129.7,
-        //  8192: 141.4 / 136.9, 8704: 161 / 150: the switch sits where w + z of the streamed tiles reach ~360 MB)
-        t->nt = streamed * GL_TILE_ELEMS * 16 > ((int64_t)360 << 20);
+        // (the hint on z pays from n ~ 6400 on: w + z of the streamed tiles ~ 200 MB, see tl_ld_stream)
+        t->nt = streamed * GL_TILE_ELEMS * 16 > ((int64_t)200 << 20);
         if (const char *e = getenv("GRAPHLEARN_AMD_TILE_NT")) t->nt = atoi(e) != 0;
     }
     P.dbg = nullptr;
