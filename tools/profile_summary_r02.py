@@ -33,7 +33,8 @@ def bench_line(d):
 
 
 def headline(name):  # the headline's k_tile launches (not the rounds instantiation of bench.py's n = 8192 leg)
-    return short(name).startswith("k_tile") and not short(name).endswith(", true>")
+    n = short(name)
+    return n.startswith("k_tile") and not n.endswith((", true>", ", 1>", ", 2>"))
 
 
 def launches(d, prefix):

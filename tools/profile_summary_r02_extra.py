@@ -67,7 +67,8 @@ for n in (1024, 2048, 8192):
             tr[pmc] = st.mean(vals) * mult / 500
         lines += [f"PMC (per iteration, 500-iteration launches): FETCH_SIZE x 2 x 1024 = {tr['fetch8192']/1e6:.1f} MB, WRITE_SIZE x 1024 = "
                   f"{tr['write8192']/1e6:.1f} MB, together {(tr['fetch8192']+tr['write8192'])/1e6:.1f} MB against 24 E = {24*e/1e6:.1f} MB "
-                  f"algorithmic (the resident quarter of w never moves) -> {(tr['fetch8192']+tr['write8192'])/per_it/1e6:.2f} TB/s of real traffic.", ""]
+                  f"algorithmic (the resident quarter of w never moves) -> {(tr['fetch8192']+tr['write8192'])/per_it/1e6:.2f} TB/s between the L2s and the fabric "
+                  "(the counters sit in front of the Infinity Cache: the streamed w that it serves is included).", ""]
 shutil.copy(one("lgmrf", "kernel_stats.csv"), os.path.join(out_dir, "r02_lgmrf_kernel_stats.csv"))
 lines += ["## LGMRF n = 2048, d = 512: the first 256 node updates of a cycle (`GRAPHLEARN_AMD_LGMRF_MAX_NODES=256 tools/lgmrf_bench.py 2048 512 1`)", ""]
 by = table("lgmrf", lines, 10)
