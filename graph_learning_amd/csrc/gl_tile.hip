@@ -165,7 +165,13 @@ __device__ __forceinline__ bool tl_spin(unsigned &spins, unsigned long long t0, 
     return true;
 }
 
+template <bool NT = false>
 __device__ __forceinline__ double2 tl_ldz(const double *base, unsigned byte_off) {
+    if (NT) {  // (rounds past the Infinity Cache: z leaves the cache to the streamed w, see tl_ld_stream)
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(reinterpret_cast<const char *>(base) + byte_off));
+        return double2{v.x, v.y};
+    }
     return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
@@ -189,7 +195,7 @@ __device__ __forceinline__ double tl_lin(const double c, const double g, const d
 // row pair (it pins the running sums, which LLVM otherwise sinks to the end of the unrolled body, spilling every
 // addend on the way) is a scheduling boundary.
 // WRAP = false (rounds): the ring is filled by the caller right before the pass and is dead after it.
-template <int U, bool RAGGED, bool NORMS, bool WRAP = true>
+template <int U, bool RAGGED, bool NORMS, bool WRAP = true, bool ZNT = false>
 __device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[U], double2 (&zr)[RING], const double2 *zl,
                                               const unsigned zb, const double2 *s_rows, const double dj0, const double dj1,
                                               const double pj0, const double pj1, const double m0, const double m1,
@@ -226,7 +232,7 @@ __device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[
                 const int pos = (s / 2) % RING;
                 gz = double2{g2 * zr[pos].x, g2 * zr[pos].y};
                 // refill with the RING-th next streamed row pair (2 RING row pairs ahead; wraps into the next iteration)
-                if (WRAP || s + 2 * RING < SLOTS) zr[pos] = tl_ldz(P.z, zbv + (unsigned)(((s + 2 * RING) % SLOTS) * (2 * TB) * 8));
+                if (WRAP || s + 2 * RING < SLOTS) zr[pos] = tl_ldz<ZNT>(P.z, zbv + (unsigned)(((s + 2 * RING) % SLOTS) * (2 * TB) * 8));
             } else {
                 gz = zl_n;
             }
@@ -809,8 +815,8 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 const double2 *rows = &s_node[my_rs & 15][0];
                 if (has) {
 #pragma unroll
-                    for (int k = 0; k < RING; ++k) zr[k] = tl_ldz(P.z, zb + (unsigned)(2 * k * (2 * TB) * 8));
-                    tl_chunk_pass<U, RAGGED, NORMS, false>(P, wreg, zr, &s_z[wave][0][lane], zb, rows, cv0.x, cv1.x, cv0.y, cv1.y, m0, m1,
+                    for (int k = 0; k < RING; ++k) zr[k] = tl_ldz<NT>(P.z, zb + (unsigned)(2 * k * (2 * TB) * 8));
+                    tl_chunk_pass<U, RAGGED, NORMS, false, NT>(P, wreg, zr, &s_z[wave][0][lane], zb, rows, cv0.x, cv1.x, cv0.y, cv1.y, m0, m1,
                                                            &s_part[wave][0][0], col, lane, wave >= TW / 2, nqy, nw);
                 } else {  // (a column whose first tile here is its diagonal tile)
                     asm volatile("" : "+v"(lane_s));  // (as below)
