@@ -299,6 +299,109 @@ __device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[
     col[0] = colp0, col[1] = colp1, col[2] = colw0, col[3] = colw1;
 }
 
+// The resident pass of the ROUNDS (n > 4096): as tl_chunk_pass<32>, but only WRG = 20 (18 with the norms) of the tile's 32
+// row pairs keep their w in registers; the last ones live in the wave's LDS slice, which in exchange holds z for every 8th
+// (16th) row pair only (the others come through the ring).  The rounds need registers beside the resident pass -- the streamed pass, its rings,
+// the accumulators of the fold -- and with all 32 row pairs in registers the compiler parked 2 (6 with the norms) of them in
+// scratch: every access to those sits in the same vmcnt queue as the z ring and stalls the pass for a memory round trip
+// (n = 5000 with norms: 46 against 32 us per iteration without).
+// LDS slice of a wave (zw, 16 x 64 double2): [0, ZLN) 2 gamma z of row pairs ZEV - 1, 2 ZEV - 1, ..; [ZLN, 16) w of row pairs WRG .. 31.
+constexpr int WRG_NONE = SLOTS;
+// How the wave's LDS slice is split (measured, us per iteration without / with the norms: every 8th row pair of z in LDS,
+// 20 row pairs of w in registers: n = 5000: 30.6 / 52.5 -- two row pairs still in scratch with the norms --, 8192: 111.1 /
+// 123.7; every 16th, 18 in registers: 31.5 / 35.4, 112.9 / 117.0): the variant with the norms gives up more of z.
+template <bool NORMS>
+struct RoundsSplit {
+    static constexpr int ZEV = NORMS ? 16 : 8;        // every ZEV-th row pair keeps its z in LDS
+    static constexpr int ZLN = SLOTS / ZEV;           // ... that many of them
+    static constexpr int WRG = SLOTS - (16 - ZLN);    // row pairs of w in registers (18 or 20); the others in LDS behind the z
+    static constexpr int slot(int t) { return t + t / (ZEV - 1); }  // the t-th streamed row pair
+};
+template <bool RAGGED, bool NORMS, bool ZNT>
+__device__ __forceinline__ void tl_resident_pass_rounds(const TileDev &P, double2 (&wreg)[SLOTS], double2 (&zr)[RING], double2 *zw,
+                                                        const unsigned zb, const double2 *s_rows, const double dj0, const double dj1,
+                                                        const double pj0, const double pj1, const double m0, const double m1,
+                                                        double *s_row, double (&col)[4], const int lane, const bool younger,
+                                                        double &nqy, double &nw) {
+    constexpr int ZEV = RoundsSplit<NORMS>::ZEV, ZLN = RoundsSplit<NORMS>::ZLN, WRG = RoundsSplit<NORMS>::WRG;
+    constexpr int NSTR = SLOTS - ZLN;
+    const int half = lane >> 5;
+    const double c = P.c, g = P.gamma, g2 = P.g2;
+    double colp0 = col[0], colp1 = col[1], colw0 = col[2], colw1 = col[3];
+    unsigned zbv = zb;  // (not loop-invariant for the compiler: see tl_chunk_pass)
+    asm volatile("" : "+v"(zbv));
+    if (younger) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int gq = 0; gq < SLOTS / 4; ++gq) {
+        double rowp[4], roww[4];
+        if (gq == (SLOTS / 4) * GL_TILE_PRIO_EIGHTHS / 8) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int s = 4 * gq + k;
+            double2 gz;
+            if (s % ZEV != ZEV - 1) {
+                const int t = s - (s + 1) / ZEV;  // streamed row pairs before this one
+                const int pos = t % RING;
+                gz = double2{g2 * zr[pos].x, g2 * zr[pos].y};
+                if (t + RING < NSTR) zr[pos] = tl_ldz<ZNT>(P.z, zbv + (unsigned)(RoundsSplit<NORMS>::slot(t + RING) * (2 * TB) * 8));
+            } else {
+                gz = zw[(s / ZEV) * 64];
+            }
+            const double2 rv = s_rows[2 * s + half];
+            const double di = rv.x, pi = rv.y;
+            const double2 wv = s < WRG ? wreg[s < WRG ? s : 0] : zw[(ZLN + s - WRG) * 64];
+            double wn[2], pp[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const double w = e ? wv.y : wv.x;
+                const double y = tl_lin(c, g, w, di, e ? dj1 : dj0);   // :147
+                const double tt = y - (e ? gz.y : gz.x);               // :150
+                const double pr = tt > 0 ? tt : 0.0;
+                const double q = tl_lin(c, g, pr, pi, e ? pj1 : pj0);  // :153
+                if (RAGGED) {
+                    const double m = e ? m1 : m0;
+                    wn[e] = m * ((w - y) + q);
+                    pp[e] = m * pr;
+                } else {
+                    wn[e] = (w - y) + q;  // :163
+                    pp[e] = pr;
+                }
+                if (NORMS) {
+                    const double dq = RAGGED ? (e ? m1 : m0) * (q - y) : q - y;
+                    nqy = __builtin_fma(dq, dq, nqy);
+                    nw = __builtin_fma(wn[e], wn[e], nw);
+                }
+            }
+            colp0 += pp[0];
+            colp1 += pp[1];
+            colw0 += wn[0];
+            colw1 += wn[1];
+            rowp[k] = pp[0] + pp[1];
+            roww[k] = wn[0] + wn[1];
+            if (s < WRG) wreg[s < WRG ? s : 0] = double2{wn[0], wn[1]};
+            else zw[(ZLN + s - WRG) * 64] = double2{wn[0], wn[1]};
+            if (k % GL_TILE_PIN == GL_TILE_PIN - 1) {
+                if (NORMS)
+                    asm volatile("" : "+v"(nqy), "+v"(nw), "+v"(colp0), "+v"(colp1), "+v"(colw0), "+v"(colw1));
+                else
+                    asm volatile("" : "+v"(colp0), "+v"(colp1), "+v"(colw0), "+v"(colw1));
+            }
+        }
+        const double rw = halfwave_rows4(roww, lane);
+        const double rp = halfwave_rows4(rowp, lane);
+        // the address of the row entries is formed anew every time: kept in a register over the pass it is the first thing
+        // the compiler parks in scratch, and every reload waits for the whole z ring (s_waitcnt vmcnt(0))
+        int lr = lane;
+        asm volatile("" : "+v"(lr));
+        if ((lr & 7) == 0) {
+            const int row = 2 * (4 * gq + ((lr >> 3) & 3)) + (lr >> 5);
+            s_row[row] = rp;
+            s_row[TB + row] = rw;
+        }
+    }
+    col[0] = colp0, col[1] = colp1, col[2] = colw0, col[3] = colw1;
+}
+
 // column sums of a wave (each lane: its two columns over the rows of its half) -> the wave's column vectors in LDS
 __device__ __forceinline__ void tl_put_cols(const double (&col)[4], double *s_col, const int lane) {
     const int half = lane >> 5, c0 = 2 * (lane & 31);
@@ -445,6 +548,7 @@ __device__ __forceinline__ void tl_stream_pass(const TileDev &P, double2 (&wq)[R
 template <int U, bool RAGGED, bool NORMS, int BIGV = 0>  // BIGV: 0, 1 = rounds, 2 = rounds with non-temporal streams
 __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     constexpr bool BIG = BIGV != 0, NT = BIGV == 2;
+    constexpr int ZEV = RoundsSplit<NORMS>::ZEV, ZLN = RoundsSplit<NORMS>::ZLN, WRG = BIG ? RoundsSplit<NORMS>::WRG : WRG_NONE;
     static_assert(!BIG || U == SLOTS, "rounds work on whole tiles");
     constexpr int ZRES = U == SLOTS ? SLOTS / 2 : U;  // LDS-resident row pairs of z per chunk
     constexpr int NS = U - ZRES;                      // streamed ones
@@ -488,12 +592,16 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         const int64_t tb = (int64_t)wdv.tile * GL_TILE_ELEMS + (int64_t)a0 * (2 * TB) + lofs;
         zb = (unsigned)(tb * 8);
 #pragma unroll
-        for (int s = 0; s < U; ++s) wreg[s] = *reinterpret_cast<const double2 *>(P.w + tb + s * (2 * TB));
+        for (int s = 0; s < U; ++s) {
+            const double2 wv = *reinterpret_cast<const double2 *>(P.w + tb + s * (2 * TB));
+            if (BIG && s >= WRG) s_z[wave][ZLN + s - WRG][lane] = wv;  // (rounds: the last row pairs of w live in LDS)
+            else wreg[s] = wv;
+        }
 #pragma unroll
-        for (int s = 0; s < U; ++s) {  // LDS-resident part (U = 32: the odd row pairs), pre-multiplied: 2 gamma z
-            if (NS > 0 && (s & 1) == 0) continue;
+        for (int s = 0; s < U; ++s) {  // LDS-resident part (U = 32: the odd row pairs; rounds: every fourth), pre-multiplied: 2 gamma z
+            if (BIG ? s % ZEV != ZEV - 1 : (NS > 0 && (s & 1) == 0)) continue;
             const double2 zv = *reinterpret_cast<const double2 *>(P.z + tb + s * (2 * TB));
-            s_z[wave][NS > 0 ? s / 2 : s][lane] = double2{P.g2 * zv.x, P.g2 * zv.y};
+            s_z[wave][BIG ? s / ZEV : (NS > 0 ? s / 2 : s)][lane] = double2{P.g2 * zv.x, P.g2 * zv.y};
         }
         if (NS > 0 && !BIG) {
 #pragma unroll
@@ -549,7 +657,10 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             }
         }
 #pragma unroll
-        for (int s = 0; s < U; ++s) acc = __builtin_fma(wreg[s].y, wreg[s].y, __builtin_fma(wreg[s].x, wreg[s].x, acc));
+        for (int s = 0; s < U; ++s) {
+            const double2 wv = (BIG && s >= WRG) ? (has ? s_z[wave][ZLN + (s >= WRG ? s - WRG : 0)][lane] : double2{0.0, 0.0}) : wreg[s];
+            acc = __builtin_fma(wv.y, wv.y, __builtin_fma(wv.x, wv.x, acc));
+        }
 #pragma unroll
         for (int f = 0; f < FRMAX; ++f) acc = __builtin_fma(fw[f].y, fw[f].y, __builtin_fma(fw[f].x, fw[f].x, acc));
         acc = wave_sum(acc);
@@ -781,7 +892,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         double accp[NACQ], accw[NACQ];  // BIG: what the rounds before the last one add to the records I publish
 #pragma unroll
         for (int j = 0; j < NACQ; ++j) accp[j] = accw[j] = 0.0;
-        if (!BIG) {
+        if constexpr (!BIG) {
             if (has) {
                 const double2 cv0 = s_node[wdv.sj][c0], cv1 = s_node[wdv.sj][c0 + 1];
                 double col[4] = {0.0, 0.0, 0.0, 0.0};
@@ -815,9 +926,9 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 const double2 *rows = &s_node[my_rs & 15][0];
                 if (has) {
 #pragma unroll
-                    for (int k = 0; k < RING; ++k) zr[k] = tl_ldz<NT>(P.z, zb + (unsigned)(2 * k * (2 * TB) * 8));
-                    tl_chunk_pass<U, RAGGED, NORMS, false, NT>(P, wreg, zr, &s_z[wave][0][lane], zb, rows, cv0.x, cv1.x, cv0.y, cv1.y, m0, m1,
-                                                           &s_part[wave][0][0], col, lane, wave >= TW / 2, nqy, nw);
+                    for (int k = 0; k < RING; ++k) zr[k] = tl_ldz<NT>(P.z, zb + (unsigned)(RoundsSplit<NORMS>::slot(k) * (2 * TB) * 8));
+                    tl_resident_pass_rounds<RAGGED, NORMS, NT>(P, wreg, zr, &s_z[wave][0][lane], zb, rows, cv0.x, cv1.x, cv0.y, cv1.y, m0, m1,
+                                                               &s_part[wave][0][0], col, lane, wave >= TW / 2, nqy, nw);
                 } else {  // (a column whose first tile here is its diagonal tile)
                     asm volatile("" : "+v"(lane_s));  // (as below)
                     double2 wq[RS], zq[RS];
@@ -1170,7 +1281,8 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     if (has) {
         const int64_t tb = (int64_t)wdv.tile * GL_TILE_ELEMS + (int64_t)a0 * (2 * TB) + lofs;
 #pragma unroll
-        for (int s = 0; s < U; ++s) *reinterpret_cast<double2 *>(P.w + tb + s * (2 * TB)) = wreg[s];
+        for (int s = 0; s < U; ++s)
+            *reinterpret_cast<double2 *>(P.w + tb + s * (2 * TB)) = (BIG && s >= WRG) ? s_z[wave][ZLN + (s >= WRG ? s - WRG : 0)][lane] : wreg[s];
     }
 #pragma unroll
     for (int f = 0; f < FRMAX; ++f)
