@@ -1191,15 +1191,19 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 break;
             }
             if (wave == 0) {
-                sp = s_own[0][0][lane];
-                sw = s_own[0][1][lane];
+                // (addresses formed from the lane number here and now: kept over the pass they end up in scratch in the
+                //  variants with norms, and their reloads sit between the owner's poll and the node values it publishes)
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                sp = s_own[0][0][ln];
+                sw = s_own[0][1][ln];
 #pragma unroll
                 for (int v = 1; v < TW; ++v) {
-                    sp += s_own[v][0][lane];
-                    sw += s_own[v][1][lane];
+                    sp += s_own[v][0][ln];
+                    sw += s_own[v][1][ln];
                 }
-                const bool real = own_i < P.n;
-                const double d_cur = s_dual[0][lane], yb_cur = s_dual[1][lane], pb_cur = s_dual[2][lane];
+                const bool real = (int64_t)own * TB + ln < P.n;
+                const double d_cur = s_dual[0][ln], yb_cur = s_dual[1][ln], pb_cur = s_dual[2][ln];
                 const double qb = pb_cur + P.gamma * sp;  // :154
                 const double dq = qb - yb_cur;            // == -ybar + qbar (:159)
                 double dq2 = real ? dq * dq : 0.0;
@@ -1208,20 +1212,20 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 const double ybn = dnew + P.gamma * sw;                     // :148 of the next iteration
                 const double pbn = (ybn - sqrt(ybn * ybn + P.a4g)) / 2;     // :151
                 const double d_new = real ? dnew : 0.0, pb_new = real ? pbn : 0.0;
-                s_dual[3][lane] = d_cur;
-                s_dual[0][lane] = d_new;
-                s_dual[1][lane] = real ? ybn : 0.0;
-                s_dual[2][lane] = pb_new;
-                const int off = (own * 2 * TB + lane) * 16;
+                s_dual[3][ln] = d_cur;
+                s_dual[0][ln] = d_new;
+                s_dual[1][ln] = real ? ybn : 0.0;
+                s_dual[2][ln] = pb_new;
+                const int off = (own * 2 * TB + ln) * 16;
                 __builtin_amdgcn_raw_buffer_store_b128(tl_gran(nscale * d_new, tag_out), r_nval, off, 0, 16);
                 __builtin_amdgcn_raw_buffer_store_b128(tl_gran(nscale * pb_new, tag_out), r_nval, off + TB * 16, 0, 16);
                 if (NORMS) {  // my block's norm partials (the node values are out: nobody waits for these)
                     dq2 = wave_sum(dq2);
                     d2 = wave_sum(d2);
-                    if (lane == 2 || lane == 3) {
-                        const double v = lane == 2 ? dq2 : d2;
-                        s_bn[lane] = v;
-                        __builtin_amdgcn_raw_buffer_store_b128(tl_gran(v, tag_out), r_bn, ((((it & 3) * (int)P.nb + own) * 4) + lane) * 16, 0, 16);
+                    if (ln == 2 || ln == 3) {
+                        const double v = ln == 2 ? dq2 : d2;
+                        s_bn[ln] = v;
+                        __builtin_amdgcn_raw_buffer_store_b128(tl_gran(v, tag_out), r_bn, ((((it & 3) * (int)P.nb + own) * 4) + ln) * 16, 0, 16);
                     }
                 }
             } else if (NORMS && wave == TW - 1) {
