@@ -29,7 +29,11 @@
 //     records that arrive in the same round trip as the node values, before anything is modified -- and not
 //     at all while tol = 0 (fixed-iteration calls), except once at the end for the values reported; the norms
 //     themselves are only formed in the iterations whose rule is evaluated.
-// Every sum has a fixed order (no atomics): bit-reproducible run to run.
+//   * past n = 4096 the lattice no longer fits the register files: a workgroup then takes a rectangle of tiles and works
+//     through it in ROUNDS, one tile per wave from registers and LDS as above, the others streamed through register
+//     rings (see k_tile, BIGV); the records, the owners and the rule are the same.
+// Every sum has a fixed order (no atomics): bit-reproducible run to run.  The per-edge arithmetic follows the reference
+// with two re-associations (GL_TILE_FAST_ARITH): <= 1 ulp per operation, iterates within ~1e-14 of the oracle.
 //
 // Nothing is written back before the end of the call (w lives in registers, the dual state in registers of
 // the owners), so a launch whose workgroups are not all co-resident (start-up rendezvous, bounded by the wall
