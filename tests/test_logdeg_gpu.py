@@ -290,6 +290,36 @@ def test_resident_engine_falls_back_when_workgroups_do_not_meet(golden, engine, 
     np.testing.assert_allclose(w, g["raw_w_it50"], rtol=0, atol=ATOL)
 
 
+def test_rounds_fall_back_untouched_when_workgroups_do_not_meet(engine, monkeypatch):
+    """Past n = 4096 the tile engine updates its streamed tiles in place -- but only after the start-up rendezvous:
+    a launch whose workgroups never met has written nothing, and the call (also an asynchronous one, at its next
+    synchronising call) is served by the streaming engine from the untouched state."""
+    if engine != "resident":
+        pytest.skip("the tile engine's rounds only")
+    n = 4203
+    z = np.random.default_rng(n).uniform(0.05, 3.0, size=n * (n - 1) // 2)
+    with _lib.LogDegreeSession(n) as s:       # reference run: streaming engine throughout
+        monkeypatch.setenv("GRAPHLEARN_AMD_ENGINE", "stream")
+        s.set_distances(z)
+        s.init(1.0, 1.0, 0.5, None)
+        s.iterate(17, 0.0)
+        s.iterate(21, 0.0)
+        w_ref, d_ref = s.weights_condensed(), s.dual()
+    monkeypatch.setenv("GRAPHLEARN_AMD_ENGINE", "resident")
+    monkeypatch.setenv("GRAPHLEARN_AMD_RES_TEST_NOT_RESIDENT", "1")
+    with _lib.LogDegreeSession(n) as s:
+        s.set_distances(z)
+        s.init(1.0, 1.0, 0.5, None)
+        assert s.engine_kernel == "k_tile"
+        s.iterate_async(17)                   # fails at the rendezvous; noticed at the next synchronising call
+        n_it, conv, _ = s.iterate(21, 0.0)
+        assert n_it == 21 and s.engine == "stream" and s.total_iterations == 38
+        w, d = s.weights_condensed(), s.dual()
+    # the same engine ran the same iterations from the same state (its degree sums are grouped by call length: 1e-16)
+    np.testing.assert_allclose(w, w_ref, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(d, d_ref, rtol=0, atol=1e-13)
+
+
 @pytest.mark.parametrize("n", [2600, 3000])
 def test_resident_matches_streaming_at_ragged_large_sizes(n, engine, monkeypatch):
     """Resident engine on lattices with a ragged last block (n not a multiple of 64) and many fringe
