@@ -1487,9 +1487,10 @@ int admm_res_plan(gl_ctx *ctx, int64_t n, AdmmRes &A) {
     A.tagged = !is("resident");  // "resident" keeps the grid-barrier form (tests, comparison)
     // wide form: twice the rows per workgroup, half the parties in the hand-off (default above n = 1024, where the poll of
     // a step is what a step costs; GRAPHLEARN_AMD_LGMRF_WIDE = 0 | 1 forces)
-    // (ms per node update, narrow / wide: n = 512: 0.33 / 0.22-0.26, 1024: 0.42 / 0.37, 1536: 0.55 / 0.44, 2048: 0.64 / 0.49;
-    //  24 rows, 16 of them in registers, measured too: 0.29 / 0.42 / 0.56 -- the registers are gone)
-    A.wide = A.tagged && n >= 512;
+    // (ms per node update, narrow / wide: n = 256: 0.31 / 0.29, 384: 0.34 / 0.30, 512: 0.33 / 0.22-0.26, 1024: 0.42 / 0.37,
+    //  1536: 0.55 / 0.44, 2048: 0.64 / 0.49; 24 rows, 16 of them in registers, measured too: 0.29 / 0.42 / 0.56 at 512 /
+    //  1024 / 2048 -- the registers are gone)
+    A.wide = A.tagged && n >= 256;
     if (const char *e = getenv("GRAPHLEARN_AMD_LGMRF_WIDE")) A.wide = A.tagged && n > 2 * ADMM_RES_MAXR && atoi(e) != 0;
     if (A.wide) {
         R = 2 * ADMM_RES_MAXR;

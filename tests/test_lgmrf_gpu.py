@@ -26,7 +26,7 @@ def admm_form(request, monkeypatch):
     persistent multi-workgroup kernels (matrix rows resident in LDS; steps separated by grid barriers, or
     the right-hand side handed over as self-validating tagged records -- "tagged": up to 8 rows per workgroup,
     all in LDS; "wide": up to 16, half of them in registers) and the automatic choice (wave to n = 64, quad to
-    n = 160, tagged above, wide above n = 1024)."""
+    n = 160, tagged above, wide from n = 256)."""
     monkeypatch.delenv("GRAPHLEARN_AMD_LGMRF_WIDE", raising=False)
     if request.param == "auto":
         monkeypatch.delenv("GRAPHLEARN_AMD_LGMRF_ADMM", raising=False)
