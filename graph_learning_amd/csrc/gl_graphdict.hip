@@ -47,6 +47,20 @@ template <>
 __device__ __forceinline__ double gd_fma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
 template <>
 __device__ __forceinline__ float gd_fma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// squared differences of a pair: one packed subtraction and one packed multiplication in fp32 (the compiler packs the
+// fused multiply-adds by itself, not these two), the plain operations in fp64 -- the same values either way
+typedef float gd_v2f __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ void gd_sqdiff2(const T a0, const T a1, const T b0, const T b1, T &s0, T &s1) {
+    const T d0 = a0 - b0, d1 = a1 - b1;
+    s0 = d0 * d0, s1 = d1 * d1;
+}
+template <>
+__device__ __forceinline__ void gd_sqdiff2<float>(const float a0, const float a1, const float b0, const float b1, float &s0, float &s1) {
+    const gd_v2f d = gd_v2f{a0, a1} - gd_v2f{b0, b1};
+    const gd_v2f q = d * d;
+    s0 = q.x, s1 = q.y;
+}
 
 template <typename T, int KP, int RC>
 __global__ __launch_bounds__(64) void k_gd_grad_c(const T *__restrict__ XT, const T *__restrict__ WS,
@@ -89,14 +103,17 @@ __global__ __launch_bounds__(64) void k_gd_grad_c(const T *__restrict__ XT, cons
             for (int q = 0; q < GD_SPL; ++q) xj[q] = XT[(int64_t)jc * Tp + t0 + 64 * q];
         };
         auto accumulate = [&](const T (&w)[RC][KP], const T (&xj)[GD_SPL]) {
+            static_assert(GD_SPL % 2 == 0, "samples per lane are taken in pairs");
 #pragma unroll
             for (int a = 0; a < RC; ++a)
 #pragma unroll
-                for (int q = 0; q < GD_SPL; ++q) {
-                    const T d = xi[a][q] - xj[q];
-                    const T sq = d * d;
+                for (int q = 0; q < GD_SPL; q += 2) {
+                    T sq0, sq1;
+                    gd_sqdiff2<T>(xi[a][q], xi[a][q + 1], xj[q], xj[q + 1], sq0, sq1);
 #pragma unroll
-                    for (int k = 0; k < KP; ++k) acc[q][k] = gd_fma<T>(w[a][k], sq, acc[q][k]);
+                    for (int k = 0; k < KP; ++k) acc[q][k] = gd_fma<T>(w[a][k], sq0, acc[q][k]);
+#pragma unroll
+                    for (int k = 0; k < KP; ++k) acc[q + 1][k] = gd_fma<T>(w[a][k], sq1, acc[q + 1][k]);
                 }
         };
         int j = i0 + 1;
@@ -168,12 +185,15 @@ __global__ __launch_bounds__(256, 3) void k_gd_grad_w(const T *__restrict__ X, c
             xj = X[(int64_t)tc * n_pad + j];
         };
         auto accumulate = [&](const T (&xi)[SW], const T (&cf)[KP], const T xj) {
+            static_assert(SW % 2 == 0, "rows of a strip are taken in pairs");
 #pragma unroll
-            for (int a = 0; a < SW; ++a) {
-                const T d = xi[a] - xj;
-                const T sq = d * d;
+            for (int a = 0; a < SW; a += 2) {
+                T sq0, sq1;
+                gd_sqdiff2<T>(xi[a], xi[a + 1], xj, xj, sq0, sq1);
 #pragma unroll
-                for (int k = 0; k < KP; ++k) acc[a][k] = gd_fma<T>(cf[k], sq, acc[a][k]);
+                for (int k = 0; k < KP; ++k) acc[a][k] = gd_fma<T>(cf[k], sq0, acc[a][k]);
+#pragma unroll
+                for (int k = 0; k < KP; ++k) acc[a + 1][k] = gd_fma<T>(cf[k], sq1, acc[a + 1][k]);
             }
         };
         request(tA, xiA, cfA, xjA);
