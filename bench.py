@@ -45,9 +45,9 @@ def algorithmic_bytes_per_iteration(n: int) -> int:
     return 12 * n * (n - 1)
 
 
-def cpu_baseline(z_scaled: np.ndarray, budget_its=(3, 13)):
+def cpu_baseline(z_scaled: np.ndarray, budget_its=(5, 65)):
     """Oracle (NumPy/SciPy restatement with the reference's CSR strategy) on the host cores:
-    (t(13 its) - t(3 its)) / 10, which excludes the one-time operator build."""
+    (t(65 its) - t(5 its)) / 60 -- about 11 s of CPU work at n = 4096 -- which excludes the one-time operator build."""
     from oracle import logdeg as old
 
     n = old.n_nodes_from_edges(z_scaled.size)
