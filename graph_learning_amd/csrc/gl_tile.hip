@@ -79,7 +79,8 @@ constexpr int TB = GL_TB;
 constexpr int SLOTS = TB / 2;  // 32 row pairs per tile
 constexpr int TW = 8;          // waves per workgroup (two per SIMD)
 constexpr int TT = TW * 64;
-constexpr int NBW = 13;        // node blocks one workgroup may touch (8 chunks: at most 16 distinct ones; 9 seen)
+constexpr int NBW = 16;        // node blocks one workgroup may touch in the rounds (8 columns + up to 8 rows); descriptor size
+constexpr int NBW_FIT = 13;    // ... while the lattice fits the register files (8 chunks: 9 seen); what s_node holds there
 constexpr int FRMAX = 2;       // fringe row pairs per wave
 constexpr int RING = 4;        // register ring of streamed z row pairs (U = 32)
 constexpr int NACQ = (NBW + TW - 1) / TW;  // node blocks one wave fetches
@@ -316,9 +317,10 @@ constexpr int WRG_NONE = SLOTS;
 // 123.7; every 16th, 18 in registers: 31.5 / 35.4, 112.9 / 117.0): the variant with the norms gives up more of z.
 template <bool NORMS>
 struct RoundsSplit {
-    static constexpr int ZEV = NORMS ? 16 : 8;        // every ZEV-th row pair keeps its z in LDS
+    static constexpr int SLICE = 15;                  // row pairs of LDS per wave (one less than below n = 4096: s_node holds 16 blocks)
+    static constexpr int ZEV = NORMS ? 64 : 8;        // every ZEV-th row pair keeps its z in LDS (64: none)
     static constexpr int ZLN = SLOTS / ZEV;           // ... that many of them
-    static constexpr int WRG = SLOTS - (16 - ZLN);    // row pairs of w in registers (18 or 20); the others in LDS behind the z
+    static constexpr int WRG = SLOTS - (SLICE - ZLN); // row pairs of w in registers (18 or 21); the others in LDS behind the z
     static constexpr int slot(int t) { return t + t / (ZEV - 1); }  // the t-th streamed row pair
 };
 template <bool RAGGED, bool NORMS, bool ZNT>
@@ -541,8 +543,8 @@ __device__ __forceinline__ void tl_stream_pass(const TileDev &P, double2 (&wq)[R
 // report the ratios of their last iteration); without, the pass is a fifth shorter (asynchronous fixed-iteration calls).
 // One instantiation of the pass per kernel: two of them inside one loop cost 150 registers (measured).
 //
-// BIG (4096 < n <= ~8700, U = 32): the lattice no longer fits the register files.  A workgroup takes a rectangle of
-// tiles, 8 block columns (one per wave) x up to 5 block rows, and works through it in ROUNDS: in round r wave v
+// BIG (4096 < n <= ~11400, U = 32): the lattice no longer fits the register files.  A workgroup takes a rectangle of
+// tiles, 8 block columns (one per wave) x up to 8 block rows, and works through it in ROUNDS: in round r wave v
 // handles tile (I0 + r, J0 + v) -- the first one from its registers as before, the others streamed (tl_stream_pass);
 // diagonal tiles are streamed tiles with the validity mask i < j.  A wave's tiles share their block column, so its
 // column sums stay in registers over the rounds; its row vectors are folded after every round (two workgroup
@@ -554,10 +556,11 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     constexpr bool BIG = BIGV != 0, NT = BIGV == 2;
     constexpr int ZEV = RoundsSplit<NORMS>::ZEV, ZLN = RoundsSplit<NORMS>::ZLN, WRG = BIG ? RoundsSplit<NORMS>::WRG : WRG_NONE;
     static_assert(!BIG || U == SLOTS, "rounds work on whole tiles");
-    constexpr int ZRES = U == SLOTS ? SLOTS / 2 : U;  // LDS-resident row pairs of z per chunk
+    // LDS-resident row pairs of z per chunk (rounds: a slice of RoundsSplit::SLICE row pairs shared by z and w)
+    constexpr int ZRES = BIGV != 0 ? RoundsSplit<NORMS>::SLICE : (U == SLOTS ? SLOTS / 2 : U);
     constexpr int NS = U - ZRES;                      // streamed ones
     __shared__ double2 s_z[TW][ZRES][64];             // up to 128 KiB
-    __shared__ double2 s_node[NBW][TB];               // {d, pbar} (x gamma: GL_TILE_FAST_ARITH) of the node blocks this workgroup touches
+    __shared__ double2 s_node[BIGV != 0 ? NBW : NBW_FIT][TB];  // {d, pbar} (x gamma: GL_TILE_FAST_ARITH) of the node blocks this workgroup touches
     __shared__ double s_part[TW][4][TB];              // per chunk: row p, row w, column p, column w (owner phase: s_own)
     __shared__ double s_dual[4][TB];                  // owner workgroups: d, ybar, pbar, d of the previous iteration
     __shared__ double s_bn[4];                        // ... and the norm partials of its last update
@@ -1443,10 +1446,14 @@ static int tile_finish(gl_logdeg *s, std::vector<WaveDesc> &wd, std::vector<WgDe
 // R rows, R the smallest number of rounds with which the chip's workgroups cover the lattice (R + 8 <= NBW node
 // blocks per workgroup).  Wave v of a workgroup takes column J = 8 t + v: tiles (I, J), I = I0 .. min(I0 + R - 1, J).
 static int tile_prepare_rounds(gl_logdeg *s) {
+    auto why = [&](int code) {  // (GRAPHLEARN_AMD_TILE_DEBUG: which condition sent the session to the streaming engine)
+        if (getenv("GRAPHLEARN_AMD_TILE_DEBUG")) fprintf(stderr, "[tile] rounds do not apply to n = %lld: condition %d\n", (long long)s->dev.n, code);
+        return GL_OK;
+    };
     gl_ctx *ctx = s->ctx;
     const LogdegDev &D = s->dev;
     const int ncu = ctx->prop.multiProcessorCount, nb = (int)D.nb;
-    if ((int64_t)gl_num_tiles(D.n) * GL_TILE_ELEMS * 8 >= (int64_t)1 << 32) return GL_OK;  // (32-bit byte offsets in the streamed pass)
+    if ((int64_t)gl_num_tiles(D.n) * GL_TILE_ELEMS * 8 >= (int64_t)1 << 32) return why(1);  // (32-bit byte offsets in the streamed pass)
     // strips: a narrow first one (nb mod 8 columns, at the short end of the lattice), then 8 columns each
     std::vector<int> sc0, sc1;
     for (int c = 0; c < nb;) {
@@ -1464,7 +1471,7 @@ static int tile_prepare_rounds(gl_logdeg *s) {
             break;
         }
     }
-    if (R == 0) return GL_OK;  // too large for one rectangle per workgroup: the streaming engine serves it
+    if (R == 0) return why(2);  // too large for one rectangle per workgroup: the streaming engine serves it
     // groups per strip; the workgroups left over go, one at a time, to the strip with the most rows per group (more
     // tiles in registers, fewer streamed)
     std::vector<int> grp((size_t)nstrips);
@@ -1481,7 +1488,7 @@ static int tile_prepare_rounds(gl_logdeg *s) {
             ++grp[(size_t)best];
         }
     NWG = std::max(NWG, nb);  // every node block needs an owner
-    if (NWG > ncu || NWG > 64 * nb) return GL_OK;
+    if (NWG > ncu || NWG > 64 * nb) return why(3);
     std::vector<WaveDesc> wd((size_t)NWG * TW);
     std::vector<WgDesc> gd((size_t)NWG);
     for (WaveDesc &w : wd) {
@@ -1510,14 +1517,14 @@ static int tile_prepare_rounds(gl_logdeg *s) {
                 w.I = I0;
                 w.J = J;
                 w.nr = std::min(I1 - I0, J - I0 + 1);
-                if (w.nr > 8) return GL_OK;
+                if (w.nr > 8) return why(4);
                 if (I0 < J) w.tile = (int)gl_tile_id(I0, J, nb);  // round 0 from the registers
                 w.sj = slot_of(J);
-                if (w.sj < 0) return GL_OK;
+                if (w.sj < 0) return why(5);
                 G.colmask[w.sj] |= 1 << v;
                 for (int r = 0; r < w.nr; ++r) {
                     const int sl = slot_of(I0 + r);
-                    if (sl < 0) return GL_OK;
+                    if (sl < 0) return why(6);
                     if (r == 0) w.si = sl;
                     w.rs |= sl << (4 * r);
                     (r < 4 ? G.rowmask[sl] : G.rowmask2[sl]) |= (int)(1u << (8 * (r & 3) + v));
@@ -1637,7 +1644,7 @@ int gl_tile_prepare(gl_logdeg *s) {
         auto slot_of = [&](int B) -> int {
             for (int k = 0; k < G.nblk; ++k)
                 if (G.blk[k] == B) return k;
-            if (G.nblk >= NBW) return -1;
+            if (G.nblk >= NBW_FIT) return -1;
             G.blk[G.nblk] = B;
             return G.nblk++;
         };

@@ -422,12 +422,13 @@ def test_just_past_the_register_files_against_oracle(engine, n):
     assert rel[0] == pytest.approx(info["rel"][0], rel=1e-9) and rel[1] == pytest.approx(info["rel"][1], rel=1e-9)
 
 
-def test_rounds_of_the_tile_engine_in_converge_mode_against_the_streaming_engine(engine, monkeypatch):
-    """n = 5000 (ragged, 3 rounds): run to tol on the tile engine and on the streaming engine (itself checked against
-    the oracle above): same stopping iteration, same ratios, same iterate; and a second call continues the first."""
+@pytest.mark.parametrize("n", [5000, 9300])
+def test_rounds_of_the_tile_engine_in_converge_mode_against_the_streaming_engine(engine, monkeypatch, n):
+    """n = 5000 (ragged, 3 rounds) and n = 9300 (ragged, 7 rounds, 15 node blocks per workgroup): run to tol on the tile
+    engine and on the streaming engine (itself checked against the oracle above): same stopping iteration, same ratios,
+    same iterate; and a second call continues the first."""
     if engine != "resident":
         pytest.skip("compares the two engines itself")
-    n = 5000
     z = np.random.default_rng(n).uniform(0.05, 3.0, size=n * (n - 1) // 2)
     out = {}
     for eng in ("stream", "resident"):

@@ -1,4 +1,4 @@
-"""Randomised sweep of the tile engine's rounds (n > 4096) against the streaming engine: random sizes (ragged and not),
+"""Randomised sweep of the tile engine's rounds (n > 4096) against the streaming engine: random sizes 4097 .. 11200 (ragged and not),
 parameters, warm starts, sparse distance patterns, resumed calls, fixed-iteration and converge mode.
 usage: python tools/fuzz_rounds.py [seconds=120] [seed=0].  Exit code 1 on the first mismatch."""
 import os, sys, time
@@ -12,7 +12,7 @@ t_end = time.time() + budget
 ctx = _lib.default_context()
 cases = 0
 while time.time() < t_end:
-    n = int(rng.integers(4097, 8705)) if rng.uniform() < 0.7 else int(rng.choice([4097, 4160, 4161, 4224, 4608, 5120, 6144, 6145, 8191, 8192, 8193, 8704]))
+    n = int(rng.integers(4097, 11201)) if rng.uniform() < 0.7 else int(rng.choice([4097, 4160, 4161, 4224, 4608, 5120, 6144, 6145, 8191, 8192, 8193, 8704, 8705, 9000, 10240, 11200]))
     e = n * (n - 1) // 2
     z = rng.uniform(0.05, 4.0, size=e)
     if rng.uniform() < 0.4:
