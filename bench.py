@@ -70,8 +70,8 @@ def other_configs(ctx):
     They are reported under config.other_configs and are NOT the graded `value`.
 
     lgmrf      BASELINE configs[2]: LGMRF n=2048, d=512 (S = X'X/d, X ~ N(0, (L+I)^-1)): node updates 64..191 of the
-               block-coordinate descent (lgmrf.py:175-219), timed through the C ABI as the difference of two fits capped
-               by GRAPHLEARN_AMD_LGMRF_MAX_NODES; every QP runs its 100 ADMM steps on this input.
+               block-coordinate descent (lgmrf.py:175-219), timed through the C ABI between HIP events
+               (gl_lgmrf_time_node_updates); every QP runs its 100 ADMM steps on this input.
     graphdict  BASELINE configs[4]: GraphDictLog K=8, n=1024, T=4096: ms per primal-dual step, fp64 (what the reference
                computes) and fp32 contractions (what the config names).
     logmodel_n8192  the headline loop on a lattice four times as large (SURVEY section 8 row d quotes the roofline for
@@ -111,17 +111,13 @@ def other_configs(ctx):
         lap = er_laplacian(n, 6.0 / n, 0.3, 2.0, seed=rng)
         xs = solve_triangular(np.linalg.cholesky(lap + np.eye(n)), rng.standard_normal((n, d)), lower=True, trans="T").T
         cov = xs.T @ xs / d
-        def capped(nodes_cap):  # one block-coordinate cycle capped at `nodes_cap` node updates (transfers and set-up included)
-            os.environ["GRAPHLEARN_AMD_LGMRF_MAX_NODES"] = str(nodes_cap)
-            t0 = time.perf_counter()
-            LGMRF(max_cycle=1).fit(cov, ctx=ctx)
-            return time.perf_counter() - t0
-        capped(8)                                        # code objects loaded
-        # node updates 64 .. 191 of the cycle (the first ones meet a still diagonal Theta and their QPs stop early)
+        from graph_learning_amd.lgmrf import time_node_updates
+        # node updates 64 .. 191 of the first cycle (the first ones meet a still diagonal Theta and their QPs stop early),
+        # between HIP events on the stream, through a measurement entry point of its own (the public fit cannot be cut short)
         lo, hi = 64, 192
-        dt = capped(hi) - capped(lo)
+        time_node_updates(cov, 0, 8, ctx=ctx)            # code objects loaded
+        dt = time_node_updates(cov, lo, hi - lo, ctx=ctx)
         nodes = hi - lo
-        del os.environ["GRAPHLEARN_AMD_LGMRF_MAX_NODES"]
         m = n - 1
         out["lgmrf"] = {"workload": "LGMRF n=2048 d=512 (BASELINE configs[2]), block-coordinate node updates, fast path",
                         "node_updates_timed": nodes, "ms_per_node_update": dt * 1e3 / nodes, "node_updates_per_s": nodes / dt,
@@ -131,7 +127,6 @@ def other_configs(ctx):
                         "bound": "latency: 100 dependent ADMM steps per node update (DESIGN.md section 5)", "dtype": "f64"}
     except Exception as exc:
         out["lgmrf_error"] = repr(exc)
-        os.environ.pop("GRAPHLEARN_AMD_LGMRF_MAX_NODES", None)
     try:  # a lattice four times the headline's: what does not fit the register files streams (rounds)
         n = 8192
         e = n * (n - 1) // 2

@@ -82,6 +82,8 @@ SIGNATURES = {
                                      C.c_void_p, _c_int_p]),
     "gl_lgmrf_fit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_double,
                                C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _c_int_p, _c_int_p]),
+    "gl_lgmrf_time_node_updates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int,
+                                             C.c_void_p, C.c_int, C.c_int64, C.c_int64, _c_double_p]),
     "gl_graphdict_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "gl_graphdict_destroy": (None, [C.c_void_p]),
     "gl_graphdict_set_signals": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -118,13 +118,23 @@ __global__ __launch_bounds__(256) void k_gram(const double *__restrict__ x, int6
         for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) Ts[wave][(lane >> 4) + 4 * r][lane & 15] = acc[mi][ni][r];
+            // the patch is exchanged between the lanes of ONE wave: its stores are ordered before the transposed loads (and
+            // those before the next block's stores) explicitly, not by what the compiler happens to assume about aliasing
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double tv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tv[r] = Ts[wave][lane & 15][(lane >> 4) + 4 * r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 // row of the mirror image = a column of the block, column = one of its rows
                 const int64_t j = j0 + wn * 32 + ni * 16 + (lane >> 4) + 4 * r;
                 const int64_t i = i0 + wm * 32 + mi * 16 + (lane & 15);
-                const double v = Ts[wave][lane & 15][(lane >> 4) + 4 * r];
-                if (i < n && j < n) G[j * n + i] = v;
+                if (i < n && j < n) G[j * n + i] = tv[r];
             }
         }
 }

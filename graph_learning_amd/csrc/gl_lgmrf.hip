@@ -1949,11 +1949,18 @@ GL_API int gl_nonneg_qp_solve(gl_ctx *ctx, const double *mat, const double *vec,
 // LGMRF(norm_par, prob_tol, max_cycle, qp_step, qp_tol, regularization_type, adj_mask).fit(x)
 // for the generalized Laplacian set (lgmrf.py:228-235).  x is n x n (not modified).
 // path: 0 = automatic (fast when the mask is all ones / NULL), 1 = force general, 2 = force fast.
-GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par, double prob_tol, int max_cycle,
-                        double qp_step, double qp_tol, int regularization_type, const double *adj_mask, int path,
-                        double *laplacian_out, double *inv_laplacian_out, int *converged_out, int *cycles_out) {
+// probe_from / probe_to >= 0 (gl_lgmrf_time_node_updates only): ONE cycle is cut short after node update probe_to - 1 and
+// the updates probe_from .. probe_to - 1 are bracketed by HIP events on the stream; the matrices are then NOT a fit and
+// nothing is copied out.  The public fit always passes -1: no environment variable can truncate it.
+static int lgmrf_fit_impl(gl_ctx *ctx, const double *x, int64_t n, double norm_par, double prob_tol, int max_cycle,
+                          double qp_step, double qp_tol, int regularization_type, const double *adj_mask, int path,
+                          double *laplacian_out, double *inv_laplacian_out, int *converged_out, int *cycles_out,
+                          int64_t probe_from, int64_t probe_to, double *probe_seconds) {
     if (!ctx) return GL_E_INVALID;
-    if (!x || !laplacian_out || !inv_laplacian_out || n < 2) return gl_set_error(ctx, GL_E_INVALID, "bad argument");
+    const bool probe = probe_from >= 0;
+    if (!x || (!probe && (!laplacian_out || !inv_laplacian_out)) || n < 2) return gl_set_error(ctx, GL_E_INVALID, "bad argument");
+    if (probe && (probe_to <= probe_from || probe_to > n || !probe_seconds)) return gl_set_error(ctx, GL_E_INVALID, "bad probe range");
+    if (probe) max_cycle = 1;
     if (regularization_type != 1 && regularization_type != 2)
         return gl_set_error(ctx, GL_E_INVALID, "regularization type can be either 1 or 2, got %d", regularization_type);
     GL_HIP(ctx, hipSetDevice(ctx->device));
@@ -2038,7 +2045,7 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
     // A forced ADMM form (GRAPHLEARN_AMD_LGMRF_ADMM) or GRAPHLEARN_AMD_LGMRF_FUSED=0 keeps the launch path.
     {
         const char *fz = getenv("GRAPHLEARN_AMD_LGMRF_FUSED");
-        if (n <= 64 && !getenv("GRAPHLEARN_AMD_LGMRF_ADMM") && !(fz && !strcmp(fz, "0"))) {
+        if (!probe && n <= 64 && !getenv("GRAPHLEARN_AMD_LGMRF_ADMM") && !(fz && !strcmp(fz, "0"))) {
             const size_t lds = ((size_t)4 * n * (n + 1) + 9 * n) * 8;
             double *res = D.scal + 12;
             const int np = n <= 16 ? 16 : (n <= 32 ? 32 : 64);
@@ -2081,11 +2088,9 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
             k_lg_shift<<<g2, 256, 0, ctx->stream>>>(D.Th, D.G, n, D.rho);
             GL_TRY(invert_spd_inplace(ctx, D.G, n, pivrow));
         }
-        // measurement facility (bench.py's lgmrf leg): GRAPHLEARN_AMD_LGMRF_MAX_NODES caps the node updates of a cycle,
-        // so that a bounded sample of a BASELINE-size cycle can be timed; the result is then NOT a fit
-        int64_t u_end = n;
-        if (const char *e = getenv("GRAPHLEARN_AMD_LGMRF_MAX_NODES")) u_end = std::max<int64_t>(0, std::min<int64_t>(n, atoll(e)));
+        const int64_t u_end = probe ? probe_to : n;
         for (int64_t u = 0; u < u_end; ++u) {
+            if (probe && u == probe_from) GL_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
             k_lg_qp_setup<<<1, VT, 0, ctx->stream>>>(D, u);
             const bool fused_winv = fast && (ares.wave || ares.quad || (ares.on && ares.tagged));  // the ADMM kernel forms its rows of the inverse itself
             if (fused_winv) {
@@ -2113,6 +2118,13 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
             GL_HIP(ctx, hipGetLastError());
         }
         cycles = cycle + 1;
+        if (probe) {
+            float ms = 0;
+            GL_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+            GL_HIP(ctx, hipEventSynchronize(ctx->ev1));
+            GL_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            *probe_seconds = (double)ms * 1e-3;
+        }
         if (ares.on) {  // error word of the persistent ADMM launches of this cycle
             double flag = 0;
             GL_HIP(ctx, hipMemcpyAsync(&flag, D.scal + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -2141,10 +2153,30 @@ GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par
             GL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // bound the launch queue
         }
     }
-    GL_TRY(gl_d2h(ctx, laplacian_out, D.Th, nn));
-    GL_TRY(gl_d2h(ctx, inv_laplacian_out, D.C, nn));
+    if (!probe) {
+        GL_TRY(gl_d2h(ctx, laplacian_out, D.Th, nn));
+        GL_TRY(gl_d2h(ctx, inv_laplacian_out, D.C, nn));
+    }
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (converged_out) *converged_out = converged;
     if (cycles_out) *cycles_out = cycles;
     return GL_OK;
+}
+
+GL_API int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n, double norm_par, double prob_tol, int max_cycle,
+                        double qp_step, double qp_tol, int regularization_type, const double *adj_mask, int path,
+                        double *laplacian_out, double *inv_laplacian_out, int *converged_out, int *cycles_out) {
+    return lgmrf_fit_impl(ctx, x, n, norm_par, prob_tol, max_cycle, qp_step, qp_tol, regularization_type, adj_mask, path,
+                          laplacian_out, inv_laplacian_out, converged_out, cycles_out, -1, -1, nullptr);
+}
+
+// Measurement only (bench.py's LGMRF leg, tools/): the node updates first_node .. first_node + count - 1 of the FIRST
+// block-coordinate cycle (lgmrf.py:175-219), timed with HIP events on the context's stream.  Produces no matrices.
+GL_API int gl_lgmrf_time_node_updates(gl_ctx *ctx, const double *x, int64_t n, double norm_par, double qp_step, double qp_tol,
+                                      int regularization_type, const double *adj_mask, int path, int64_t first_node,
+                                      int64_t count, double *seconds_out) {
+    if (!ctx) return GL_E_INVALID;
+    if (first_node < 0 || count < 1) return gl_set_error(ctx, GL_E_INVALID, "bad node range");
+    return lgmrf_fit_impl(ctx, x, n, norm_par, 0.0, 1, qp_step, qp_tol, regularization_type, adj_mask, path, nullptr, nullptr,
+                          nullptr, nullptr, first_node, first_node + count, seconds_out);
 }

@@ -69,6 +69,9 @@
 //    streaming and the small engine always compute that way).
 #define GL_TILE_FAST_ARITH 1
 #endif
+#ifndef GL_TILE_EXACT_HEAD
+#define GL_TILE_EXACT_HEAD 3  // the stopping rule is evaluated exactly (no lag) for this many iterations at the start of a call
+#endif
 #ifndef GL_TILE_MIN_BULK_TILES
 #define GL_TILE_MIN_BULK_TILES 3
 #endif
@@ -573,6 +576,10 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     const int wg = blockIdx.x;
     const int half = lane >> 5, c0 = 2 * (lane & 31), lofs = half * TB + c0;
     if (P.ctr[4] != 0) return;  // an earlier launch of this session failed and has not been looked at yet
+    // development (GRAPHLEARN_AMD_RES_STAMPS): where a CALL spends its time -- entry, loads done, rendezvous, first and last
+    // iteration, write-back (the waits that make the stamps meaningful exist only in stamped runs)
+    unsigned long long cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (P.dbg) cs[0] = __builtin_amdgcn_s_memrealtime();
 
     const WaveDesc wdv = P.wd[wg * TW + wave];
     // the workgroup's descriptor: lane l keeps words l and 64 + l, wave-uniform reads go through v_readlane
@@ -698,6 +705,10 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     // ---- start-up rendezvous: every workgroup of the grid is on the chip, or nobody touches anything.  The arrival
     //      counter is monotonic over the launches of the session (target = arrivals so far + grid), so nothing has to be
     //      reset between launches: the launch is the only thing on the stream.
+    if (P.dbg) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        cs[1] = __builtin_amdgcn_s_memrealtime();
+    }
     if (tid == 0) {
         const GlGridBar gb{P.bar, 0};
         __hip_atomic_fetch_add(P.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -708,6 +719,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     }
     __syncthreads();
     const bool met = s_flag[0] != 0;
+    if (P.dbg) cs[2] = __builtin_amdgcn_s_memrealtime();
     if (met && !active) return;  // nothing to do here: no edges, no node block (nobody waits for this workgroup)
     bool failed = !met;
     int done_iters = 0, stopped = 0;
@@ -835,7 +847,10 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 double b[4] = {0, 0, 0, 0};
                 int stop = 0;
                 double rp = INFINITY, rd = INFINITY;
-                bool now_exact = exact || last_pass;
+                // The first iterations of every call are judged exactly too: a call that starts from a converged or nearly
+                // converged iterate (edge_init, a resumed session) drops below tol at once, with no older record to warn of it
+                bool sticky = exact;
+                bool now_exact = exact || last_pass || it <= GL_TILE_EXACT_HEAD;
                 if (!now_exact && it >= 2) {
                     // what the early look of iteration it - 1 found (one workgroup takes it for all, below; its record has been
                     // on its way for a whole hand-off): -1 failed, 1 below tol, 2 within 25 % of it
@@ -857,7 +872,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     const int look = good ? (int)lane_bcast(mine, 0) : -1;
                     good = good && look >= 0;
                     if (look == 1) stop = 1, rp = lane_bcast(mine, 1), rd = lane_bcast(mine, 2);  // (a jump straight below tol: seen one iteration late)
-                    if (look == 2) now_exact = true;
+                    if (look == 2) now_exact = sticky = true;
                 }
                 if (now_exact && !stop) {
                     good = good && norms_of(it - 1, b);
@@ -867,12 +882,13 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                         rd = sqrt(b[2]) / sqrt(b[3]);
                     }
                     stop = (itp >= 1 && rp < P.tol && rd < P.tol) ? 1 : 0;
+                    if (itp >= 1 && rp < 1.25 * P.tol && rd < 1.25 * P.tol) sticky = true;  // (the screen's threshold)
                 }
                 if (lane == 0) {
                     s_rel[0] = rp;
                     s_rel[1] = rd;
                     s_flag[2] = stop;
-                    s_flag[3] = now_exact ? 1 : 0;
+                    s_flag[3] = (sticky ? 1 : 0) | (now_exact ? 2 : 0);
                 }
             }
             if (!good) s_flag[1] = 1;
@@ -883,8 +899,8 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             break;
         }
         if (want_rule) {
-            exact = s_flag[3] != 0;
-            if (exact || s_flag[2]) {  // (a look at older records only reports when it stops the run)
+            exact = (s_flag[3] & 1) != 0;
+            if ((s_flag[3] & 2) || s_flag[2]) {  // (a look at older records only reports when it stops the run)
                 rel_p = s_rel[0];
                 rel_d = s_rel[1];
                 evaluated = true;
@@ -1274,6 +1290,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 s_part[wave][1][lane] = 0.0;
             }
         }
+        if (P.dbg && it == 0) cs[3] = __builtin_amdgcn_s_memrealtime();  // end of the first iteration
         if (stamp && tid == 0) {
             ts[5] = __builtin_amdgcn_s_memrealtime();
             unsigned long long *o = P.dbg + ((size_t)wg * 16 + (it - 8)) * 6;
@@ -1283,12 +1300,16 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
 
     if (failed) {  // nothing of the session's state has been written
         if (wg == 0 && tid == 0) {
+            // where the session stood: ctr[1] for gl_resident_finish (synchronous calls), ctr[2] for resident_check
+            // (asynchronous ones).  ctr[1] may hold anything here -- the streaming engine re-arms it to 0 after its calls
+            P.ctr[1] = P.it0;
             P.ctr[2] = P.it0;
             P.ctr[4] = met ? 2 : 1;  // 1: the workgroups never met; 2: a hand-off was lost in mid-run
         }
         return;
     }
     // ---- registers back to the iterate buffer, dual state back to memory, bookkeeping for the host / the other engines
+    if (P.dbg) cs[4] = __builtin_amdgcn_s_memrealtime();
     if (has) {
         const int64_t tb = (int64_t)wdv.tile * GL_TILE_ELEMS + (int64_t)a0 * (2 * TB) + lofs;
 #pragma unroll
@@ -1304,6 +1325,14 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         P.pbar[own_i] = s_dual[2][lane];
         P.dprev[own_i] = s_dual[3][lane];
         if (lane < 4) P.bnorm[((P.it0 + done_iters - 1) & 1) * 4 * P.nb + 4 * own + lane] = s_bn[lane];
+    }
+    if (P.dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cs[5] = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            unsigned long long *o = P.dbg + (size_t)P.NWG * 16 * (6 + 2 * TW) + ((size_t)wg * TW + wave) * 8;
+            for (int q = 0; q < 6; ++q) o[q] = cs[q];
+        }
     }
     if (wg == 0 && tid == 0) {
         const long long itf = P.it0 + done_iters;
@@ -1429,8 +1458,8 @@ static int tile_finish(gl_logdeg *s, std::vector<WaveDesc> &wd, std::vector<WgDe
         if (const char *e = getenv("GRAPHLEARN_AMD_TILE_NT")) t->nt = atoi(e) != 0;
     }
     P.dbg = nullptr;
-    if (getenv("GRAPHLEARN_AMD_RES_STAMPS") && hipMalloc((void **)&t->dbg, (size_t)NWG * 16 * (6 + 2 * TW) * 8) == hipSuccess) {
-        (void)hipMemset(t->dbg, 0, (size_t)NWG * 16 * (6 + 2 * TW) * 8);
+    if (getenv("GRAPHLEARN_AMD_RES_STAMPS") && hipMalloc((void **)&t->dbg, (size_t)NWG * (16 * (6 + 2 * TW) + 8 * TW) * 8) == hipSuccess) {
+        (void)hipMemset(t->dbg, 0, (size_t)NWG * (16 * (6 + 2 * TW) + 8 * TW) * 8);
         P.dbg = t->dbg;
         int maxblk = 0;
         for (const WgDesc &G : gd) maxblk = std::max(maxblk, G.nblk);
@@ -1727,8 +1756,30 @@ int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms) {
 void gl_tile_dump_stamps(gl_logdeg *s) {
     if (!s || !s->tile || !s->tile->dbg) return;
     const int NWG = s->tile->dev.NWG, nb = (int)s->tile->dev.nb;
-    std::vector<unsigned long long> h((size_t)NWG * 16 * (6 + 2 * TW));
+    std::vector<unsigned long long> h((size_t)NWG * (16 * (6 + 2 * TW) + 8 * TW));
     (void)hipMemcpy(h.data(), s->tile->dbg, h.size() * 8, hipMemcpyDeviceToHost);
+    {  // the call as a whole (100 MHz ticks -> us), relative to the earliest entry of any wave
+        const unsigned long long *cw = h.data() + (size_t)NWG * 16 * (6 + 2 * TW);
+        unsigned long long t0 = ~0ull;
+        for (int v = 0; v < NWG * TW; ++v)
+            if (cw[(size_t)v * 8]) t0 = std::min(t0, cw[(size_t)v * 8]);
+        double mean[6] = {0}, last[6] = {0};
+        long cnt = 0;
+        for (int v = 0; v < NWG * TW; ++v) {
+            const unsigned long long *o = cw + (size_t)v * 8;
+            if (!o[0] || !o[5]) continue;
+            ++cnt;
+            for (int q = 0; q < 6; ++q) {
+                const double d = (double)(o[q] - t0) / 100.0;
+                mean[q] += d, last[q] = std::max(last[q], d);
+            }
+        }
+        if (cnt)
+            fprintf(stderr, "[tile call stamps] us after the first wave's entry, mean / latest wave: entry %.1f / %.1f  loads done %.1f / %.1f  "
+                            "rendezvous %.1f / %.1f  first iteration done %.1f / %.1f  loop done %.1f / %.1f  stored %.1f / %.1f\n",
+                    mean[0] / cnt, last[0], mean[1] / cnt, last[1], mean[2] / cnt, last[2], mean[3] / cnt, last[3], mean[4] / cnt, last[4],
+                    mean[5] / cnt, last[5]);
+    }
     {  // per-wave pass durations: mean, and mean over workgroups of (slowest - fastest wave of the workgroup)
         const unsigned long long *pw = h.data() + (size_t)NWG * 16 * 6;
         double sum = 0, skew = 0, mx = 0, first_last = 0;

@@ -111,3 +111,18 @@ class LGMRF(BaseEstimator):
         self.converged_ = conv.value
         self.n_cycles_ = cyc.value
         return self
+
+
+def time_node_updates(x, first_node: int, count: int, *, norm_par=1.0, qp_step=0.1, qp_tol=1e-6, regularization_type=1,
+                      adj_mask=None, path: int = 0, ctx=None) -> float:
+    """Measurement only (bench.py, tools/): seconds the node updates ``first_node .. first_node + count - 1`` of the first
+    block-coordinate cycle (reference lgmrf.py:175-219) take on the device (HIP events on the context's stream).
+    Returns no matrices; :meth:`LGMRF.fit` itself cannot be truncated."""
+    x = _lib.as_f64(x)
+    c = ctx or _lib.default_context()
+    mask = None if adj_mask is None else _lib.as_f64(adj_mask)
+    out = C.c_double(0.0)
+    c.check(c._lib.gl_lgmrf_time_node_updates(c.handle, _lib.ptr(x), x.shape[0], float(norm_par), float(qp_step),
+                                              float(qp_tol), int(regularization_type), _lib.ptr(mask), int(path),
+                                              int(first_node), int(count), C.byref(out)), "time_node_updates")
+    return out.value

@@ -214,6 +214,12 @@ int gl_nonneg_qp_solve(gl_ctx *ctx, const double *mat, const double *vec, int64_
 int gl_lgmrf_fit(gl_ctx *ctx, const double *x, int64_t n_nodes, double norm_par, double prob_tol, int max_cycle,
                  double qp_step, double qp_tol, int regularization_type, const double *adj_mask, int path,
                  double *laplacian_out, double *inv_laplacian_out, int *converged_out, int *cycles_out);
+/* Measurement only (no reference counterpart; bench.py's LGMRF leg): seconds the node updates first_node ..
+ * first_node + count - 1 of the FIRST block-coordinate cycle (lgmrf.py:175-219) take on the device, between HIP
+ * events on the context's stream.  Nothing is returned but the time; gl_lgmrf_fit itself cannot be truncated. */
+int gl_lgmrf_time_node_updates(gl_ctx *ctx, const double *x, int64_t n_nodes, double norm_par, double qp_step,
+                               double qp_tol, int regularization_type, const double *adj_mask, int path,
+                               int64_t first_node, int64_t count, double *seconds_out);
 
 /* ---- graph dictionary with log-barrier degrees (graph_learn/dictionary/log_model.py:14-50 over
  * dictionary/base_model.py:355-676) -- SURVEY.md section 8 row f-1 ---------------------------

@@ -13,6 +13,12 @@ Versions used: see the ``versions`` entry written into every file.
 import os
 import sys
 
+# ONE BLAS / OpenMP thread: numpy.linalg.inv and the matrix products of the reference (lgmrf.py:53-60) sum in an order
+# that depends on the thread count, and on the ill-conditioned lgmrf_c3 input that moves the reference's own result
+# (measured below and stored as *_thread_sensitivity).  Recorded in every file's `versions`.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ[_v] = "1"
+
 import numpy as np
 import scipy
 from numpy.random import default_rng
@@ -31,7 +37,7 @@ from graph_learn.temporal.smooth import WindowLogModel  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 VERS = np.array([f"numpy {np.__version__}", f"scipy {scipy.__version__}",
-                 "reference LTS4/graph-learning @ 2024-12-20"])
+                 "reference LTS4/graph-learning @ 2024-12-20", "BLAS/OpenMP threads 1"])
 
 
 def save(name, **arrays):
@@ -375,6 +381,15 @@ def gen_lgmrf_c3():
         m = ref_lgmrf.LGMRF(max_cycle=cycles).fit(cov.copy())
         iu = np.triu_indices(n)
         tag = f"n{n}"
+        # how far the REFERENCE itself moves on this input when only the BLAS thread count changes (1 -> 8): the tolerance
+        # of the tests that compare with this fixture is set from it (relative to the largest entry of each quantity)
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=8):
+            m8 = ref_lgmrf.LGMRF(max_cycle=cycles).fit(cov.copy())
+        rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
+        arrays[f"{tag}_thread_sensitivity"] = np.array([rel(m8.laplacian_, m.laplacian_), rel(m8.inv_laplacian_, m.inv_laplacian_)])
+        print(tag, "1 thread vs 8 threads: laplacian", arrays[f"{tag}_thread_sensitivity"][0], "inverse",
+              arrays[f"{tag}_thread_sensitivity"][1], flush=True)
         arrays[f"{tag}_x32"] = x32
         arrays[f"{tag}_cycles"] = np.int64(cycles)
         arrays[f"{tag}_cov_mean"] = np.float64(cov.mean())

@@ -179,8 +179,10 @@ def test_lgmrf_c3_shape_n512_against_reference_fixture(golden, admm_form, path):
     mean(S) = 2e-3), n = 512, two cycles of lgmrf.py:169-226 -- against the matrices the REFERENCE produced
     (tests/golden/make_golden.py::gen_lgmrf_c3).  On this input every QP runs its 100 ADMM steps and the
     iterate grows (max|Theta| = 22.58 after two cycles): the comparison is relative to that scale, and the
-    tolerance is 1e-6 because the input amplifies rounding (NumPy itself moves by 2e-9 relative when only the
-    BLAS thread count changes, tests/test_oracle_golden.py)."""
+    tolerance follows from the measured sensitivity of the REFERENCE on this input: the fixture (made with ONE BLAS
+    thread, recorded in its `versions`) stores how far the reference's own result moves when only the thread count
+    changes to 8 (n512_thread_sensitivity = 3.2e-9 of max|Theta|); the device path sums in yet another order
+    (wave-wide butterflies, 100 ADMM steps x 512 nodes x 2 cycles) and is held to 300 x that = 1e-6."""
     if admm_form not in LARGE_FORMS:
         pytest.skip("single-wave / single-workgroup forms end at n = 160")
     if path == 1 and admm_form != "auto":
@@ -192,11 +194,14 @@ def test_lgmrf_c3_shape_n512_against_reference_fixture(golden, admm_form, path):
     m = LGMRF(max_cycle=int(g["n512_cycles"])).fit(cov.copy(), path=path)
     ref = triu_to_square(g["n512_lapl_triu"], n)
     scale = np.abs(ref).max()
-    assert scale == pytest.approx(22.578421533059075, rel=1e-12)
+    assert scale == pytest.approx(22.578421555988328, rel=1e-12)
     assert m.converged_ == int(g["n512_conv"]) == -1 and m.n_cycles_ == 2
+    sens = float(g["n512_thread_sensitivity"][0])
+    assert 1e-9 < sens < 1e-8
     err = np.abs(m.laplacian_ - ref).max() / scale
-    print(f"[lgmrf c3 n=512 form={admm_form} path={path}] max|Theta - ref| / max|ref| = {err:.2e}")
-    assert err < 1e-6
+    print(f"[lgmrf c3 n=512 form={admm_form} path={path}] max|Theta - ref| / max|ref| = {err:.2e} "
+          f"(reference, 1 vs 8 BLAS threads: {sens:.1e})")
+    assert err < 300 * sens
     rows = g["n512_rows"]
     assert np.abs(m.inv_laplacian_[rows] - g["n512_inv_rows"]).max() <= 1e-6 * np.abs(g["n512_inv_rows"]).max()
     assert np.abs(np.diag(m.inv_laplacian_) - g["n512_inv_diag"]).max() <= 1e-6 * np.abs(g["n512_inv_diag"]).max()
@@ -206,7 +211,11 @@ def test_lgmrf_c3_shape_n512_against_reference_fixture(golden, admm_form, path):
 def test_lgmrf_c3_shape_n1024_blow_up_matches_reference(golden, admm_form):
     """n = 1024, d = 256, ONE cycle: the reference itself diverges on this input (max|Theta| = 1.5348e4 after
     the cycle, fixture made by the reference in 85 s); the device path reproduces diagonal, sampled rows,
-    Frobenius norm and maximum.  This is the evidence for DESIGN.md section 5 ("C3 as specified is ill-posed")."""
+    Frobenius norm and maximum.  This is the evidence for DESIGN.md section 5 ("C3 as specified is ill-posed").
+    Tolerance: the fixture (ONE BLAS thread) records that the reference's own Theta moves by 9.7e-7 of max|Theta| and
+    its inverse by 1.7e-6 of max|C| when only the thread count changes to 8 (n1024_thread_sensitivity); the device
+    path is held to 20 x those figures (2e-5 / 3.5e-5), relative to the same maxima (the sampled rows hold the
+    largest entries of both matrices)."""
     if admm_form != "auto":
         pytest.skip("once, on the default form")
     g = golden("lgmrf_c3")
@@ -214,16 +223,22 @@ def test_lgmrf_c3_shape_n1024_blow_up_matches_reference(golden, admm_form):
     assert cov.mean() == float(g["n1024_cov_mean"])
     m = LGMRF(max_cycle=1).fit(cov.copy())
     scale = float(g["n1024_lapl_absmax"])
-    assert scale == pytest.approx(15348.155995583951, rel=1e-12)
+    assert scale == pytest.approx(15348.149994978496, rel=1e-12)
     assert m.converged_ == -1 and m.n_cycles_ == 1
+    s_th, s_inv = (float(v) for v in g["n1024_thread_sensitivity"])
+    assert 3e-7 < s_th < 3e-6 and 5e-7 < s_inv < 5e-6
+    tol_th, tol_inv = 20 * s_th, 20 * s_inv
     rows = g["n1024_rows"]
     e_rows = np.abs(m.laplacian_[rows] - g["n1024_lapl_rows"]).max() / scale
     e_diag = np.abs(np.diag(m.laplacian_) - g["n1024_lapl_diag"]).max() / scale
-    print(f"[lgmrf c3 n=1024] rows {e_rows:.2e} diag {e_diag:.2e} (relative to max|Theta| = {scale:.6g})")
-    assert e_rows < 1e-5 and e_diag < 1e-5        # 1.5e4-fold growth in one cycle: rounding is amplified accordingly
-    assert np.abs(m.laplacian_).max() == pytest.approx(scale, rel=1e-5)
-    assert np.linalg.norm(m.laplacian_) == pytest.approx(float(g["n1024_lapl_fro"]), rel=1e-5)
-    assert np.abs(m.inv_laplacian_[rows] - g["n1024_inv_rows"]).max() <= 1e-5 * np.abs(g["n1024_inv_rows"]).max()
+    inv_scale = np.abs(m.inv_laplacian_).max()
+    e_inv = np.abs(m.inv_laplacian_[rows] - g["n1024_inv_rows"]).max() / inv_scale
+    print(f"[lgmrf c3 n=1024] Theta rows {e_rows:.2e} diag {e_diag:.2e} (of max|Theta| = {scale:.6g}; reference 1 vs 8 threads "
+          f"{s_th:.1e}); C rows {e_inv:.2e} (of max|C| = {inv_scale:.4g}; reference {s_inv:.1e})")
+    assert e_rows < tol_th and e_diag < tol_th     # 1.5e4-fold growth in one cycle: rounding is amplified accordingly
+    assert np.abs(m.laplacian_).max() == pytest.approx(scale, rel=tol_th)
+    assert np.linalg.norm(m.laplacian_) == pytest.approx(float(g["n1024_lapl_fro"]), rel=tol_th)
+    assert e_inv < tol_inv
 
 
 def test_lgmrf_c3_full_size_one_cycle_properties(admm_form):

@@ -482,3 +482,99 @@ def test_large_lattice_n8192_against_dense_restatement(engine):
         w, dd = s.weights_condensed(), s.dual()
     np.testing.assert_allclose(w, wm[iu], rtol=0, atol=1e-12)
     np.testing.assert_allclose(dd, d, rtol=0, atol=1e-11)
+
+
+# ------------------------------------------------------------------ the instantiations bench.py times
+def test_c2_size_timed_instantiation_against_oracle(engine):
+    """bench.py times gl_logdeg_iterate_async -> k_tile<32, false, false, 0> (the variant WITHOUT the norms of the
+    stopping rule) at n=4096, d=1024; the driver runs it as `--steps 20`.  Exactly that: two asynchronous calls of 20
+    iterations against 40 iterations of the oracle (smooth_learning.py:146-167), w and the dual variable to 1e-10."""
+    if engine != "resident":
+        pytest.skip("the tile engine's asynchronous variant")
+    x, _ = logmodel_problem(4096, 1024, seed=2)
+    z_ref = old.signal_distances(x)
+    zt = z_ref * old.theta_for_degree(squareform(z_ref), 10)
+    with _lib.LogDegreeSession(4096) as s:
+        s.set_distances(zt)
+        s.init(1, 1, 0.5, None)
+        assert s.engine == "resident" and s.engine_kernel == "k_tile"
+        s.iterate_async(20)
+        s.iterate_async(20)
+        assert s.total_iterations == 40
+        w = s.weights_condensed()
+        d = s.dual()
+        assert s.engine == "resident"          # no fall-back happened: the tile engine produced these
+    _, info = old.learn_log_degrees(zt, 1, 1, maxit=40, tol=0.0, edge_tol=-np.inf, return_info=True)
+    np.testing.assert_allclose(w, info["raw"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(d, info["dual"], rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("n,iters", [(4096, 2000), (8192, 48), (3000, 301), (2048, 500), (1030, 333)])
+def test_async_variant_equals_synchronous_variant_bit_for_bit(engine, n, iters):
+    """The asynchronous calls run the kernel variant without the stopping rule's norms, the synchronous ones the variant
+    with them: the iterate's arithmetic is the same, so from the same start the results are EQUAL (not close).  Sizes:
+    the BASELINE lattice (U = 32, everything in registers), n = 8192 (rounds, non-temporal streams:
+    k_tile<32,false,false,2>), and one lattice per shorter chunk length (ragged / U = 16 / U = 8)."""
+    if engine != "resident":
+        pytest.skip("tile engine only")
+    z = np.random.default_rng(n).uniform(0.05, 3.0, size=n * (n - 1) // 2)
+    out = []
+    for mode in ("async", "sync"):
+        with _lib.LogDegreeSession(n) as s:
+            s.set_distances(z)
+            s.init(1.0, 1.0, 0.5, None)
+            assert s.engine_kernel == "k_tile"
+            if mode == "async":
+                s.iterate_async(iters)
+            else:
+                n_it, conv, _ = s.iterate(iters, 0.0)
+                assert n_it == iters and not conv
+            out.append((s.weights_condensed(), s.dual()))
+            assert s.engine == "resident" and s.total_iterations == iters
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+
+
+def test_tile_engine_falls_back_after_the_session_has_advanced_on_the_streaming_engine(golden, engine, monkeypatch):
+    """a synchronous tile-engine call whose workgroups never meet must fall back to the streaming engine also
+    when the session has already advanced (a short call, < 16 iterations, runs on the streaming engine and leaves the
+    counters where a stale comparison would mistake the failure for a mid-run one)."""
+    if engine != "resident":
+        pytest.skip("tile engine only")
+    g = golden("logmodel_n64_d256")
+    zt = g["z"] * float(g["theta_deg6"])
+    monkeypatch.setenv("GRAPHLEARN_AMD_RES_TEST_NOT_RESIDENT", "1")
+    with _lib.LogDegreeSession(64) as s:
+        s.set_distances(zt)
+        s.init(1, 1, 0.5, None)
+        s.iterate(10, 0.0)                     # streaming engine (short call)
+        assert s.engine == "resident" and s.total_iterations == 10
+        n_it, conv, _ = s.iterate(40, 0.0)     # tile engine: rendezvous fails, nothing touched, streaming engine redoes it
+        assert n_it == 40 and not conv and s.engine == "stream" and s.total_iterations == 50
+        w = s.weights_condensed()
+    np.testing.assert_allclose(w, g["raw_w_it50"], rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("n", [100, 200, 700])
+def test_rule_that_fires_at_the_head_of_a_call_fires_at_the_same_iteration_on_every_engine(engine, monkeypatch, n):
+    """the tile engine looks at the stopping rule with a lag of one iteration while the ratios are far from
+    tol -- but never during the first iterations of a call, which it judges exactly.  With tol set just above the ratios of
+    iteration 1 (iteration 0 is never judged, smooth_learning.py:156-161; its ratios are inf, so this is the steepest drop
+    there is) every engine stops after exactly two iterations, as the reference's loop does."""
+    z = np.random.default_rng(n).uniform(0.05, 3.0, size=n * (n - 1) // 2)
+    monkeypatch.setenv("GRAPHLEARN_AMD_ENGINE", "stream")
+    with _lib.LogDegreeSession(n) as s:
+        s.set_distances(z)
+        s.init(1.0, 1.0, 0.5, None)
+        _, _, rel = s.iterate(2, 0.0)          # ratios of iteration 1
+    tol = 1.001 * max(rel)
+    res = {}
+    for eng in ("stream", engine):
+        monkeypatch.setenv("GRAPHLEARN_AMD_ENGINE", eng)
+        with _lib.LogDegreeSession(n) as s:
+            s.set_distances(z)
+            s.init(1.0, 1.0, 0.5, None)
+            res[eng] = s.iterate(1000, tol)[:2] + (s.weights_condensed(-np.inf),)
+    assert res["stream"][:2] == (2, True)
+    assert res[engine][:2] == (2, True)
+    np.testing.assert_allclose(res[engine][2], res["stream"][2], rtol=0, atol=1e-12)

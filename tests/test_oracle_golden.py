@@ -204,11 +204,14 @@ def test_lgmrf_oracle_c3_shape_n512_equals_reference(golden):
     o = olg.LGMRFOracle(max_cycle=2).fit(cov.copy())
     ref = g["n512_lapl_triu"]
     got = o.laplacian_[np.triu_indices(512)]
-    assert np.abs(ref).max() == pytest.approx(22.578421533059075, rel=1e-12)
-    # The input is ill-conditioned (K has a large negative eigenvalue), so rounding differences are amplified:
-    # the same NumPy with another BLAS thread count (4 at generation, the machine's default here) already
-    # moves the result by 2e-9 relative.  1e-7 is the bar; bit equality is not available on this input.
-    assert np.abs(got - ref).max() <= 1e-7 * np.abs(ref).max()
+    assert np.abs(ref).max() == pytest.approx(22.578421555988328, rel=1e-12)
+    # The input is ill-conditioned (K has a large negative eigenvalue), so rounding differences are amplified: the
+    # REFERENCE itself moves by n512_thread_sensitivity (3.2e-9 of max|Theta|, stored in the fixture) when only the
+    # BLAS thread count changes from the 1 thread the fixture was made with to 8.  The bar is 30 x that (1e-7);
+    # bit equality is not available on this input.
+    sens = g["n512_thread_sensitivity"]
+    assert 1e-9 < sens[0] < 1e-8 and "BLAS/OpenMP threads 1" in list(g["versions"])
+    assert np.abs(got - ref).max() <= 30 * sens[0] * np.abs(ref).max()
     assert o.converged_ == int(g["n512_conv"]) and min(o.qp_iters_) == 100     # every QP ran into its cap
     rows = g["n512_rows"]
     assert np.abs(o.inv_laplacian_[rows] - g["n512_inv_rows"]).max() <= 1e-7 * np.abs(g["n512_inv_rows"]).max()

@@ -1,10 +1,11 @@
-"""Dev tool: ms per LGMRF node update (fast path) as the difference of two capped fits, narrow and wide tagged ADMM forms.
+"""Dev tool: ms per LGMRF node update (fast path) between HIP events (gl_lgmrf_time_node_updates), narrow and wide tagged ADMM forms.
 usage: python tools/lgmrf_node_time.py [n ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from scipy.linalg import solve_triangular
-from graph_learning_amd import LGMRF, _lib
+from graph_learning_amd import _lib
+from graph_learning_amd.lgmrf import time_node_updates
 from graph_learning_amd.synth import er_laplacian
 
 ctx = _lib.default_context()
@@ -16,13 +17,8 @@ for n in [int(a) for a in sys.argv[1:]] or [512, 1024, 2048]:
     cov = xs.T @ xs / d
     for wide in ("0", "1"):
         os.environ["GRAPHLEARN_AMD_LGMRF_WIDE"] = wide
-        def capped(k):
-            os.environ["GRAPHLEARN_AMD_LGMRF_MAX_NODES"] = str(k)
-            t0 = time.perf_counter()
-            LGMRF(max_cycle=1).fit(cov, ctx=ctx)
-            return time.perf_counter() - t0
-        capped(8)
+        time_node_updates(cov, 0, 8, ctx=ctx)
         lo, hi = 64, min(192, n)
-        dt = min(capped(hi) - capped(lo) for _ in range(2))
+        dt = min(time_node_updates(cov, lo, hi - lo, ctx=ctx) for _ in range(2))
         print(f"n={n} wide={wide}: {dt * 1e3 / (hi - lo):.3f} ms per node update", flush=True)
-    del os.environ["GRAPHLEARN_AMD_LGMRF_MAX_NODES"], os.environ["GRAPHLEARN_AMD_LGMRF_WIDE"]
+    del os.environ["GRAPHLEARN_AMD_LGMRF_WIDE"]
