@@ -36,8 +36,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PROFILE_JSON = "r02_rocprof_summary.json"   # falls back to nothing when absent
-HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md), the roofline the edge pass is bound by
+PROFILE_JSON = "r03_rocprof_summary.json"   # falls back to nothing when absent
+CENSUS_JSON = "r03_tile_census.json"        # instruction census of the timed kernel's pass (tools/tile_pass_census.py)
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md), the roofline the streaming edge pass is bound by
+FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X fp64 vector spec = 256 CUs x 4 SIMDs x 16 lanes/clk x 2 flop x 2.4 GHz: the tile engine's roof
 
 
 def algorithmic_bytes_per_iteration(n: int) -> int:
@@ -267,26 +269,76 @@ def main():
             kernel, kprefix = "k_edge<false> (edge pass: prox update of all edges + degree sums)", "k_edge"
             launch_us, launch_bytes, its_per_launch = edge_us, bytes_it, 1
         achieved = launch_bytes / (launch_us * 1e-6) / 1e9
-        # HBM traffic: PMC counters cannot be read from inside this process; the figure below is the per-iteration
-        # constant of the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md) of
-        # a 2000-iteration launch -- "profile-derived", and left out when this run's launch is not comparable
+        # HBM traffic: PMC counters cannot be read from inside this process; the figure below comes from the committed
+        # rocprofv3 --pmc passes of THIS command line (FETCH_SIZE x 2 + WRITE_SIZE per launch, MI355X_MICROARCH.md): the
+        # launches of `--steps 20` and of the default `--steps 2000` were both profiled, other step counts are priced by
+        # the line through those two points (a call's fixed traffic + its per-iteration traffic)
         traffic, traffic_src = None, None
         try:
             with open(os.path.join(ROOT, "profiles", PROFILE_JSON)) as f:
                 prof = json.load(f)
-            if n == 4096 and (engine != "resident" or its_per_launch >= 1000):
-                per_it = next(v["total_bytes_per_iteration"] for k, v in prof["traffic"].items() if k.startswith(kprefix))
-                traffic = per_it * its_per_launch
-                traffic_src = (f"profile-derived: profiles/{PROFILE_JSON} (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE per "
-                               f"iteration of a {prof.get('iterations_per_launch', 2000)}-iteration launch) x {its_per_launch}")
+            pts = prof["traffic_bytes_per_launch"].get(kprefix) if n == 4096 else None   # {"20": bytes, "2000": bytes}
+            if pts and engine == "resident":
+                if str(its_per_launch) in pts:
+                    traffic = float(pts[str(its_per_launch)])
+                    how = f"the profiled {its_per_launch}-iteration launch"
+                else:
+                    (s0, b0), (s1, b1) = sorted((int(k), float(v)) for k, v in pts.items())[:2]
+                    traffic = b0 + (b1 - b0) / (s1 - s0) * (its_per_launch - s0)
+                    how = f"the line through the profiled {s0}- and {s1}-iteration launches"
+                traffic_src = f"profile-derived: profiles/{PROFILE_JSON} (rocprofv3 --pmc, FETCH_SIZE x 2 + WRITE_SIZE; {how})"
+            elif pts:
+                traffic = float(pts["1"])
+                traffic_src = f"profile-derived: profiles/{PROFILE_JSON} (rocprofv3 --pmc, FETCH_SIZE x 2 + WRITE_SIZE per launch)"
         except Exception:
             traffic = None
-        # The persistent engines keep w on chip, so the bytes they really move per iteration are far below the
-        # algorithmic 24 E: k_resident streams z (8 E) + degree slabs, k_tile half of z (4 E; nothing at all when the
-        # lattice is small enough for z to live in LDS) + ~6 MB of records.  Priced against the same 8 TB/s that is
-        # `streamed_frac`: how close the kernel is to the memory system's limit (it is not: it is bound by fp64 issue
-        # and hand-off latency).
-        streamed_bytes = (2 if engine_kernel == "k_tile" else 4) * n * (n - 1)
+        hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+               "algorithmic_bytes_per_launch": launch_bytes,
+               "definition": "SURVEY 8d: 24 E algorithmic bytes per iteration (read w, read z, write w) / launch time"}
+        if engine == "resident" and engine_kernel == "k_tile":
+            # The tile engine keeps w in registers and half of z in LDS: those 24 E bytes do not move, so the HBM figure
+            # above exceeds 1 and bounds nothing.  What binds the kernel is the issue rate of the fp64 vector pipe: the
+            # pass is a chain of fp64 VALU instructions (census of the shipped kernel: profiles/r03_tile_census.json,
+            # tools/tile_pass_census.py), two waves per SIMD.  Peak: 256 CUs x 4 SIMDs x 16 fp64 lanes per clock x 2.4 GHz
+            # = 39.3 T lane-operations/s = the 78.6 TFLOP/s vector spec with every instruction priced as an FMA (2 flop).
+            census, census_ok = None, None
+            try:
+                import hashlib
+                with open(os.path.join(ROOT, "profiles", CENSUS_JSON)) as f:
+                    census = json.load(f)
+                with open(os.path.join(ROOT, "graph_learning_amd", "csrc", "gl_tile.hip"), "rb") as f:
+                    census_ok = hashlib.sha256(f.read()).hexdigest()[:16] == census["source_sha16"]
+            except Exception:
+                census = None
+            streamed_bytes = 2 * n * (n - 1)      # half of z per iteration (4 E); records ~3 MB on top
+            roof = {"bound": "valu_f64", "unit": "TFLOP/s", "peak": FP64_VALU_PEAK_TFLOPS, "achieved": None, "frac": None}
+            if census is not None:
+                nb = (n + 63) // 64
+                row_pairs = nb * (nb + 1) // 2 * 32                     # every tile of the lattice, diagonal ones included
+                f64_per_rp = census["per_row_pair"]["valu_f64"]
+                lane_ops = f64_per_rp * row_pairs * 64 * its_per_launch  # fp64 VALU lane-operations of the launch
+                roof["achieved"] = 2.0 * lane_ops / (launch_us * 1e-6) / 1e12
+                roof["frac"] = roof["achieved"] / FP64_VALU_PEAK_TFLOPS
+                roof["flop_convention"] = ("every fp64 vector instruction priced as an FMA (2 flop per lane): the pipe issues "
+                                          "one wave-instruction per 4 cycles whatever it computes, so this is the share of "
+                                          "the fp64 issue slots the launch used; the pass mixes 6 FMAs with 12.1 adds / max")
+                roof["census"] = {"source": f"profiles/{CENSUS_JSON}", "matches_this_build": census_ok,
+                                  "per_row_pair": census["per_row_pair"], "row_pairs_per_iteration": row_pairs}
+                steady_lane = f64_per_rp * row_pairs * 64 / (steady_us * 1e-6)
+                roof["steady_state_frac"] = 2.0 * steady_lane / 1e12 / FP64_VALU_PEAK_TFLOPS
+            roof.update({"traffic": traffic, "traffic_source": traffic_src, "kernel": kernel,
+                         "iterations_per_launch": its_per_launch, "avg_launch_us": launch_us,
+                         "streamed_bytes_per_iteration": streamed_bytes,
+                         "streamed_frac_of_hbm_peak": streamed_bytes * its_per_launch / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "hbm_algorithmic": hbm,
+                         "note": ("bound = the resource that binds this kernel: fp64 vector-instruction issue (plus one all-to-all "
+                                  "hand-off chain per iteration, pure latency: DESIGN.md section 3a).  `hbm_algorithmic` keeps "
+                                  "SURVEY 8d's figure (24 E bytes per iteration / time; > 1 because the iterate never leaves the "
+                                  "register files); `traffic` = what really crossed the fabric (PMC)")})
+        else:
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic, "kernel": kernel, "iterations_per_launch": its_per_launch,
+                    "algorithmic_bytes_per_launch": launch_bytes, "avg_launch_us": launch_us, "traffic_source": traffic_src}
         out = {
             "metric": "primal-dual iterations/sec, LogModel n=4096 d=1024",
             "value": its_per_s,
@@ -310,19 +362,7 @@ def main():
                                         "iterations_per_s": 1e6 / steady_us,
                                         "frac_of_hbm_peak_algorithmic": bytes_it / (steady_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
                        "time_to_converge": converge},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kernel, "iterations_per_launch": its_per_launch,
-                         "algorithmic_bytes_per_launch": launch_bytes, "avg_launch_us": launch_us,
-                         "traffic_source": traffic_src,
-                         "streamed_bytes_per_iteration": streamed_bytes if engine == "resident" else bytes_it,
-                         "streamed_frac": (streamed_bytes * its_per_launch / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS)
-                         if engine == "resident" else achieved / HBM_PEAK_GBS,
-                         "note": ("achieved = ALGORITHMIC bytes (24 E per iteration: read w, read z, write w; SURVEY 8d) / "
-                                  "launch time, so `frac` exceeds 1 for an engine that does not move those bytes: w lives in "
-                                  "registers and half of z in LDS.  `streamed_frac` prices what the kernel really streams "
-                                  "(`streamed_bytes_per_iteration`) against the same 8 TB/s; the kernel is bound by fp64 "
-                                  "issue and hand-off latency, not by memory (DESIGN.md section 3a)") if engine == "resident" else None},
+            "roofline": roof,
         }
         if not args.no_other_configs and world == 1:
             out["config"]["other_configs"] = other_configs(ctx)

@@ -54,6 +54,7 @@ struct gl_logdeg {
     bool have_z = false, inited = false;
     bool have_zsq = false;
     int64_t it = 0;               // iterations completed (iterate lives in w[it & 1])
+    int64_t init_version = 0;     // bumped by every gl_logdeg_init (engines that cache what depends on z and gamma compare it)
     double theta = 1.0;
     bool theta_pending = false;   // set_signals left theta on the device (dstat[4]): gl_logdeg_theta fetches it
     // captured batch of iterations (launch-bound inner loop -> one graph launch)
@@ -85,7 +86,8 @@ int gl_resident_finish(gl_logdeg *s, int64_t *iters_done, bool *stopped, bool *n
 // gl_tile.hip
 int gl_tile_prepare(gl_logdeg *s);
 void gl_tile_free(gl_logdeg *s);
-int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms);
+int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int final_parity);
+bool gl_tile_writes_final_parity(const gl_logdeg *s);
 void gl_tile_dump_stamps(gl_logdeg *s);
 // gl_small.hip
 bool gl_small_applicable(const gl_logdeg *s);

@@ -1033,6 +1033,7 @@ GL_API int gl_logdeg_init(gl_logdeg *s, double alpha, double beta, double step_s
         GL_HIP(ctx, hipMemsetAsync(from, 0, (size_t)((char *)D.ctr + 8 * 8 - from), ctx->stream));
     }
     s->it = 0;
+    ++s->init_version;
     k_edge<true><<<dim3((unsigned)D.G), dim3(64), 0, ctx->stream>>>(D, D.dvar, D.pbar);
     GL_HIP(ctx, hipGetLastError());
     k_node<true><<<dim3((unsigned)D.nb), dim3(NODE_WAVES * 64), 0, ctx->stream>>>(D);  // also dstat = {inf, inf, tol 0}
@@ -1051,8 +1052,8 @@ GL_API int gl_logdeg_init(gl_logdeg *s, double alpha, double beta, double step_s
 static bool use_small(const gl_logdeg *s, int64_t iters) { return iters >= 8 && gl_small_applicable(s); }
 static bool use_resident(const gl_logdeg *s, int64_t iters) { return (s->tile != nullptr || s->res != nullptr) && iters >= 16; }
 // the persistent launch of the session's resident-family engine: the tile engine where it applies
-static int persistent_launch(gl_logdeg *s, int64_t iters, double tol, bool norms) {
-    return s->tile ? gl_tile_launch(s, iters, tol, norms) : gl_resident_launch(s, iters, tol);
+static int persistent_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int final_parity = -1) {
+    return s->tile ? gl_tile_launch(s, iters, tol, norms, final_parity) : gl_resident_launch(s, iters, tol);
 }
 static void persistent_free(gl_logdeg *s) {
     gl_resident_free(s);
@@ -1114,9 +1115,10 @@ GL_API int gl_logdeg_iterate_async(gl_logdeg *s, int64_t n_iter) {
     }
     if (use_resident(s, n_iter)) {
         // tol = 0 never stops: the iteration count and the parity of the final buffer are known now
-        GL_TRY(persistent_launch(s, n_iter, 0.0, false));  // nobody reads the ratios of an asynchronous call
         const int64_t itf = s->it + n_iter;
-        if ((itf & 1) != (s->it & 1)) {
+        const bool direct = gl_tile_writes_final_parity(s);  // the tile engine writes w[itf & 1] itself (below the rounds)
+        GL_TRY(persistent_launch(s, n_iter, 0.0, false, direct ? (int)(itf & 1) : -1));  // nobody reads the ratios of an asynchronous call
+        if (!direct && (itf & 1) != (s->it & 1)) {
             const size_t bytes = (size_t)s->dev.ntiles * GL_TILE_ELEMS * sizeof(double);
             GL_HIP(ctx, hipMemcpyAsync(s->dev.w[itf & 1], s->dev.w[s->it & 1], bytes, hipMemcpyDeviceToDevice,
                                        ctx->stream));

@@ -32,8 +32,20 @@
 //   * past n = 4096 the lattice no longer fits the register files: a workgroup then takes a rectangle of tiles and works
 //     through it in ROUNDS, one tile per wave from registers and LDS as above, the others streamed through register
 //     rings (see k_tile, BIGV); the records, the owners and the rule are the same.
-// Every sum has a fixed order (no atomics): bit-reproducible run to run.  The per-edge arithmetic follows the reference
-// with two re-associations (GL_TILE_FAST_ARITH): <= 1 ulp per operation, iterates within ~1e-14 of the oracle.
+// Every sum has a fixed order (no atomics): bit-reproducible run to run.
+//
+// Arithmetic of the pass.  The reference forms, per edge (smooth_learning.py:147-163),
+//     y = c w - g (d_i + d_j),  p = max(0, y - 2 g z),  q = c p - g (pbar_i + pbar_j),  w' = w - y + q
+// and per node the degree sums S p and S w'.  Substituting y and q into w' gives the same real number as
+//     w' = (1 - c) w + c p + g (u_i + u_j),        u = d - pbar,
+// so the node values that travel are {g d, g u}; and summing THAT over the edges of node i gives
+//     S w'_i = (1 - c) S w_i + c S p_i + (n - 2) u_i + sum_j u_j:
+// the degree of the new iterate follows from node quantities alone.  The pass therefore forms one degree sum (S p), not
+// two, and 7 fp64 operations per edge instead of 8: 18.5 instead of 26 fp64 instructions per row pair and lane, half the
+// records.  The recurrence contracts ((1 - c) = 2 gamma beta ~ 0.01), so its rounding does not accumulate; iterates stay
+// within ~1e-14 of the oracle (1e-10 is the parity contract).  The distances arrive pre-multiplied
+// (zg = 2 gamma z, formed once per gl_logdeg_init) with +1e300 at every entry outside i < j < n: p is exactly 0 there
+// without a mask.
 //
 // Nothing is written back before the end of the call (w lives in registers, the dual state in registers of
 // the owners), so a launch whose workgroups are not all co-resident (start-up rendezvous, bounded by the wall
@@ -60,14 +72,14 @@
 #ifndef GL_TILE_PROBE_GAP
 #define GL_TILE_PROBE_GAP 12  // s_sleep units (64 cycles) between the two: about half a round trip
 #endif
-#ifndef GL_TILE_FAST_ARITH
-// 1: the node values travel pre-multiplied by gamma ({gamma d, gamma pbar}: one product per node and iteration instead of one
-//    per edge) and c w - s, c p - s are fused multiply-adds -- 13 instead of 17 fp64 instructions per edge.  Each of the
-//    two changes moves a result by at most one rounding of the reference's NumPy arithmetic (gamma (d_i + d_j) against
-//    gamma d_i + gamma d_j; two roundings against one): iterates agree with the oracle to ~1e-14 instead of ~1e-15, far
-//    inside the 1e-10 of the parity contract.  0: the reference's operations one by one (the
-//    streaming and the small engine always compute that way).
-#define GL_TILE_FAST_ARITH 1
+#ifndef GL_TILE_ROWGROUP
+#define GL_TILE_ROWGROUP 8     // row pairs whose row sums share one halving butterfly (4: 1.5 adds per row pair, 8: 1.125)
+#endif
+#ifndef GL_TILE_ROUNDS_ZEV
+#define GL_TILE_ROUNDS_ZEV 8         // rounds: every 8th row pair of the resident tile keeps its z in LDS ...
+#endif
+#ifndef GL_TILE_ROUNDS_ZEV_NORMS
+#define GL_TILE_ROUNDS_ZEV_NORMS 64  // ... none in the variants with the norms (more row pairs of w in LDS instead)
 #endif
 #ifndef GL_TILE_EXACT_HEAD
 #define GL_TILE_EXACT_HEAD 3  // the stopping rule is evaluated exactly (no lag) for this many iterations at the start of a call
@@ -98,7 +110,7 @@ struct WaveDesc {  // 16 ints
     int si, sj;    // slots of I and J in the workgroup's block list
     int fcnt;      // fringe group: row pairs fa0 .. fa0 + fcnt - 1 of diagonal tile (fB, fB); 0: none
     int fa0, fB, fs;  // ... its first row pair, node block, slot of that block in the workgroup's list
-    int ftgt;      // where its degree partials are folded: 0 = my row vectors (fB == I, or no chunk), 2 = my column vectors (fB == J)
+    int ftgt;      // where its degree partials are folded: 0 = my row vector (fB == I, or no chunk), 1 = my column vector (fB == J)
     // n > 4096 ("rounds", see k_tile): the wave works on tiles (I + r, J), r = 0 .. nr - 1, one per round; the first one
     // is resident (tile >= 0) when it is not a diagonal tile, the others stream
     int nr;        // rounds this wave takes part in
@@ -118,17 +130,21 @@ struct WgDesc {  // 128 ints
 };
 static_assert(sizeof(WaveDesc) == 64 && sizeof(WgDesc) == 512, "descriptor sizes");
 
+constexpr double ZG_OUTSIDE = 1e300;  // zg at entries outside i < j < n: p = max(0, y - zg) is exactly 0 there
+
 struct TileDev {
-    double *w;        // tiled iterate buffer: read at the start, written at the end
-    const double *z;  // tiled scaled distances
+    double *w;        // tiled iterate buffer: read at the start (rounds: updated in place)
+    double *wout;     // ... where the registers are written at the end (w itself, or the other ping-pong buffer)
+    const double *zg; // tiled 2 gamma z, ZG_OUTSIDE outside i < j < n
     double *dvar, *ybar, *pbar, *dprev;
     double *bnorm;    // the streaming engine's [2][nb][4] norm partials (kept consistent at the end)
     double *dstat;
     long long *ctr;
     const WaveDesc *wd;
     const WgDesc *gd;
-    tl_u4 *part;   // [n_entries][2][64] granules: degree partials {S p, S w} of one workgroup for one node block
-    tl_u4 *nval;   // [nb][2][64] granules: {d, pbar} of a node block
+    tl_u4 *part;   // [n_entries][64] granules: degree partials S p of one workgroup for one node block
+    tl_u4 *nval;   // [nb][2][64] granules: {gamma d, gamma (d - pbar)} of a node block
+    tl_u4 *usum;   // [2][nb] granules: sum over a node block of gamma (d - pbar) (ring by tag parity)
     tl_u4 *wnorm;  // [4][NWG][2] granules: {sum (q-y)^2, sum w^2} of a workgroup (ring by iteration)
     tl_u4 *bnrm;   // [4][nb][4] granules: norm partials of a node block and of its slice of wnorm
     tl_u4 *look;   // [4][4] granules: the rule's early look of one workgroup for all ({code, ratio, ratio, -}; ring by iteration)
@@ -137,11 +153,12 @@ struct TileDev {
     unsigned long long *dbg;  // development only (GRAPHLEARN_AMD_RES_STAMPS=1): per-workgroup phase stamps
     int64_t n, nb;
     int NWG, n_entries;
-    double gamma, c, g2, a4g, tol;
+    double gamma, c, omc, nm2, a4g, tol;  // omc = 1 - c (exact: c is in [1/2, 2]), nm2 = n - 2
     long long it0;
     int maxit;
     unsigned tag0;
     unsigned rendezvous;  // value the arrival counter reaches when every workgroup of this launch has arrived
+    int check_rendezvous; // wait for that at the start also below the rounds (test hook)
 };
 
 __device__ __forceinline__ double tl_val(tl_u4 g) {
@@ -173,6 +190,20 @@ __device__ __forceinline__ bool tl_spin(unsigned &spins, unsigned long long t0, 
     return true;
 }
 
+// 16 bytes per lane from global memory straight into LDS (LDS-DMA: lane l's bytes land at lds + 16 l, no register in
+// between).  The builtin exists in the device pass only; the host pass, which parses kernel bodies too, sees an empty body.
+__device__ __forceinline__ void tl_dma16(const double *g, double2 *lds) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(g, lds, 16, 0, 0);
+#endif
+}
+
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() also waits for every vector-memory operation of
+// the wave (its workgroup-scope fences cover global memory: s_waitcnt vmcnt(0)): here that would drain the bulk loads of the
+// prologue in front of the first pass, and the z ring at every hand-off.  Nothing in this kernel passes data between the
+// waves of a workgroup through global memory.
+__device__ __forceinline__ void tl_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <bool NT = false>
 __device__ __forceinline__ double2 tl_ldz(const double *base, unsigned byte_off) {
     if (NT) {  // (rounds past the Infinity Cache: z leaves the cache to the streamed w, see tl_ld_stream)
@@ -183,36 +214,57 @@ __device__ __forceinline__ double2 tl_ldz(const double *base, unsigned byte_off)
     return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
-// y = c w - gamma (d_i + d_j) and q = c p - gamma (pbar_i + pbar_j)  (:147, :153); si, sj: the node values as s_node holds
-// them (pre-multiplied by gamma when GL_TILE_FAST_ARITH)
-__device__ __forceinline__ double tl_lin(const double c, const double g, const double v, const double si, const double sj) {
-#if GL_TILE_FAST_ARITH
-    return __builtin_fma(c, v, -(si + sj));
-#else
-    return c * v - g * (si + sj);
-#endif
+// One edge (see the head of the file): ai, bi = {gamma d, gamma u} of the row node, aj, bj of the column node, gz = 2 gamma z
+// (ZG_OUTSIDE outside i < j < n: then p = 0 exactly).  Returns p and t = c p + gamma (u_i + u_j); the new iterate is
+// w' = (1 - c) w + t and the update q - y = w' - w = t - c w: both are formed from the OLD w and t, so that w' can take the
+// old w's register (formed as w' - w, the difference keeps both alive and the register allocator rotates the whole iterate
+// through a second set of registers: measured, 13 us per pass instead of 4.5).  5 + 1 (+ 1 with the norms) fp64 instructions.
+__device__ __forceinline__ void tl_edge(const double c, const double w, const double gz, const double ai, const double bi,
+                                        const double aj, const double bj, double &pr, double &t) {
+    const double y = __builtin_fma(c, w, -(ai + aj));   // :147
+    const double tt = y - gz;                           // :150
+    pr = tt > 0 ? tt : 0.0;
+    t = __builtin_fma(c, pr, bi + bj);                  // :153 without its c p ... see above
+}
+// w <- w' = (1 - c) w + t (:163), IN PLACE, and the sums of squares of the stopping rule (:158-159) from the old w and t
+// (fused multiply-adds: these sums are compared with tol, not with NumPy bit for bit; its norm sums in another order anyway).
+// The update is written as the three-address instruction itself: the compiler's choice, v_fmac with t as the accumulator,
+// leaves w' in t's register and pays a 64-bit move per edge to bring it home (and, in the variants with the norms, runs out
+// of registers over it).  volatile: left alone the scheduler sinks these to the end of the unrolled pass.
+template <bool NORMS>
+__device__ __forceinline__ void tl_new_w(const double c, const double omc, double &w, const double t, double &nqy, double &nw) {
+    if (NORMS) {
+        const double dq = __builtin_fma(-c, w, t);      // q - y
+        nqy = __builtin_fma(dq, dq, nqy);
+    }
+    asm volatile("v_fma_f64 %0, %1, %0, %2" : "+v"(w) : "s"(omc), "v"(t));
+    if (NORMS) nw = __builtin_fma(w, w, nw);            // of the NEW iterate: next iteration's denominator (see s_wcarry)
 }
 
 // One chunk: U row pairs of a bulk tile, w in registers.  With U = 32 the even row pairs come through the
 // register ring (refilled RING streamed row pairs = 2 RING row pairs ahead: the odd ones in between double the
 // lead time a register buys; the last refills of a pass are next iteration's first row pairs: z never changes),
-// the odd ones -- and everything when U <= 16 -- from the chunk's LDS slice, pre-multiplied by 2 gamma.  Row sums by a halving butterfly per 4 row pairs, column sums in
-// registers; everything leaves through LDS (row p, row w, column p, column w vectors of 64; rows are those of
+// the odd ones -- and everything when U <= 16 -- from the chunk's LDS slice.  Row sums of p by a halving butterfly per 8
+// row pairs, column sums in registers; everything leaves through LDS (row p, column p vectors of 64; rows are those of
 // the whole tile, the chunk fills its own 2 U of them).
 // The LDS operands of row pair s + 1 are requested before row pair s is computed: the empty asm after every
 // row pair (it pins the running sums, which LLVM otherwise sinks to the end of the unrolled body, spilling every
 // addend on the way) is a scheduling boundary.
+// MASKW (variants with the norms on a ragged lattice): the new w of my two columns is multiplied by m0 / m1 (0 outside
+// j < n), so that the sums of squares see zeros there; without the norms such entries simply carry a bounded value
+// nobody reads (p is 0 there anyway, and the write-back masks them).
 // WRAP = false (rounds): the ring is filled by the caller right before the pass and is dead after it.
-template <int U, bool RAGGED, bool NORMS, bool WRAP = true, bool ZNT = false>
+template <int U, bool MASKW, bool NORMS, bool WRAP = true, bool ZNT = false>
 __device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[U], double2 (&zr)[RING], const double2 *zl,
-                                              const unsigned zb, const double2 *s_rows, const double dj0, const double dj1,
-                                              const double pj0, const double pj1, const double m0, const double m1,
-                                              double *s_row, double (&col)[4], const int lane, const bool younger, double &nqy,
+                                              const unsigned zb, const double2 *s_rows, const double aj0, const double aj1,
+                                              const double bj0, const double bj1, const double m0, const double m1,
+                                              double *s_row, double (&col)[2], const int lane, const bool younger, double &nqy,
                                               double &nw) {
     constexpr int NS = U == SLOTS ? SLOTS / 2 : 0;  // streamed row pairs
+    constexpr int GR = GL_TILE_ROWGROUP;            // row pairs per butterfly (4 or 8)
     const int half = lane >> 5;
-    const double c = P.c, g = P.gamma, g2 = P.g2;
-    double colp0 = col[0], colp1 = col[1], colw0 = col[2], colw1 = col[3];
+    const double c = P.c, omc = P.omc;
+    double colp0 = col[0], colp1 = col[1];
     // not loop-invariant for the compiler: otherwise it hoists one 64-bit address per streamed row pair (and the
     // LDS addresses) out of the iteration loop, for each instantiation of this pass, and spills them all
     unsigned zbv = zb;
@@ -227,26 +279,26 @@ __device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[
     // younger half therefore runs the first half of its pass at priority 1: both end together.
     if (younger) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int gq = 0; gq < U / 4; ++gq) {
-        double rowp[4], roww[4];
-        if (gq == (U / 4) * GL_TILE_PRIO_EIGHTHS / 8) __builtin_amdgcn_s_setprio(0);
+    for (int gq = 0; gq < U / GR; ++gq) {
+        double rowp[GR];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int s = 4 * gq + k;
+        for (int k = 0; k < GR; ++k) {
+            const int s = GR * gq + k;
+            if (s == U * GL_TILE_PRIO_EIGHTHS / 8) __builtin_amdgcn_s_setprio(0);
             double2 gz;  // 2 gamma z of this row pair (:150)
             constexpr bool STREAMS = NS > 0;
             const bool streamed = STREAMS && (s & 1) == 0;  // U = 32: even row pairs stream, odd ones live in LDS
             if (streamed) {
                 const int pos = (s / 2) % RING;
-                gz = double2{g2 * zr[pos].x, g2 * zr[pos].y};
+                gz = zr[pos];
                 // refill with the RING-th next streamed row pair (2 RING row pairs ahead; wraps into the next iteration)
-                if (WRAP || s + 2 * RING < SLOTS) zr[pos] = tl_ldz<ZNT>(P.z, zbv + (unsigned)(((s + 2 * RING) % SLOTS) * (2 * TB) * 8));
+                if (WRAP || s + 2 * RING < SLOTS) zr[pos] = tl_ldz<ZNT>(P.zg, zbv + (unsigned)(((s + 2 * RING) % SLOTS) * (2 * TB) * 8));
             } else {
                 gz = zl_n;
             }
             double2 rv;
             if (GL_TILE_LDS_PREFETCH && WRAP) {
-                rv = rv_n;  // {d_i, pbar_i}: one address per half-wave (broadcast)
+                rv = rv_n;  // {gamma d_i, gamma u_i}: one address per half-wave (broadcast)
                 if (s + 1 < U) {
                     rv_n = s_rows[2 * (s + 1) + half];
                     if (!STREAMS) zl_n = zl[(s + 1) * 64];
@@ -256,93 +308,65 @@ __device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[
                 rv = s_rows[2 * s + half];
                 if (!streamed) gz = zl[(STREAMS ? s / 2 : s) * 64];
             }
-            const double di = rv.x, pi = rv.y;
-            const double2 wv = wreg[s];
-            double wn[2], pp[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const double w = e ? wv.y : wv.x;
-                const double y = tl_lin(c, g, w, di, e ? dj1 : dj0);   // :147
-                const double tt = y - (e ? gz.y : gz.x);               // :150
-                const double pr = tt > 0 ? tt : 0.0;
-                const double q = tl_lin(c, g, pr, pi, e ? pj1 : pj0);  // :153
-                if (RAGGED) {
-                    const double m = e ? m1 : m0;
-                    wn[e] = m * ((w - y) + q);
-                    pp[e] = m * pr;
-                } else {
-                    wn[e] = (w - y) + q;  // :163
-                    pp[e] = pr;
-                }
-                if (NORMS) {
-                    // sums of squares for the stopping rule (:158-159).  Fused multiply-adds: these sums are compared with
-                    // tol, not with NumPy bit for bit (its norm sums in another order anyway); the iterate itself never sees them
-                    const double dq = RAGGED ? (e ? m1 : m0) * (q - y) : q - y;  // == -y + q
-                    nqy = __builtin_fma(dq, dq, nqy);
-                    nw = __builtin_fma(wn[e], wn[e], nw);  // of the NEW iterate: next iteration's denominator (see s_wcarry)
-                }
-            }
+            double pp[2], t[2];
+            tl_edge(c, wreg[s].x, gz.x, rv.x, rv.y, aj0, bj0, pp[0], t[0]);
+            tl_edge(c, wreg[s].y, gz.y, rv.x, rv.y, aj1, bj1, pp[1], t[1]);
+            if (MASKW) t[0] *= m0, t[1] *= m1;  // (w is 0 outside j < n and stays 0)
+            tl_new_w<NORMS>(c, omc, wreg[s].x, t[0], nqy, nw);
+            tl_new_w<NORMS>(c, omc, wreg[s].y, t[1], nqy, nw);
             colp0 += pp[0];
             colp1 += pp[1];
-            colw0 += wn[0];
-            colw1 += wn[1];
             rowp[k] = pp[0] + pp[1];
-            roww[k] = wn[0] + wn[1];
-            wreg[s] = double2{wn[0], wn[1]};
             if (k % GL_TILE_PIN == GL_TILE_PIN - 1) {
                 if (NORMS)
-                    asm volatile("" : "+v"(nqy), "+v"(nw), "+v"(colp0), "+v"(colp1), "+v"(colw0), "+v"(colw1));
+                    asm volatile("" : "+v"(nqy), "+v"(nw), "+v"(colp0), "+v"(colp1));
                 else
-                    asm volatile("" : "+v"(colp0), "+v"(colp1), "+v"(colw0), "+v"(colw1));
+                    asm volatile("" : "+v"(colp0), "+v"(colp1));
             }
         }
-        const double rw = halfwave_rows4(roww, lane);  // lane l: the total of row pair (l >> 3) & 3 of the group
-        const double rp = halfwave_rows4(rowp, lane);
-        if ((lane & 7) == 0) {
-            const int row = 2 * (4 * gq + ((lane >> 3) & 3)) + half;
-            s_row[row] = rp;       // (s_row points at the chunk's first row inside the tile's row vector)
-            s_row[TB + row] = rw;
-        }
+#if GL_TILE_ROWGROUP == 8
+        const double rp = halfwave_rows8(rowp, lane);  // lane l: the total of row pair (l >> 2) & 7 of the group
+        if ((lane & 3) == 0) s_row[2 * (8 * gq + ((lane >> 2) & 7)) + half] = rp;  // (s_row points at the chunk's first row inside the tile's row vector)
+#else
+        const double rp = halfwave_rows4(rowp, lane);  // lane l: the total of row pair (l >> 3) & 3 of the group
+        if ((lane & 7) == 0) s_row[2 * (4 * gq + ((lane >> 3) & 3)) + half] = rp;
+#endif
     }
-    col[0] = colp0, col[1] = colp1, col[2] = colw0, col[3] = colw1;
+    col[0] = colp0, col[1] = colp1;
 }
 
-// The resident pass of the ROUNDS (n > 4096): as tl_chunk_pass<32>, but only WRG = 20 (18 with the norms) of the tile's 32
-// row pairs keep their w in registers; the last ones live in the wave's LDS slice, which in exchange holds z for every 8th
-// (16th) row pair only (the others come through the ring).  The rounds need registers beside the resident pass -- the streamed pass, its rings,
-// the accumulators of the fold -- and with all 32 row pairs in registers the compiler parked 2 (6 with the norms) of them in
-// scratch: every access to those sits in the same vmcnt queue as the z ring and stalls the pass for a memory round trip
-// (n = 5000 with norms: 46 against 32 us per iteration without).
+// The resident pass of the ROUNDS (n > 4096): as tl_chunk_pass<32>, but only WRG of the tile's 32 row pairs keep their
+// w in registers; the last ones live in the wave's LDS slice, which in exchange holds z for every ZEV-th row pair only
+// (the others come through the ring).  The rounds need registers beside the resident pass -- the streamed pass, its rings,
+// the accumulators of the fold -- and a row pair of w that the compiler parks in scratch stalls the pass for a memory
+// round trip per access (its reload sits in the same vmcnt queue as the z ring: n = 5000 with norms, 46 against 32 us).
 // LDS slice of a wave (zw, 16 x 64 double2): [0, ZLN) 2 gamma z of row pairs ZEV - 1, 2 ZEV - 1, ..; [ZLN, 16) w of row pairs WRG .. 31.
 constexpr int WRG_NONE = SLOTS;
-// How the wave's LDS slice is split (measured, us per iteration without / with the norms: every 8th row pair of z in LDS,
-// 20 row pairs of w in registers: n = 5000: 30.6 / 52.5 -- two row pairs still in scratch with the norms --, 8192: 111.1 /
-// 123.7; every 16th, 18 in registers: 31.5 / 35.4, 112.9 / 117.0): the variant with the norms gives up more of z.
 template <bool NORMS>
 struct RoundsSplit {
     static constexpr int SLICE = 15;                  // row pairs of LDS per wave (one less than below n = 4096: s_node holds 16 blocks)
-    static constexpr int ZEV = NORMS ? 64 : 8;        // every ZEV-th row pair keeps its z in LDS (64: none)
+    static constexpr int ZEV = NORMS ? GL_TILE_ROUNDS_ZEV_NORMS : GL_TILE_ROUNDS_ZEV;  // every ZEV-th row pair keeps its z in LDS (64: none)
     static constexpr int ZLN = SLOTS / ZEV;           // ... that many of them
-    static constexpr int WRG = SLOTS - (SLICE - ZLN); // row pairs of w in registers (18 or 21); the others in LDS behind the z
+    static constexpr int WRG = SLOTS - (SLICE - ZLN); // row pairs of w in registers; the others in LDS behind the z
     static constexpr int slot(int t) { return t + t / (ZEV - 1); }  // the t-th streamed row pair
 };
-template <bool RAGGED, bool NORMS, bool ZNT>
+template <bool MASKW, bool NORMS, bool ZNT>
 __device__ __forceinline__ void tl_resident_pass_rounds(const TileDev &P, double2 (&wreg)[SLOTS], double2 (&zr)[RING], double2 *zw,
-                                                        const unsigned zb, const double2 *s_rows, const double dj0, const double dj1,
-                                                        const double pj0, const double pj1, const double m0, const double m1,
-                                                        double *s_row, double (&col)[4], const int lane, const bool younger,
+                                                        const unsigned zb, const double2 *s_rows, const double aj0, const double aj1,
+                                                        const double bj0, const double bj1, const double m0, const double m1,
+                                                        double *s_row, double (&col)[2], const int lane, const bool younger,
                                                         double &nqy, double &nw) {
     constexpr int ZEV = RoundsSplit<NORMS>::ZEV, ZLN = RoundsSplit<NORMS>::ZLN, WRG = RoundsSplit<NORMS>::WRG;
     constexpr int NSTR = SLOTS - ZLN;
     const int half = lane >> 5;
-    const double c = P.c, g = P.gamma, g2 = P.g2;
-    double colp0 = col[0], colp1 = col[1], colw0 = col[2], colw1 = col[3];
+    const double c = P.c, omc = P.omc;
+    double colp0 = col[0], colp1 = col[1];
     unsigned zbv = zb;  // (not loop-invariant for the compiler: see tl_chunk_pass)
     asm volatile("" : "+v"(zbv));
     if (younger) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int gq = 0; gq < SLOTS / 4; ++gq) {
-        double rowp[4], roww[4];
+        double rowp[4];
         if (gq == (SLOTS / 4) * GL_TILE_PRIO_EIGHTHS / 8) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -351,82 +375,57 @@ __device__ __forceinline__ void tl_resident_pass_rounds(const TileDev &P, double
             if (s % ZEV != ZEV - 1) {
                 const int t = s - (s + 1) / ZEV;  // streamed row pairs before this one
                 const int pos = t % RING;
-                gz = double2{g2 * zr[pos].x, g2 * zr[pos].y};
-                if (t + RING < NSTR) zr[pos] = tl_ldz<ZNT>(P.z, zbv + (unsigned)(RoundsSplit<NORMS>::slot(t + RING) * (2 * TB) * 8));
+                gz = zr[pos];
+                if (t + RING < NSTR) zr[pos] = tl_ldz<ZNT>(P.zg, zbv + (unsigned)(RoundsSplit<NORMS>::slot(t + RING) * (2 * TB) * 8));
             } else {
                 gz = zw[(s / ZEV) * 64];
             }
             const double2 rv = s_rows[2 * s + half];
-            const double di = rv.x, pi = rv.y;
-            const double2 wv = s < WRG ? wreg[s < WRG ? s : 0] : zw[(ZLN + s - WRG) * 64];
-            double wn[2], pp[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const double w = e ? wv.y : wv.x;
-                const double y = tl_lin(c, g, w, di, e ? dj1 : dj0);   // :147
-                const double tt = y - (e ? gz.y : gz.x);               // :150
-                const double pr = tt > 0 ? tt : 0.0;
-                const double q = tl_lin(c, g, pr, pi, e ? pj1 : pj0);  // :153
-                if (RAGGED) {
-                    const double m = e ? m1 : m0;
-                    wn[e] = m * ((w - y) + q);
-                    pp[e] = m * pr;
-                } else {
-                    wn[e] = (w - y) + q;  // :163
-                    pp[e] = pr;
-                }
-                if (NORMS) {
-                    const double dq = RAGGED ? (e ? m1 : m0) * (q - y) : q - y;
-                    nqy = __builtin_fma(dq, dq, nqy);
-                    nw = __builtin_fma(wn[e], wn[e], nw);
-                }
-            }
+            double2 wl = double2{0.0, 0.0};
+            if (s >= WRG) wl = zw[(ZLN + s - WRG) * 64];
+            double2 &wv = s < WRG ? wreg[s < WRG ? s : 0] : wl;
+            double pp[2], t[2];
+            tl_edge(c, wv.x, gz.x, rv.x, rv.y, aj0, bj0, pp[0], t[0]);
+            tl_edge(c, wv.y, gz.y, rv.x, rv.y, aj1, bj1, pp[1], t[1]);
+            if (MASKW) t[0] *= m0, t[1] *= m1;
+            tl_new_w<NORMS>(c, omc, wv.x, t[0], nqy, nw);
+            tl_new_w<NORMS>(c, omc, wv.y, t[1], nqy, nw);
             colp0 += pp[0];
             colp1 += pp[1];
-            colw0 += wn[0];
-            colw1 += wn[1];
             rowp[k] = pp[0] + pp[1];
-            roww[k] = wn[0] + wn[1];
-            if (s < WRG) wreg[s < WRG ? s : 0] = double2{wn[0], wn[1]};
-            else zw[(ZLN + s - WRG) * 64] = double2{wn[0], wn[1]};
+            if (s >= WRG) zw[(ZLN + s - WRG) * 64] = wl;
             if (k % GL_TILE_PIN == GL_TILE_PIN - 1) {
                 if (NORMS)
-                    asm volatile("" : "+v"(nqy), "+v"(nw), "+v"(colp0), "+v"(colp1), "+v"(colw0), "+v"(colw1));
+                    asm volatile("" : "+v"(nqy), "+v"(nw), "+v"(colp0), "+v"(colp1));
                 else
-                    asm volatile("" : "+v"(colp0), "+v"(colp1), "+v"(colw0), "+v"(colw1));
+                    asm volatile("" : "+v"(colp0), "+v"(colp1));
             }
         }
-        const double rw = halfwave_rows4(roww, lane);
         const double rp = halfwave_rows4(rowp, lane);
         // the address of the row entries is formed anew every time: kept in a register over the pass it is the first thing
         // the compiler parks in scratch, and every reload waits for the whole z ring (s_waitcnt vmcnt(0))
         int lr = lane;
         asm volatile("" : "+v"(lr));
-        if ((lr & 7) == 0) {
-            const int row = 2 * (4 * gq + ((lr >> 3) & 3)) + (lr >> 5);
-            s_row[row] = rp;
-            s_row[TB + row] = rw;
-        }
+        if ((lr & 7) == 0) s_row[2 * (4 * gq + ((lr >> 3) & 3)) + (lr >> 5)] = rp;
     }
-    col[0] = colp0, col[1] = colp1, col[2] = colw0, col[3] = colw1;
+    col[0] = colp0, col[1] = colp1;
 }
 
-// column sums of a wave (each lane: its two columns over the rows of its half) -> the wave's column vectors in LDS
-__device__ __forceinline__ void tl_put_cols(const double (&col)[4], double *s_col, const int lane) {
+// column sums of a wave (each lane: its two columns over the rows of its half) -> the wave's column vector in LDS
+__device__ __forceinline__ void tl_put_cols(const double (&col)[2], double *s_col, const int lane) {
     const int half = lane >> 5, c0 = 2 * (lane & 31);
-    const double colp0 = add_xor32(col[0]), colp1 = add_xor32(col[1]), colw0 = add_xor32(col[2]), colw1 = add_xor32(col[3]);
+    const double colp0 = add_xor32(col[0]), colp1 = add_xor32(col[1]);
     if (half == 0) {
         s_col[c0] = colp0;
         s_col[c0 + 1] = colp1;
-        s_col[TB + c0] = colw0;
-        s_col[TB + c0 + 1] = colw1;
     }
 }
 
-// One STREAMED tile (n > 4096: what the register files do not hold): w and z come from memory through two
+// One STREAMED tile (n > 4096: what the register files do not hold): w and 2 gamma z come from memory through two
 // 4-deep register rings (row pair s + 4 is requested while row pair s is computed; the last four requests of a
 // tile are the first row pairs of the wave's next streamed tile), the new w goes straight back.  Same per-edge
-// arithmetic as the chunk pass; validity (i < j < n: diagonal tiles, ragged last block column) by selects.
+// arithmetic as the chunk pass; the new w is multiplied by its validity (i < j < n: diagonal tiles, ragged last block
+// column), since it returns to memory, where every engine expects zeros outside the lattice.
 #ifndef GL_TILE_STREAM_RING
 #define GL_TILE_STREAM_RING 4
 #endif
@@ -462,17 +461,17 @@ __device__ __forceinline__ void tl_st_stream(char *p, const double2 v) {
 #ifndef GL_TILE_STREAM_SCHED
 #define GL_TILE_STREAM_SCHED 1
 #endif
-template <bool NORMS, bool MASKED, bool NT>
+template <bool NORMS, bool NT>
 __device__ __forceinline__ void tl_stream_pass(const TileDev &P, double2 (&wq)[RS], double2 (&zq)[RS], const unsigned tb,
-                                               const unsigned nxt, const double2 *s_rows, const double dj0, const double dj1,
-                                               const double pj0, const double pj1, const bool diag, const bool jv0, const bool jv1,
-                                               double *s_row, double (&col)[4], const int lane, double &nqy, double &nw,
+                                               const unsigned nxt, const double2 *s_rows, const double aj0, const double aj1,
+                                               const double bj0, const double bj1, const bool diag, const bool jv0, const bool jv1,
+                                               double *s_row, double (&col)[2], const int lane, double &nqy, double &nw,
                                                const int g0) {
     const int half = lane >> 5, c0 = 2 * (lane & 31);
-    const double c = P.c, g = P.gamma, g2 = P.g2;
+    const double c = P.c, omc = P.omc;
     char *wbase = reinterpret_cast<char *>(P.w);
-    const char *zbase = reinterpret_cast<const char *>(P.z);
-    double colp0 = col[0], colp1 = col[1], colw0 = col[2], colw1 = col[3];
+    const char *zbase = reinterpret_cast<const char *>(P.zg);
+    double colp0 = col[0], colp1 = col[1];
 #pragma unroll 1
     for (int gi = 0; gi < SLOTS / RS; ++gi) {
         // the waves of the chip start their tiles at different row pairs (g0): tiles are 32 KiB apart, and waves that walk
@@ -485,36 +484,22 @@ __device__ __forceinline__ void tl_stream_pass(const TileDev &P, double2 (&wq)[R
 #pragma unroll
         for (int gh = 0; gh < RS / 4; ++gh) {
             const int gq = gr * (RS / 4) + gh;
-            double rowp[4], roww[4];
+            double rowp[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int s = 4 * gq + k, pos = 4 * gh + k;
-                const double2 wv = wq[pos], zv = zq[pos];
+                double2 wv = wq[pos];
+                const double2 zv = zq[pos];
                 const double2 rv = s_rows[2 * s + half];
-                const double di = rv.x, pi = rv.y;
-                double wn[2], pp[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const double w = e ? wv.y : wv.x;
-                    const double y = tl_lin(c, g, w, di, e ? dj1 : dj0);   // :147
-                    const double tt = y - g2 * (e ? zv.y : zv.x);          // :150
-                    const double pr = tt > 0 ? tt : 0.0;
-                    const double q = tl_lin(c, g, pr, pi, e ? pj1 : pj0);  // :153
-                    double dq = q - y;
-                    wn[e] = (w - y) + q;  // :163
-                    pp[e] = pr;
-                    if (MASKED) {  // (entries outside i < j < n hold w = z = 0: everything above is finite)
-                        const double m = ((e ? jv1 : jv0) && (!diag || 2 * s + half < c0 + e)) ? 1.0 : 0.0;
-                        wn[e] *= m;
-                        pp[e] *= m;
-                        dq *= m;
-                    }
-                    if (NORMS) {
-                        nqy = __builtin_fma(dq, dq, nqy);
-                        nw = __builtin_fma(wn[e], wn[e], nw);
-                    }
-                }
-                tl_st_stream<NT && GL_TILE_NT_W>(wbase + tb + (unsigned)(s * (2 * TB) * 8), double2{wn[0], wn[1]});
+                double pp[2], t[2];
+                tl_edge(c, wv.x, zv.x, rv.x, rv.y, aj0, bj0, pp[0], t[0]);
+                tl_edge(c, wv.y, zv.y, rv.x, rv.y, aj1, bj1, pp[1], t[1]);
+                // (entries outside i < j < n hold w = 0 and zg = ZG_OUTSIDE: p is 0 there by itself, w' stays 0 by this factor)
+                t[0] *= (jv0 && (!diag || 2 * s + half < c0)) ? 1.0 : 0.0;
+                t[1] *= (jv1 && (!diag || 2 * s + half < c0 + 1)) ? 1.0 : 0.0;
+                tl_new_w<NORMS>(c, omc, wv.x, t[0], nqy, nw);
+                tl_new_w<NORMS>(c, omc, wv.y, t[1], nqy, nw);
+                tl_st_stream<NT && GL_TILE_NT_W>(wbase + tb + (unsigned)(s * (2 * TB) * 8), wv);
                 // the ring's registers are requested again only now that their values have been used (requested earlier, the
                 // compiler copies the whole ring aside and waits for all of it at the top of the loop)
                 asm volatile("" ::: "memory");
@@ -522,24 +507,16 @@ __device__ __forceinline__ void tl_stream_pass(const TileDev &P, double2 (&wq)[R
                 zq[pos] = tl_ld_stream<NT>(zbase + nbase + (unsigned)(pos * (2 * TB) * 8));
                 colp0 += pp[0];
                 colp1 += pp[1];
-                colw0 += wn[0];
-                colw1 += wn[1];
                 rowp[k] = pp[0] + pp[1];
-                roww[k] = wn[0] + wn[1];
 #if GL_TILE_STREAM_SCHED
                 __builtin_amdgcn_sched_barrier(0);  // one row pair at a time: the registers belong to the resident tile
 #endif
             }
-            const double rw = halfwave_rows4(roww, lane);
             const double rp = halfwave_rows4(rowp, lane);
-            if ((lane & 7) == 0) {
-                const int row = 2 * (4 * gq + ((lane >> 3) & 3)) + half;
-                s_row[row] = rp;
-                s_row[TB + row] = rw;
-            }
+            if ((lane & 7) == 0) s_row[2 * (4 * gq + ((lane >> 3) & 3)) + half] = rp;
         }
     }
-    col[0] = colp0, col[1] = colp1, col[2] = colw0, col[3] = colw1;
+    col[0] = colp0, col[1] = colp1;
 }
 
 // NORMS: the norms of the stopping rule are formed every iteration (calls with tol > 0, and synchronous calls, which
@@ -557,29 +534,40 @@ __device__ __forceinline__ void tl_stream_pass(const TileDev &P, double2 (&wq)[R
 template <int U, bool RAGGED, bool NORMS, int BIGV = 0>  // BIGV: 0, 1 = rounds, 2 = rounds with non-temporal streams
 __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     constexpr bool BIG = BIGV != 0, NT = BIGV == 2;
+    constexpr bool MASKW = RAGGED && NORMS;  // (see tl_chunk_pass)
     constexpr int ZEV = RoundsSplit<NORMS>::ZEV, ZLN = RoundsSplit<NORMS>::ZLN, WRG = BIG ? RoundsSplit<NORMS>::WRG : WRG_NONE;
     static_assert(!BIG || U == SLOTS, "rounds work on whole tiles");
     // LDS-resident row pairs of z per chunk (rounds: a slice of RoundsSplit::SLICE row pairs shared by z and w)
     constexpr int ZRES = BIGV != 0 ? RoundsSplit<NORMS>::SLICE : (U == SLOTS ? SLOTS / 2 : U);
     constexpr int NS = U - ZRES;                      // streamed ones
     __shared__ double2 s_z[TW][ZRES][64];             // up to 128 KiB
-    __shared__ double2 s_node[BIGV != 0 ? NBW : NBW_FIT][TB];  // {d, pbar} (x gamma: GL_TILE_FAST_ARITH) of the node blocks this workgroup touches
-    __shared__ double s_part[TW][4][TB];              // per chunk: row p, row w, column p, column w (owner phase: s_own)
-    __shared__ double s_dual[4][TB];                  // owner workgroups: d, ybar, pbar, d of the previous iteration
+    __shared__ double2 s_node[BIGV != 0 ? NBW : NBW_FIT][TB];  // {gamma d, gamma u} of the node blocks this workgroup touches
+    __shared__ double s_part[TW][2][TB];              // per chunk: row sums of p, column sums of p (owner phase: s_own)
+    __shared__ double s_dual[5][TB];                  // owner workgroups: d, ybar, pbar, d of the previous iteration, gamma S w
     __shared__ double s_bn[4];                        // ... and the norm partials of its last update
+    __shared__ double s_gu;                           // ... and gamma sum_j u_j over all nodes (inputs of the current iteration)
     __shared__ double s_wn[TW][2];
     __shared__ double s_wcarry[TW];                   // per wave: sum of squares of its current w (the rule's denominator)
-    __shared__ int s_flag[4];                         // {rendezvous ok, failed, stop, -}
+    __shared__ int s_flag[4];                         // {rendezvous ok, failed, stop, exact}
     __shared__ double s_rel[2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wg = blockIdx.x;
-    const int half = lane >> 5, c0 = 2 * (lane & 31), lofs = half * TB + c0;
+    const int half = lane >> 5, c0 = 2 * (lane & 31);
     if (P.ctr[4] != 0) return;  // an earlier launch of this session failed and has not been looked at yet
-    // development (GRAPHLEARN_AMD_RES_STAMPS): where a CALL spends its time -- entry, loads done, rendezvous, first and last
-    // iteration, write-back (the waits that make the stamps meaningful exist only in stamped runs)
-    unsigned long long cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (P.dbg) cs[0] = __builtin_amdgcn_s_memrealtime();
+    // development (GRAPHLEARN_AMD_RES_STAMPS): where a CALL spends its time -- entry, prologue issued, rendezvous, first
+    // iteration, loop, write-back
+    auto call_stamp = [&](int q) {  // (written at once: kept in registers the stamps would cost the pass a dozen of them)
+        if (P.dbg && (threadIdx.x & 63) == 0)
+            P.dbg[(size_t)P.NWG * 16 * (6 + 2 * TW) + ((size_t)blockIdx.x * TW + (threadIdx.x >> 6)) * 8 + q] = __builtin_amdgcn_s_memrealtime();
+    };
+    call_stamp(0);
+    // ---- start-up rendezvous, arrival: every workgroup of the grid is on the chip, or nobody touches anything.  The
+    //      arrival counter is monotonic over the launches of the session (target = arrivals so far + grid), so nothing has
+    //      to be reset between launches: the launch is the only thing on the stream.  The arrival travels while the
+    //      prologue below is issued; wave 0 waits for the others before it issues its own bulk loads (its poll would
+    //      otherwise wait behind them: vector memory operations of a wave complete in order).
+    if (tid == 0) __hip_atomic_fetch_add(P.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     const WaveDesc wdv = P.wd[wg * TW + wave];
     // the workgroup's descriptor: lane l keeps words l and 64 + l, wave-uniform reads go through v_readlane
@@ -591,6 +579,41 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     const unsigned long long slice_mask = ((unsigned long long)(unsigned)gd_int(GD_SLICE + 1) << 32) | (unsigned)gd_int(GD_SLICE);
     const bool active = gd_int(GD_ACTIVE) != 0;
     unsigned *err = P.bar + 32;
+    const auto r_part = __builtin_amdgcn_make_buffer_rsrc((void *)P.part, 0, (int)((int64_t)P.n_entries * TB * 16), 0x00020000);
+    const auto r_nval = __builtin_amdgcn_make_buffer_rsrc((void *)P.nval, 0, (int)(P.nb * 2 * TB * 16), 0x00020000);
+    const auto r_us = __builtin_amdgcn_make_buffer_rsrc((void *)P.usum, 0, (int)(2 * P.nb * 16), 0x00020000);
+    const auto r_wn = __builtin_amdgcn_make_buffer_rsrc((void *)P.wnorm, 0, (int)(4 * P.NWG * 2 * 16), 0x00020000);
+    const auto r_bn = __builtin_amdgcn_make_buffer_rsrc((void *)P.bnrm, 0, (int)(4 * P.nb * 4 * 16), 0x00020000);
+    const auto r_lk = __builtin_amdgcn_make_buffer_rsrc((void *)P.look, 0, 4 * 4 * 16, 0x00020000);
+
+    // ---- the node values this call starts from (what the previous call, or init, left in memory): requested first, so
+    //      that waiting for them does not wait for the bulk loads behind them
+    double nv_d[NACQ], nv_p[NACQ];
+#pragma unroll
+    for (int j = 0; j < NACQ; ++j) {
+        const int k = wave + TW * j;
+        nv_d[j] = nv_p[j] = 0.0;
+        if (k < nblk) {
+            const int64_t i = (int64_t)gd_int(GD_BLK + k) * TB + lane;
+            nv_d[j] = P.dvar[i];
+            nv_p[j] = P.pbar[i];
+        }
+    }
+    // ---- dual state of my node block (owner workgroups, wave 0, lane = node): in LDS, not in registers that
+    //      every wave of the grid would have to set aside.  gamma S w of the current iterate is ybar - d (:148); the sum of
+    //      my block's gamma u is published for every owner (tag of this call's input state).
+    const int64_t own_i = (int64_t)own * TB + lane;
+    if (own >= 0 && wave == 0) {
+        const double d0 = P.dvar[own_i], y0 = P.ybar[own_i], p0 = P.pbar[own_i];
+        s_dual[0][lane] = d0;
+        s_dual[1][lane] = y0;
+        s_dual[2][lane] = p0;
+        s_dual[3][lane] = P.dprev[own_i];
+        s_dual[4][lane] = y0 - d0;
+        if (lane < 4) s_bn[lane] = 0.0;
+        const double us = wave_sum(P.gamma * (d0 - p0));
+        if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(tl_gran(us, P.tag0), r_us, (int)(((P.tag0 & 1u) * (unsigned)P.nb + (unsigned)own) * 16u), 0, 16);
+    }
 
     // ---- static work of this wave
     const bool has = wdv.tile >= 0;
@@ -602,44 +625,49 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     for (int k = 0; k < RING; ++k) zr[k] = double2{0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < U; ++s) wreg[s] = double2{0.0, 0.0};
-    if (has) {
-        const int64_t tb = (int64_t)wdv.tile * GL_TILE_ELEMS + (int64_t)a0 * (2 * TB) + lofs;
-        zb = (unsigned)(tb * 8);
-#pragma unroll
-        for (int s = 0; s < U; ++s) {
-            const double2 wv = *reinterpret_cast<const double2 *>(P.w + tb + s * (2 * TB));
-            if (BIG && s >= WRG) s_z[wave][ZLN + s - WRG][lane] = wv;  // (rounds: the last row pairs of w live in LDS)
-            else wreg[s] = wv;
-        }
-#pragma unroll
-        for (int s = 0; s < U; ++s) {  // LDS-resident part (U = 32: the odd row pairs; rounds: every fourth), pre-multiplied: 2 gamma z
-            if (BIG ? s % ZEV != ZEV - 1 : (NS > 0 && (s & 1) == 0)) continue;
-            const double2 zv = *reinterpret_cast<const double2 *>(P.z + tb + s * (2 * TB));
-            s_z[wave][BIG ? s / ZEV : (NS > 0 ? s / 2 : s)][lane] = double2{P.g2 * zv.x, P.g2 * zv.y};
-        }
-        if (NS > 0 && !BIG) {
-#pragma unroll
-            for (int k = 0; k < RING; ++k) zr[k] = tl_ldz(P.z, zb + (unsigned)(2 * k * (2 * TB) * 8));
-        }
-    }
-    if (U < SLOTS) {  // rows of the tile outside my chunk contribute nothing to my row vectors
-        s_part[wave][0][lane] = 0.0;
-        s_part[wave][1][lane] = 0.0;
-    }
     // fringe group: row pairs fa0 .. fa0 + fcnt - 1 of diagonal tile (fB, fB), w and 2 gamma z in registers
     const int fcnt = BIG ? 0 : wdv.fcnt, fa0 = wdv.fa0, fB = wdv.fB, fs = wdv.fs, ftgt = wdv.ftgt;
     double2 fw[FRMAX], fgz[FRMAX];
-    int64_t ftb = 0;
-    if (fcnt > 0) ftb = gl_tile_id(fB, fB, P.nb) * GL_TILE_ELEMS + lofs;
 #pragma unroll
-    for (int f = 0; f < FRMAX; ++f) {
-        fw[f] = fgz[f] = double2{0.0, 0.0};
-        if (f < fcnt) {
-            fw[f] = *reinterpret_cast<const double2 *>(P.w + ftb + (int64_t)(fa0 + f) * (2 * TB));
-            const double2 zv = *reinterpret_cast<const double2 *>(P.z + ftb + (int64_t)(fa0 + f) * (2 * TB));
-            fgz[f] = double2{P.g2 * zv.x, P.g2 * zv.y};
+    for (int f = 0; f < FRMAX; ++f) fw[f] = fgz[f] = double2{0.0, 0.0};
+    // element offsets of this lane's first pair in my chunk and in my fringe tile: formed where they are used (prologue and
+    // write-back), from the lane number of that moment -- over the pass they would only hold registers
+    auto chunk_off = [&](int ln) -> int64_t { return (int64_t)wdv.tile * GL_TILE_ELEMS + (int64_t)a0 * (2 * TB) + (ln >> 5) * TB + 2 * (ln & 31); };
+    auto fringe_off = [&](int ln) -> int64_t { return gl_tile_id(fB, fB, P.nb) * GL_TILE_ELEMS + (ln >> 5) * TB + 2 * (ln & 31); };
+    if (has) zb = (unsigned)(chunk_off(lane) * 8);
+    // The bulk loads of the prologue, in the order the first pass wants them: the LDS-resident part of z (straight into
+    // LDS: zg is stored pre-multiplied, so nothing has to pass through registers), the head of the z ring, the fringe, w.
+    // Nothing here waits: the first pass consumes w row pair by row pair as it arrives.
+    auto bulk_loads = [&]() {
+        const int64_t tb0 = chunk_off(lane), ftb = fringe_off(lane);
+        if (has) {
+#pragma unroll
+            for (int s = 0; s < U; ++s) {  // LDS-resident part of 2 gamma z (U = 32: the odd row pairs; rounds: every ZEV-th)
+                if (BIG ? s % ZEV != ZEV - 1 : (NS > 0 && (s & 1) == 0)) continue;
+                tl_dma16(P.zg + tb0 + s * (2 * TB), &s_z[wave][BIG ? s / ZEV : (NS > 0 ? s / 2 : s)][0]);
+            }
+            if (BIG) {
+#pragma unroll
+                for (int s = WRG; s < U; ++s)  // (rounds: the last row pairs of w live in LDS)
+                    tl_dma16(P.w + tb0 + s * (2 * TB), &s_z[wave][ZLN + s - WRG][0]);
+            }
+            if (NS > 0 && !BIG) {
+#pragma unroll
+                for (int k = 0; k < RING; ++k) zr[k] = tl_ldz(P.zg, zb + (unsigned)(2 * k * (2 * TB) * 8));
+            }
         }
-    }
+#pragma unroll
+        for (int f = 0; f < FRMAX; ++f)
+            if (f < fcnt) {
+                fw[f] = *reinterpret_cast<const double2 *>(P.w + ftb + (int64_t)(fa0 + f) * (2 * TB));
+                fgz[f] = *reinterpret_cast<const double2 *>(P.zg + ftb + (int64_t)(fa0 + f) * (2 * TB));
+            }
+        if (has) {
+#pragma unroll
+            for (int s = 0; s < (BIG ? WRG : U); ++s) wreg[s] = *reinterpret_cast<const double2 *>(P.w + tb0 + s * (2 * TB));
+        }
+    };
+    if (U < SLOTS) s_part[wave][0][lane] = 0.0;  // rows of the tile outside my chunk contribute nothing to my row vector
     // rounds (BIG): my tiles are (I + r, J), r < my_nr; round 0 is the resident one when `has`
     const int my_nr = BIG ? wdv.nr : 0, my_rs = wdv.rs;
     const int r_str = has ? 1 : 0;  // my first streamed round
@@ -654,10 +682,43 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
 #pragma unroll
         for (int k = 0; k < RS; ++k) {
             wq[k] = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(P.w) + base + (unsigned)((g0 * RS + k) * (2 * TB) * 8));
-            zq[k] = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(P.z) + base + (unsigned)((g0 * RS + k) * (2 * TB) * 8));
+            zq[k] = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(P.zg) + base + (unsigned)((g0 * RS + k) * (2 * TB) * 8));
         }
     };
-    if (NORMS) {  // sum of squares of the iterate this call starts from
+    // ragged last block column: 0 / 1 factors of my two columns (only the variants with the norms keep them over the pass)
+    auto col_valid = [&](int e) { return (RAGGED && has) ? ((int64_t)wdv.J * TB + c0 + e < P.n ? 1.0 : 0.0) : 1.0; };
+    const double m0 = MASKW ? col_valid(0) : 1.0, m1 = MASKW ? col_valid(1) : 1.0;
+
+    // ---- start-up rendezvous, wait (wave 0; the other waves go on and issue their bulk loads meanwhile)
+    // Below the rounds nothing of the session's state is written before the end of the call, and the first thing a
+    // workgroup needs from another one is a record of iteration 0: a launch that is not co-resident fails there (bounded
+    // poll) exactly as it would fail here, with everything untouched.  So the wait itself is only taken by the rounds
+    // (which update their streamed tiles in place from the first pass on) and under the test hook -- a poll issued now
+    // would sit in this CU's memory queue behind the bulk loads of the other seven waves (measured: 12 us).
+    const bool wait_here = BIG || P.check_rendezvous != 0;
+    if (tid == 0) {
+        const GlGridBar gb{P.bar, 0};
+        s_flag[0] = (!wait_here || gl_spin_until(gb, P.bar, P.rendezvous)) ? 1 : 0;
+        s_flag[1] = 0;
+        s_flag[2] = 0;
+        s_flag[3] = 0;
+    }
+    // (Loads and stores of a wave complete out of order with respect to each other on gfx9, so with both kinds pending the
+    //  compiler can only wait for vmcnt(0).  The prologue's small stores and loads are therefore drained here, and every
+    //  iteration ends drained (bottom of the loop): the bulk loads below are then the only pending operations when the first
+    //  pass starts, and it waits for w row pair by row pair -- vmcnt(31), vmcnt(30), ... -- instead of for all of it.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    bulk_loads();
+    // the node values of iteration 0 (requested before the bulk loads: this does not wait for those)
+#pragma unroll
+    for (int j = 0; j < NACQ; ++j) {
+        const int k = wave + TW * j;
+        if (k < nblk) s_node[k][lane] = double2{P.gamma * nv_d[j], P.gamma * (nv_d[j] - nv_p[j])};
+    }
+    tl_barrier();
+    const bool met = s_flag[0] != 0;  // (no stamp here: a store between the bulk loads and the first pass would cost the pass its counted waits)
+    if (met && !active) return;  // nothing to do here: no edges, no node block (nobody waits for this workgroup)
+    if (NORMS) {  // sum of squares of the iterate this call starts from (waits for all of it: converge-mode calls are long)
         double acc = 0;
         if (BIG) {
 #pragma unroll 1
@@ -680,49 +741,8 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         acc = wave_sum(acc);
         if (lane == 0) s_wcarry[wave] = acc;
     }
-    // ragged last block column: 0 / 1 factors of my two columns
-    double m0 = 1.0, m1 = 1.0;
-    if (RAGGED && has) {
-        m0 = (int64_t)wdv.J * TB + c0 < P.n ? 1.0 : 0.0;
-        m1 = (int64_t)wdv.J * TB + c0 + 1 < P.n ? 1.0 : 0.0;
-    }
-    // ---- dual state of my node block (owner workgroups, wave 0, lane = node): in LDS, not in registers that
-    //      every wave of the grid would have to set aside
-    const int64_t own_i = (int64_t)own * TB + lane;
-    if (own >= 0 && wave == 0) {
-        s_dual[0][lane] = P.dvar[own_i];
-        s_dual[1][lane] = P.ybar[own_i];
-        s_dual[2][lane] = P.pbar[own_i];
-        s_dual[3][lane] = P.dprev[own_i];
-        if (lane < 4) s_bn[lane] = 0.0;
-    }
-    const auto r_part = __builtin_amdgcn_make_buffer_rsrc((void *)P.part, 0, (int)((int64_t)P.n_entries * 2 * TB * 16), 0x00020000);
-    const auto r_nval = __builtin_amdgcn_make_buffer_rsrc((void *)P.nval, 0, (int)(P.nb * 2 * TB * 16), 0x00020000);
-    const auto r_wn = __builtin_amdgcn_make_buffer_rsrc((void *)P.wnorm, 0, (int)(4 * P.NWG * 2 * 16), 0x00020000);
-    const auto r_bn = __builtin_amdgcn_make_buffer_rsrc((void *)P.bnrm, 0, (int)(4 * P.nb * 4 * 16), 0x00020000);
-    const auto r_lk = __builtin_amdgcn_make_buffer_rsrc((void *)P.look, 0, 4 * 4 * 16, 0x00020000);
-
-    // ---- start-up rendezvous: every workgroup of the grid is on the chip, or nobody touches anything.  The arrival
-    //      counter is monotonic over the launches of the session (target = arrivals so far + grid), so nothing has to be
-    //      reset between launches: the launch is the only thing on the stream.
-    if (P.dbg) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        cs[1] = __builtin_amdgcn_s_memrealtime();
-    }
-    if (tid == 0) {
-        const GlGridBar gb{P.bar, 0};
-        __hip_atomic_fetch_add(P.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_flag[0] = gl_spin_until(gb, P.bar, P.rendezvous) ? 1 : 0;
-        s_flag[1] = 0;
-        s_flag[2] = 0;
-        s_flag[3] = 0;
-    }
-    __syncthreads();
-    const bool met = s_flag[0] != 0;
-    if (P.dbg) cs[2] = __builtin_amdgcn_s_memrealtime();
-    if (met && !active) return;  // nothing to do here: no edges, no node block (nobody waits for this workgroup)
     bool failed = !met;
-    int done_iters = 0, stopped = 0;
+    int done_iters = 0, stopped = 0, fail_it = 0;
     double rel_p = INFINITY, rel_d = INFINITY;
     const bool rule_on = P.tol > 0;
     bool evaluated = false, exact = false;
@@ -756,7 +776,6 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         }
         return true;
     };
-    const double nscale = GL_TILE_FAST_ARITH ? P.gamma : 1.0;  // what the published node values are multiplied by
     for (int it = 0; met && it <= P.maxit; ++it) {
         const unsigned tag_in = P.tag0 + (unsigned)it;        // node values that are the input of iteration `it`
         const unsigned tag_out = P.tag0 + (unsigned)it + 1u;  // what iteration `it` produces
@@ -768,62 +787,34 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
         if (stamp) ts[0] = __builtin_amdgcn_s_memrealtime();
 
-        // ================= acquire: {d, pbar} of my node blocks, and the norm records of iteration it - 1 =================
+        // ================= acquire: {gamma d, gamma u} of my node blocks, and the norm records of iteration it - 1 =================
         {
             bool good = true;
             if (!last_pass) {
-                if (it == 0) {  // the state the previous call (or init) left in memory
-#pragma unroll
-                    for (int j = 0; j < NACQ; ++j) {
-                        const int k = wave + TW * j;
-                        if (k < nblk) {
-                            const int64_t i = (int64_t)gd_int(GD_BLK + k) * TB + lane;
-                            s_node[k][lane] = double2{nscale * P.dvar[i], nscale * P.pbar[i]};
-                        }
-                    }
+                if (it == 0) {  // (the state the previous call, or init, left in memory: in s_node since the prologue)
                 } else if (wave < nblk) {
-                    // GL_TILE_PROBES = 2 keeps two probes in flight, half a round trip apart (a probe that finds the values
-                    // missing costs a whole round trip, ~1 us, before the next one can see them).  Measured and rejected: 6.35
-                    // against 5.9 us per iteration at n = 1030, 12.4 against 10.4 at n = 4096 -- the second probe's registers
-                    // push the pass into scratch, and most first probes succeed anyway.
+                    // (two probes in flight, half a round trip apart, measured slower: their registers push the pass into
+                    //  scratch, and most first probes succeed anyway)
                     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                     unsigned spins = 0;
-                    tl_u4 g[NACQ][2], h[NACQ][2];
-                    auto probe = [&](tl_u4 (&q)[NACQ][2]) {
+                    tl_u4 g[NACQ][2];
+                    for (;;) {
+                        bool ok = true;
 #pragma unroll
                         for (int j = 0; j < NACQ; ++j) {
                             const int k = wave + TW * j;
-                            q[j][0] = q[j][1] = tl_u4{0u, tag_in, 0u, tag_in};
+                            g[j][0] = g[j][1] = tl_u4{0u, tag_in, 0u, tag_in};
                             if (k < nblk) {
                                 const int off = (gd_int(GD_BLK + k) * 2 * TB + lane) * 16;
-                                q[j][0] = __builtin_amdgcn_raw_buffer_load_b128(r_nval, off, 0, 16);
-                                q[j][1] = __builtin_amdgcn_raw_buffer_load_b128(r_nval, off + TB * 16, 0, 16);
+                                g[j][0] = __builtin_amdgcn_raw_buffer_load_b128(r_nval, off, 0, 16);
+                                g[j][1] = __builtin_amdgcn_raw_buffer_load_b128(r_nval, off + TB * 16, 0, 16);
                             }
+                            ok = ok && tl_ok(g[j][0], tag_in) && tl_ok(g[j][1], tag_in);
                         }
-                    };
-                    auto all_ok = [&](const tl_u4 (&q)[NACQ][2]) {
-                        bool ok = true;
-#pragma unroll
-                        for (int j = 0; j < NACQ; ++j) ok = ok && tl_ok(q[j][0], tag_in) && tl_ok(q[j][1], tag_in);
-                        return __all(ok);
-                    };
-                    probe(g);
-                    for (;;) {
-                        if (GL_TILE_PROBES > 1) {
-                            __builtin_amdgcn_s_sleep(GL_TILE_PROBE_GAP);
-                            probe(h);
-                            asm volatile("" ::: "memory");
-                        }
-                        if (all_ok(g)) break;
+                        asm volatile("" ::: "memory");
+                        if (__all(ok)) break;
                         if (!tl_spin(spins, t0, err)) {
                             good = false;
-                            break;
-                        }
-                        probe(g);
-                        asm volatile("" ::: "memory");
-                        if (GL_TILE_PROBES > 1 && all_ok(h)) {
-#pragma unroll
-                            for (int j = 0; j < NACQ; ++j) g[j][0] = h[j][0], g[j][1] = h[j][1];
                             break;
                         }
                     }
@@ -893,9 +884,10 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             }
             if (!good) s_flag[1] = 1;
         }
-        __syncthreads();
+        tl_barrier();
         if (s_flag[1]) {
             failed = true;
+            fail_it = it;
             break;
         }
         if (want_rule) {
@@ -912,22 +904,22 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         // ================= edge phase =================
         if (stamp) ts[1] = __builtin_amdgcn_s_memrealtime();
         double nqy = 0, nw = 0;
-        double accp[NACQ], accw[NACQ];  // BIG: what the rounds before the last one add to the records I publish
+        double accp[NACQ];  // BIG: what the rounds before the last one add to the records I publish
 #pragma unroll
-        for (int j = 0; j < NACQ; ++j) accp[j] = accw[j] = 0.0;
+        for (int j = 0; j < NACQ; ++j) accp[j] = 0.0;
         if constexpr (!BIG) {
             if (has) {
                 const double2 cv0 = s_node[wdv.sj][c0], cv1 = s_node[wdv.sj][c0 + 1];
-                double col[4] = {0.0, 0.0, 0.0, 0.0};
-                tl_chunk_pass<U, RAGGED, NORMS>(P, wreg, zr, &s_z[wave][0][lane], zb, &s_node[wdv.si][2 * a0], cv0.x, cv1.x, cv0.y,
-                                                cv1.y, m0, m1, &s_part[wave][0][2 * a0], col, lane, wave >= TW / 2, nqy, nw);
-                tl_put_cols(col, &s_part[wave][2][0], lane);
+                double col[2] = {0.0, 0.0};
+                tl_chunk_pass<U, MASKW, NORMS>(P, wreg, zr, &s_z[wave][0][lane], zb, &s_node[wdv.si][2 * a0], cv0.x, cv1.x, cv0.y,
+                                               cv1.y, m0, m1, &s_part[wave][0][2 * a0], col, lane, wave >= TW / 2, nqy, nw);
+                tl_put_cols(col, &s_part[wave][1][0], lane);
             }
         } else {
             // Round 0 stands apart from the loop over the later rounds so that the rings of the streamed pass are not live
             // while the resident pass runs (its 256 registers are spoken for).
             const int nrw = gd_int(GD_NRND);
-            double col[4] = {0.0, 0.0, 0.0, 0.0};
+            double col[2] = {0.0, 0.0};
             double2 cv0 = double2{0.0, 0.0}, cv1 = cv0;
             if (my_nr > 0) cv0 = s_node[wdv.sj][c0], cv1 = s_node[wdv.sj][c0 + 1];
             auto fold = [&](int r) {  // row vectors of round r -> the records I publish
@@ -937,11 +929,8 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     if (k < nblk) {
                         const int rm = ((r < 4 ? gd_int(GD_ROW + k) : gd_int(GD_ROW2 + k)) >> (8 * (r & 3))) & 255;
 #pragma unroll
-                        for (int cs = 0; cs < TW; ++cs)
-                            if ((rm >> cs) & 1) {
-                                accp[j] += s_part[cs][0][lane];
-                                accw[j] += s_part[cs][1][lane];
-                            }
+                        for (int cs2 = 0; cs2 < TW; ++cs2)
+                            if ((rm >> cs2) & 1) accp[j] += s_part[cs2][0][lane];
                     }
                 }
             };
@@ -949,21 +938,21 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 const double2 *rows = &s_node[my_rs & 15][0];
                 if (has) {
 #pragma unroll
-                    for (int k = 0; k < RING; ++k) zr[k] = tl_ldz<NT>(P.z, zb + (unsigned)(RoundsSplit<NORMS>::slot(k) * (2 * TB) * 8));
-                    tl_resident_pass_rounds<RAGGED, NORMS, NT>(P, wreg, zr, &s_z[wave][0][lane], zb, rows, cv0.x, cv1.x, cv0.y, cv1.y, m0, m1,
-                                                               &s_part[wave][0][0], col, lane, wave >= TW / 2, nqy, nw);
+                    for (int k = 0; k < RING; ++k) zr[k] = tl_ldz<NT>(P.zg, zb + (unsigned)(RoundsSplit<NORMS>::slot(k) * (2 * TB) * 8));
+                    tl_resident_pass_rounds<MASKW, NORMS, NT>(P, wreg, zr, &s_z[wave][0][lane], zb, rows, cv0.x, cv1.x, cv0.y, cv1.y, m0, m1,
+                                                              &s_part[wave][0][0], col, lane, wave >= TW / 2, nqy, nw);
                 } else {  // (a column whose first tile here is its diagonal tile)
                     asm volatile("" : "+v"(lane_s));  // (as below)
                     double2 wq[RS], zq[RS];
                     ring_load(wq, zq, tile_off(0));
-                    tl_stream_pass<NORMS, true, NT>(P, wq, zq, tile_off(0), tile_off(0), rows, cv0.x, cv1.x, cv0.y, cv1.y, wdv.I == wdv.J, jv0, jv1,
-                                                &s_part[wave][0][0], col, lane_s, nqy, nw, g0);
+                    tl_stream_pass<NORMS, NT>(P, wq, zq, tile_off(0), tile_off(0), rows, cv0.x, cv1.x, cv0.y, cv1.y, wdv.I == wdv.J, jv0, jv1,
+                                              &s_part[wave][0][0], col, lane_s, nqy, nw, g0);
                 }
             }
             if (nrw > 1) {
-                __syncthreads();
+                tl_barrier();
                 fold(0);
-                __syncthreads();
+                tl_barrier();
                 // what the streamed rounds derive from the lane number (offsets, masks) is recomputed here every iteration:
                 // hoisted out of the iteration loop it would live through the resident pass, which has no register to spare
                 asm volatile("" : "+v"(lane_s));
@@ -976,83 +965,60 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     if (r < my_nr) {
                         const unsigned tb = tile_off(r), nxt = r + 1 < my_nr ? tile_off(r + 1) : tb;
                         const double2 *rows = &s_node[(my_rs >> (4 * r)) & 15][0];
-                        tl_stream_pass<NORMS, true, NT>(P, wq, zq, tb, nxt, rows, cv0.x, cv1.x, cv0.y, cv1.y, wdv.I + r == wdv.J, jv0, jv1,
-                                                    &s_part[wave][0][0], col, lane_s, nqy, nw, g0);
+                        tl_stream_pass<NORMS, NT>(P, wq, zq, tb, nxt, rows, cv0.x, cv1.x, cv0.y, cv1.y, wdv.I + r == wdv.J, jv0, jv1,
+                                                  &s_part[wave][0][0], col, lane_s, nqy, nw, g0);
                     }
                     if (r == nrw - 1) break;  // (the barrier and the last fold are those of the publish phase below)
-                    __syncthreads();
+                    tl_barrier();
                     fold(r);
-                    __syncthreads();
+                    tl_barrier();
                 }
             }
-            if (my_nr > 0) tl_put_cols(col, &s_part[wave][2][0], lane);
+            if (my_nr > 0) tl_put_cols(col, &s_part[wave][1][0], lane);
         }
-        if (fcnt > 0) {  // my fringe row pairs (diagonal tile: entries i < j < n only)
-            const double c = P.c, g = P.gamma;
+        if (fcnt > 0) {  // my fringe row pairs (diagonal tile: entries i < j < n only; zg is ZG_OUTSIDE elsewhere: p = 0 there)
+            const double c = P.c, omc = P.omc;
             const double2 cv0 = s_node[fs][c0], cv1 = s_node[fs][c0 + 1];
-            double colp0 = 0, colp1 = 0, colw0 = 0, colw1 = 0;
-            double rsp[FRMAX], rsw[FRMAX];
+            double colp0 = 0, colp1 = 0;
+            double rsp[FRMAX];
 #pragma unroll
             for (int f = 0; f < FRMAX; ++f) {
-                rsp[f] = rsw[f] = 0.0;
+                rsp[f] = 0.0;
                 if (f < fcnt) {
                     const int a = fa0 + f;
                     const double2 rv = s_node[fs][2 * a + half];
-                    const int64_t i = (int64_t)fB * TB + 2 * a + half;
-                    double wn[2], pp[2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int64_t j = (int64_t)fB * TB + c0 + e;
-                        const bool valid = i < j && j < P.n;
-                        const double w = e ? fw[f].y : fw[f].x;
-                        const double y = tl_lin(c, g, w, rv.x, e ? cv1.x : cv0.x);
-                        const double tt = y - (e ? fgz[f].y : fgz[f].x);
-                        const double pr = tt > 0 ? tt : 0.0;
-                        const double q = tl_lin(c, g, pr, rv.y, e ? cv1.y : cv0.y);
-                        const double wnew = (w - y) + q;
-                        pp[e] = valid ? pr : 0.0;
-                        wn[e] = valid ? wnew : 0.0;
-                        if (NORMS) {
-                            const double dq = valid ? q - y : 0.0;
-                            nqy = __builtin_fma(dq, dq, nqy);
-                            nw = __builtin_fma(wn[e], wn[e], nw);
-                        }
+                    double pp[2], t[2];
+                    tl_edge(c, fw[f].x, fgz[f].x, rv.x, rv.y, cv0.x, cv0.y, pp[0], t[0]);
+                    tl_edge(c, fw[f].y, fgz[f].y, rv.x, rv.y, cv1.x, cv1.y, pp[1], t[1]);
+                    if (NORMS) {  // (without the norms the entries outside the lattice carry a bounded value nobody reads)
+                        const int64_t i = (int64_t)fB * TB + 2 * a + half, j = (int64_t)fB * TB + c0;
+                        t[0] = (i < j && j < P.n) ? t[0] : 0.0;  // (w is 0 there and stays 0)
+                        t[1] = (i < j + 1 && j + 1 < P.n) ? t[1] : 0.0;
                     }
+                    tl_new_w<NORMS>(c, omc, fw[f].x, t[0], nqy, nw);
+                    tl_new_w<NORMS>(c, omc, fw[f].y, t[1], nqy, nw);
                     colp0 += pp[0];
                     colp1 += pp[1];
-                    colw0 += wn[0];
-                    colw1 += wn[1];
-                    fw[f] = double2{wn[0], wn[1]};
                     rsp[f] = half_sum(pp[0] + pp[1]);
-                    rsw[f] = half_sum(wn[0] + wn[1]);
                 }
             }
             colp0 = add_xor32(colp0);
             colp1 = add_xor32(colp1);
-            colw0 = add_xor32(colw0);
-            colw1 = add_xor32(colw1);
             // Rows and columns of a diagonal tile are the same node block, and that block is my chunk's row or
-            // column block (or I have no chunk): the group's partials are folded into those vectors of mine.
+            // column block (or I have no chunk): the group's partials are folded into that vector of mine.
             // LDS operations of one wave execute in order.
-            double *vp = &s_part[wave][ftgt][0], *vw = &s_part[wave][ftgt + 1][0];
+            double *vp = &s_part[wave][ftgt][0];
             if (half == 0) {
-                // (row vectors of a chunk shorter than a tile are zero outside its rows: rewritten every pass)
-                const bool keep0 = has && (ftgt == 2 || (c0 >= 2 * a0 && c0 < 2 * (a0 + U)));
+                // (the row vector of a chunk shorter than a tile is zero outside its rows: rewritten every pass)
+                const bool keep0 = has && (ftgt == 1 || (c0 >= 2 * a0 && c0 < 2 * (a0 + U)));
                 const double b0 = keep0 ? vp[c0] : 0.0, b1 = keep0 ? vp[c0 + 1] : 0.0;
-                const double e0 = keep0 ? vw[c0] : 0.0, e1 = keep0 ? vw[c0 + 1] : 0.0;
                 vp[c0] = b0 + colp0;
                 vp[c0 + 1] = b1 + colp1;
-                vw[c0] = e0 + colw0;
-                vw[c0 + 1] = e1 + colw1;
             }
             if ((lane & 31) == 0) {
 #pragma unroll
                 for (int f = 0; f < FRMAX; ++f)
-                    if (f < fcnt) {
-                        const int r = 2 * (fa0 + f) + half;
-                        vp[r] += rsp[f];
-                        vw[r] += rsw[f];
-                    }
+                    if (f < fcnt) vp[2 * (fa0 + f) + half] += rsp[f];
             }
         }
         if (NORMS) {
@@ -1082,14 +1048,14 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             o[0] = ts[1];
             o[1] = ts[2];
         }
-        __syncthreads();
+        tl_barrier();
 
         // ================= publish: one record per node block I touch =================
 #pragma unroll
         for (int j = 0; j < NACQ; ++j) {
             const int k = wave + TW * j;
             if (k >= nblk) break;
-            double sp = accp[j], sw = accw[j];
+            double sp = accp[j];
             int rm = gd_int(GD_ROW + k);
             const int cm = gd_int(GD_COL + k);
             if (BIG) {  // the row vectors of the last round
@@ -1097,19 +1063,11 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 rm = ((r < 4 ? rm : gd_int(GD_ROW2 + k)) >> (8 * (r & 3))) & 255;
             }
 #pragma unroll
-            for (int cs = 0; cs < TW; ++cs) {
-                if ((rm >> cs) & 1) {
-                    sp += s_part[cs][0][lane];
-                    sw += s_part[cs][1][lane];
-                }
-                if ((cm >> cs) & 1) {
-                    sp += s_part[cs][2][lane];
-                    sw += s_part[cs][3][lane];
-                }
+            for (int cs2 = 0; cs2 < TW; ++cs2) {
+                if ((rm >> cs2) & 1) sp += s_part[cs2][0][lane];
+                if ((cm >> cs2) & 1) sp += s_part[cs2][1][lane];
             }
-            const int off = (gd_int(GD_ENT + k) * 2 * TB + lane) * 16;
-            __builtin_amdgcn_raw_buffer_store_b128(tl_gran(sp, tag_out), r_part, off, 0, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(tl_gran(sw, tag_out), r_part, off + TB * 16, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(tl_gran(sp, tag_out), r_part, (gd_int(GD_ENT + k) * TB + lane) * 16, 0, 16);
         }
         if (tid == 0) {
             double a = s_wn[0][0], b = s_wn[0][1];
@@ -1166,28 +1124,37 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
 
         // ================= node phase: the owner of a block sums its records and updates the dual state =================
         if (own >= 0) {
-            __syncthreads();  // everybody has read s_part (its first 8 KiB become s_own now)
-            double (*s_own)[2][TB] = reinterpret_cast<double (*)[2][TB]>(&s_part[0][0][0]);
+            tl_barrier();  // everybody has read s_part (its first 4 KiB become s_own now)
+            double (*s_own)[TB] = reinterpret_cast<double (*)[TB]>(&s_part[0][0][0]);
             bool good = true;
-            double sp = 0, sw = 0;
+            double sp = 0;
             {
                 early_look();  // (wave TW - 1: before its share of the poll, whose records are still on their way)
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 unsigned spins = 0;
+                // wave 1 also fetches the block sums of gamma u that this iteration's input state was published with (a whole
+                // pass ago): sum_j gamma u_j over all nodes, in a fixed order
+                constexpr int NUS = BIG ? 3 : 1;  // node blocks per lane (nb <= 64, rounds <= 192)
+                tl_u4 gu[NUS];
+                auto load_gu = [&]() {
+#pragma unroll
+                    for (int q = 0; q < NUS; ++q) {
+                        gu[q] = tl_u4{0u, tag_in, 0u, tag_in};
+                        if (wave == 1 && q * 64 + lane < P.nb)
+                            gu[q] = __builtin_amdgcn_raw_buffer_load_b128(r_us, (int)(((tag_in & 1u) * (unsigned)P.nb + (unsigned)(q * 64 + lane)) * 16u), 0, 16);
+                    }
+                };
+                load_gu();
                 for (int eb = own_e0 + wave; eb < own_e1 && good; eb += TW * RND) {  // rounds of up to RND records per wave
-                    tl_u4 g[RND][2];
+                    tl_u4 g[RND];
                     for (;;) {
                         bool ok = true;
 #pragma unroll
                         for (int u = 0; u < RND; ++u) {
                             const int e = eb + u * TW;
-                            g[u][0] = g[u][1] = tl_u4{0u, tag_out, 0u, tag_out};
-                            if (e < own_e1) {
-                                const int off = (e * 2 * TB + lane) * 16;
-                                g[u][0] = __builtin_amdgcn_raw_buffer_load_b128(r_part, off, 0, 16);
-                                g[u][1] = __builtin_amdgcn_raw_buffer_load_b128(r_part, off + TB * 16, 0, 16);
-                            }
-                            ok = ok && tl_ok(g[u][0], tag_out) && tl_ok(g[u][1], tag_out);
+                            g[u] = tl_u4{0u, tag_out, 0u, tag_out};
+                            if (e < own_e1) g[u] = __builtin_amdgcn_raw_buffer_load_b128(r_part, (e * TB + lane) * 16, 0, 16);
+                            ok = ok && tl_ok(g[u], tag_out);
                         }
                         asm volatile("" ::: "memory");
                         if (__all(ok)) break;
@@ -1198,19 +1165,35 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     }
 #pragma unroll
                     for (int u = 0; u < RND; ++u)
-                        if (eb + u * TW < own_e1) {
-                            sp += tl_val(g[u][0]);
-                            sw += tl_val(g[u][1]);
-                        }
+                        if (eb + u * TW < own_e1) sp += tl_val(g[u]);
                 }
-                s_own[wave][0][lane] = sp;
-                s_own[wave][1][lane] = sw;
+                s_own[wave][lane] = sp;
+                if (wave == 1) {
+                    for (;;) {
+                        bool ok = true;
+#pragma unroll
+                        for (int q = 0; q < NUS; ++q) ok = ok && tl_ok(gu[q], tag_in);
+                        asm volatile("" ::: "memory");
+                        if (__all(ok)) break;
+                        if (!tl_spin(spins, t0, err)) {
+                            good = false;
+                            break;
+                        }
+                        load_gu();
+                    }
+                    double t = 0.0;
+#pragma unroll
+                    for (int q = 0; q < NUS; ++q) t += (q * 64 + lane < P.nb) ? tl_val(gu[q]) : 0.0;
+                    t = wave_sum(t);
+                    if (lane == 0) s_gu = t;
+                }
                 if (!good) s_flag[1] = 1;
             }
             if (stamp) ts[4] = __builtin_amdgcn_s_memrealtime();
-            __syncthreads();
+            tl_barrier();
             if (s_flag[1]) {
                 failed = true;
+                fail_it = it;
                 break;
             }
             if (wave == 0) {
@@ -1218,30 +1201,34 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 //  variants with norms, and their reloads sit between the owner's poll and the node values it publishes)
                 int ln = lane;
                 asm volatile("" : "+v"(ln));
-                sp = s_own[0][0][ln];
-                sw = s_own[0][1][ln];
+                sp = s_own[0][ln];
 #pragma unroll
-                for (int v = 1; v < TW; ++v) {
-                    sp += s_own[v][0][ln];
-                    sw += s_own[v][1][ln];
-                }
+                for (int v = 1; v < TW; ++v) sp += s_own[v][ln];
                 const bool real = (int64_t)own * TB + ln < P.n;
-                const double d_cur = s_dual[0][ln], yb_cur = s_dual[1][ln], pb_cur = s_dual[2][ln];
-                const double qb = pb_cur + P.gamma * sp;  // :154
+                const double d_cur = s_dual[0][ln], yb_cur = s_dual[1][ln], pb_cur = s_dual[2][ln], gsw_cur = s_dual[4][ln];
+                const double gsp = P.gamma * sp;
+                const double qb = pb_cur + gsp;           // :154
                 const double dq = qb - yb_cur;            // == -ybar + qbar (:159)
                 double dq2 = real ? dq * dq : 0.0;
                 double d2 = real ? d_cur * d_cur : 0.0;
                 const double dnew = (d_cur - yb_cur) + qb;                  // :164
-                const double ybn = dnew + P.gamma * sw;                     // :148 of the next iteration
+                // gamma S w' = (1 - c) gamma S w + c gamma S p + gamma ((n - 2) gamma u_i + sum_j gamma u_j)  (head of the file)
+                const double gu_i = P.gamma * (d_cur - pb_cur);
+                const double gsw = __builtin_fma(P.omc, gsw_cur, __builtin_fma(P.c, gsp, P.gamma * __builtin_fma(P.nm2, gu_i, s_gu)));
+                const double ybn = dnew + gsw;                              // :148 of the next iteration
                 const double pbn = (ybn - sqrt(ybn * ybn + P.a4g)) / 2;     // :151
                 const double d_new = real ? dnew : 0.0, pb_new = real ? pbn : 0.0;
                 s_dual[3][ln] = d_cur;
                 s_dual[0][ln] = d_new;
                 s_dual[1][ln] = real ? ybn : 0.0;
                 s_dual[2][ln] = pb_new;
+                s_dual[4][ln] = real ? gsw : 0.0;
                 const int off = (own * 2 * TB + ln) * 16;
-                __builtin_amdgcn_raw_buffer_store_b128(tl_gran(nscale * d_new, tag_out), r_nval, off, 0, 16);
-                __builtin_amdgcn_raw_buffer_store_b128(tl_gran(nscale * pb_new, tag_out), r_nval, off + TB * 16, 0, 16);
+                const double gu_new = P.gamma * (d_new - pb_new);
+                __builtin_amdgcn_raw_buffer_store_b128(tl_gran(P.gamma * d_new, tag_out), r_nval, off, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(tl_gran(gu_new, tag_out), r_nval, off + TB * 16, 0, 16);
+                const double us = wave_sum(gu_new);
+                if (ln == 0) __builtin_amdgcn_raw_buffer_store_b128(tl_gran(us, tag_out), r_us, (int)(((tag_out & 1u) * (unsigned)P.nb + (unsigned)own) * 16u), 0, 16);
                 if (NORMS) {  // my block's norm partials (the node values are out: nobody waits for these)
                     dq2 = wave_sum(dq2);
                     d2 = wave_sum(d2);
@@ -1284,13 +1271,11 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     __builtin_amdgcn_raw_buffer_store_b128(tl_gran(v, tag_out), r_bn, ((((it & 3) * (int)P.nb + own) * 4) + lane) * 16, 0, 16);
                 }
             }
-            __syncthreads();  // s_own has been read: s_part is free for the next pass (its zeros first, below)
-            if (U < SLOTS) {  // s_own overwrote row vectors: back to zero outside the chunks' rows
-                s_part[wave][0][lane] = 0.0;
-                s_part[wave][1][lane] = 0.0;
-            }
+            tl_barrier();  // s_own has been read: s_part is free for the next pass (its zeros first, below)
+            if (U < SLOTS) s_part[wave][0][lane] = 0.0;  // s_own overwrote row vectors: back to zero outside the chunks' rows
         }
-        if (P.dbg && it == 0) cs[3] = __builtin_amdgcn_s_memrealtime();  // end of the first iteration
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see the prologue (by now everything has long completed)
+        if (it == 0) call_stamp(3);  // end of the first iteration
         if (stamp && tid == 0) {
             ts[5] = __builtin_amdgcn_s_memrealtime();
             unsigned long long *o = P.dbg + ((size_t)wg * 16 + (it - 8)) * 6;
@@ -1304,21 +1289,33 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             // (asynchronous ones).  ctr[1] may hold anything here -- the streaming engine re-arms it to 0 after its calls
             P.ctr[1] = P.it0;
             P.ctr[2] = P.it0;
-            P.ctr[4] = met ? 2 : 1;  // 1: the workgroups never met; 2: a hand-off was lost in mid-run
+            // 1: the workgroups never met (also: below the rounds, the first hand-offs of the call never arrived -- the same
+            // thing seen one step later, and nothing has been written); 2: a hand-off was lost in mid-run
+            P.ctr[4] = (!met || (!BIG && fail_it <= 1)) ? 1 : 2;
         }
         return;
     }
-    // ---- registers back to the iterate buffer, dual state back to memory, bookkeeping for the host / the other engines
-    if (P.dbg) cs[4] = __builtin_amdgcn_s_memrealtime();
+    // ---- registers back to the iterate buffer, dual state back to memory, bookkeeping for the host / the other engines.
+    //      Entries outside i < j < n return to the exact zeros every engine expects there.
+    call_stamp(4);
+    int lw = lane;
+    asm volatile("" : "+v"(lw));
     if (has) {
-        const int64_t tb = (int64_t)wdv.tile * GL_TILE_ELEMS + (int64_t)a0 * (2 * TB) + lofs;
+        const int64_t tb0 = chunk_off(lw);
 #pragma unroll
-        for (int s = 0; s < U; ++s)
-            *reinterpret_cast<double2 *>(P.w + tb + s * (2 * TB)) = (BIG && s >= WRG) ? s_z[wave][ZLN + (s >= WRG ? s - WRG : 0)][lane] : wreg[s];
+        for (int s = 0; s < U; ++s) {
+            double2 v = (BIG && s >= WRG) ? s_z[wave][ZLN + (s >= WRG ? s - WRG : 0)][lane] : wreg[s];
+            if (RAGGED && !MASKW) v = double2{((int64_t)wdv.J * TB + 2 * (lw & 31) < P.n ? 1.0 : 0.0) * v.x, ((int64_t)wdv.J * TB + 2 * (lw & 31) + 1 < P.n ? 1.0 : 0.0) * v.y};
+            *reinterpret_cast<double2 *>(P.wout + tb0 + s * (2 * TB)) = v;
+        }
     }
 #pragma unroll
     for (int f = 0; f < FRMAX; ++f)
-        if (f < fcnt) *reinterpret_cast<double2 *>(P.w + ftb + (int64_t)(fa0 + f) * (2 * TB)) = fw[f];
+        if (f < fcnt) {
+            const int64_t i = (int64_t)fB * TB + 2 * (fa0 + f) + (lw >> 5), j = (int64_t)fB * TB + 2 * (lw & 31);
+            *reinterpret_cast<double2 *>(P.wout + fringe_off(lw) + (int64_t)(fa0 + f) * (2 * TB)) =
+                double2{(i < j && j < P.n) ? fw[f].x : 0.0, (i < j + 1 && j + 1 < P.n) ? fw[f].y : 0.0};
+        }
     if (own >= 0 && wave == 0 && done_iters > 0) {
         P.dvar[own_i] = s_dual[0][lane];
         P.ybar[own_i] = s_dual[1][lane];
@@ -1328,11 +1325,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     }
     if (P.dbg) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        cs[5] = __builtin_amdgcn_s_memrealtime();
-        if (lane == 0) {
-            unsigned long long *o = P.dbg + (size_t)P.NWG * 16 * (6 + 2 * TW) + ((size_t)wg * TW + wave) * 8;
-            for (int q = 0; q < 6; ++q) o[q] = cs[q];
-        }
+        call_stamp(5);
     }
     if (wg == 0 && tid == 0) {
         const long long itf = P.it0 + done_iters;
@@ -1348,6 +1341,25 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     }
 }
 
+// zg = 2 gamma z in the tiled layout (the product the reference forms, :150, rounded the same way), ZG_OUTSIDE at every
+// entry outside i < j < n.  One workgroup per tile; formed once per gl_logdeg_init.
+__global__ __launch_bounds__(256) void k_make_zg(const double *__restrict__ z, double *__restrict__ zg, int64_t n, int64_t nb, double g2) {
+    int I, J;
+    gl_tile_decode((int64_t)blockIdx.x, nb, I, J);
+    const int64_t base = (int64_t)blockIdx.x * GL_TILE_ELEMS;
+#pragma unroll
+    for (int k = 0; k < GL_TILE_ELEMS / (2 * 256); ++k) {
+        const int e = 2 * ((int)threadIdx.x + 256 * k);  // two neighbouring columns of one row
+        const int r = e / TB, c = e % TB;
+        const int64_t i = (int64_t)I * TB + r, j = (int64_t)J * TB + c;
+        const double2 v = *reinterpret_cast<const double2 *>(z + base + e);
+        double2 o;
+        o.x = (i < j && j < n) ? g2 * v.x : ZG_OUTSIDE;
+        o.y = (i < j + 1 && j + 1 < n) ? g2 * v.y : ZG_OUTSIDE;
+        *reinterpret_cast<double2 *>(zg + base + e) = o;
+    }
+}
+
 }  // namespace
 
 // =========================================================================== host side
@@ -1359,6 +1371,9 @@ struct gl_tile {
     void *arena = nullptr;      // descriptors, record buffers, rendezvous words: one allocation
     size_t gran_off = 0, gran_bytes = 0;  // the record buffers inside it
     unsigned long long *dbg = nullptr;
+    double *zg = nullptr;       // 2 gamma z in the tiled layout, ZG_OUTSIDE outside i < j < n (inside the arena) ...
+    double zg_g2 = 0.0;         // ... the factor it was formed with (0: not yet) ...
+    int64_t zg_version = -1;    // ... and the version of the session's distances it was formed from
     unsigned next_tag = 1u;     // first tag of the next launch (a launch uses maxit + 2 consecutive ones, never 0)
     unsigned arrivals = 0;      // workgroups that have arrived at the start-up rendezvous over all launches so far
 };
@@ -1400,10 +1415,11 @@ static int tile_finish(gl_logdeg *s, std::vector<WaveDesc> &wd, std::vector<WgDe
     if (!t) return GL_E_NOMEM;
     auto up256 = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t b_wd = up256(wd.size() * sizeof(WaveDesc)), b_gd = up256(gd.size() * sizeof(WgDesc));
-    const size_t b_part = up256((size_t)n_entries * 2 * TB * 16), b_nval = up256((size_t)nb * 2 * TB * 16);
+    const size_t b_part = up256((size_t)n_entries * TB * 16), b_nval = up256((size_t)nb * 2 * TB * 16), b_us = up256((size_t)2 * nb * 16);
     const size_t b_wn = up256((size_t)4 * NWG * 2 * 16), b_bn = up256((size_t)4 * nb * 4 * 16), b_lk = up256((size_t)4 * 4 * 16);
     const size_t b_bar = up256((size_t)GL_BAR_WORDS * 4);
-    const size_t total = b_wd + b_gd + b_part + b_nval + b_wn + b_bn + b_lk + b_bar;
+    const size_t b_zg = up256((size_t)D.ntiles * GL_TILE_ELEMS * sizeof(double));
+    const size_t total = b_wd + b_gd + b_part + b_nval + b_us + b_wn + b_bn + b_lk + b_bar + b_zg;
     if (hipMalloc(&t->arena, total) != hipSuccess) {
         delete t;
         return gl_set_error(ctx, GL_E_NOMEM, "tile engine: hipMalloc(%zu) failed", total);
@@ -1415,12 +1431,15 @@ static int tile_finish(gl_logdeg *s, std::vector<WaveDesc> &wd, std::vector<WgDe
     t->gran_off = (size_t)(at - (char *)t->arena);
     P.part = (tl_u4 *)at, at += b_part;
     P.nval = (tl_u4 *)at, at += b_nval;
+    P.usum = (tl_u4 *)at, at += b_us;
     P.wnorm = (tl_u4 *)at, at += b_wn;
     P.bnrm = (tl_u4 *)at, at += b_bn;
     P.look = (tl_u4 *)at, at += b_lk;
     t->gran_bytes = (size_t)(at - (char *)t->arena) - t->gran_off;
-    P.bar = (unsigned *)at;
-    hipError_t e = hipMemsetAsync(t->arena, 0, total, ctx->stream);
+    P.bar = (unsigned *)at, at += b_bar;
+    t->zg = (double *)at;
+    P.zg = t->zg;
+    hipError_t e = hipMemsetAsync(t->arena, 0, total - b_zg, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync((void *)P.wd, wd.data(), wd.size() * sizeof(WaveDesc), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync((void *)P.gd, gd.data(), gd.size() * sizeof(WgDesc), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // wd / gd are locals
@@ -1429,7 +1448,6 @@ static int tile_finish(gl_logdeg *s, std::vector<WaveDesc> &wd, std::vector<WgDe
         delete t;
         return gl_set_error(ctx, GL_E_HIP, "tile engine set-up: %s", hipGetErrorString(e));
     }
-    P.z = D.z;
     P.dvar = D.dvar;
     P.ybar = D.ybar;
     P.pbar = D.pbar;
@@ -1483,6 +1501,7 @@ static int tile_prepare_rounds(gl_logdeg *s) {
     const LogdegDev &D = s->dev;
     const int ncu = ctx->prop.multiProcessorCount, nb = (int)D.nb;
     if ((int64_t)gl_num_tiles(D.n) * GL_TILE_ELEMS * 8 >= (int64_t)1 << 32) return why(1);  // (32-bit byte offsets in the streamed pass)
+    if (nb > 192) return why(7);  // (an owner's wave reads the block sums of gamma u three per lane)
     // strips: a narrow first one (nb mod 8 columns, at the short end of the lattice), then 8 columns each
     std::vector<int> sc0, sc1;
     for (int c = 0; c < nb;) {
@@ -1641,7 +1660,7 @@ int gl_tile_prepare(gl_logdeg *s) {
             w.fB = B;
             w.fa0 = SLOTS - need[(size_t)B];
             w.fcnt = take;
-            w.ftgt = (w.tile >= 0 && w.I != B) ? 2 : 0;  // my column vectors when B is my column block
+            w.ftgt = (w.tile >= 0 && w.I != B) ? 1 : 0;  // my column vector when B is my column block
             need[(size_t)B] -= take;
         };
         // (passes 0, 1: the older half of every workgroup's waves -- waves 0..3 win the issue arbitration of their SIMD
@@ -1697,18 +1716,31 @@ int gl_tile_prepare(gl_logdeg *s) {
     return tile_finish(s, wd, gd, NWG, U, false);
 }
 
-// Runs up to `iters` iterations in ONE launch (asynchronous).  The iterate stays in w[it0 & 1]; the caller fixes
-// the ping-pong parity afterwards.  norms = false (only with tol = 0): the ratios of the stopping rule are not
-// formed at all (dstat keeps its previous values).
-int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms) {
+bool gl_tile_writes_final_parity(const gl_logdeg *s) { return s->tile != nullptr && !s->tile->big; }
+
+// Runs up to `iters` iterations in ONE launch (asynchronous).  final_parity < 0: the iterate stays in w[it0 & 1] and the
+// caller fixes the ping-pong parity afterwards; 0 / 1 (fixed-iteration calls below the rounds): it is written to that
+// buffer directly.  norms = false (only with tol = 0): the ratios of the stopping rule are not formed at all (dstat
+// keeps its previous values).
+int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int final_parity) {
     gl_ctx *ctx = s->ctx;
     gl_tile *t = s->tile;
     TileDev P = t->dev;
     const LogdegDev &D = s->dev;
+    if (t->zg_version != s->init_version) {  // first launch since gl_logdeg_init: the distances or gamma may be new
+        k_make_zg<<<dim3((unsigned)D.ntiles), dim3(256), 0, ctx->stream>>>(D.z, t->zg, D.n, D.nb, D.g2);
+        GL_HIP(ctx, hipGetLastError());
+        t->zg_version = s->init_version;
+    }
     P.w = D.w[s->it & 1];
+    // where the registers go at the end: a fixed-iteration call knows the parity of its last iterate now and writes it where
+    // everybody expects it; a call that may stop early (and the rounds, which update their streamed tiles in place) keeps
+    // the buffer, and gl_resident_finish copies if the parity came out odd
+    P.wout = (!t->big && tol <= 0 && final_parity >= 0) ? D.w[final_parity] : P.w;
     P.gamma = D.gamma;
     P.c = D.c;
-    P.g2 = D.g2;
+    P.omc = 1.0 - D.c;
+    P.nm2 = (double)(D.n - 2);
     P.a4g = D.a4g;
     P.tol = tol;
     if (tol > 0) norms = true;
@@ -1725,17 +1757,18 @@ int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms) {
         t->arrivals = 0;
     }
     t->arrivals += (unsigned)P.NWG;
-    P.rendezvous = t->arrivals + (getenv("GRAPHLEARN_AMD_RES_TEST_NOT_RESIDENT") ? 1u : 0u);
+    P.check_rendezvous = getenv("GRAPHLEARN_AMD_RES_TEST_NOT_RESIDENT") ? 1 : 0;
+    P.rendezvous = t->arrivals + (P.check_rendezvous ? 1u : 0u);
     const bool ragged = D.n % TB != 0;
     const dim3 grid((unsigned)P.NWG), block(TT);
     auto go = [&](auto kern) { kern<<<grid, block, 0, ctx->stream>>>(P); };
+    // Without the norms the pass itself does not depend on raggedness (the mask is applied at the write-back only), so ONE
+    // instantiation serves every lattice: the RAGGED one (whose factors are 1 everywhere on a lattice that is not).
 #define GL_TILE_GO(UU, BB)                                                                       \
     do {                                                                                         \
-        if (ragged) {                                                                            \
-            if (norms) go(k_tile<UU, true, true, BB>); else go(k_tile<UU, true, false, BB>);     \
-        } else {                                                                                 \
-            if (norms) go(k_tile<UU, false, true, BB>); else go(k_tile<UU, false, false, BB>);   \
-        }                                                                                        \
+        if (!norms) go(k_tile<UU, true, false, BB>);                                             \
+        else if (ragged) go(k_tile<UU, true, true, BB>);                                         \
+        else go(k_tile<UU, false, true, BB>);                                                    \
     } while (0)
     if (t->big && t->nt)
         GL_TILE_GO(32, 2);

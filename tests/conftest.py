@@ -36,15 +36,22 @@ def c3_covariance(x32):
 
 
 def pytest_collection_modifyitems(config, items):
-    """GPU tests are selected with -m gpu; without a device they are skipped, not failed."""
+    """GPU tests are selected with -m gpu; on a machine without a GPU they are skipped, not failed.  On a machine WITH
+    one (a KFD device node exists) a library that is missing or does not load is an error of the whole session, never a
+    skip: GPU tests that quietly do not run would read as green."""
     have = None
     for item in items:
         if "gpu" in item.keywords:
             if have is None:
+                gpu_box = os.path.exists("/dev/kfd")
                 try:
                     from graph_learning_amd import _lib
                     have = _lib.device_count() > 0
-                except Exception:  # library missing or no HIP runtime
+                except Exception as exc:  # library missing, not loadable, or no HIP runtime
+                    if gpu_box:
+                        raise pytest.UsageError(f"a GPU is present but the HIP library cannot be used: {exc!r}")
                     have = False
+                if gpu_box and not have:
+                    raise pytest.UsageError("/dev/kfd exists but the library sees no gfx950 device")
             if not have:
                 item.add_marker(pytest.mark.skip(reason="no MI355X visible"))

@@ -87,3 +87,22 @@ def test_product_never_imports_the_oracle():
     for m in re.finditer(r"^\s*(from|import)\s+oracle\b.*$", bench, flags=re.M):
         before = bench[: m.start()]
         assert before.rfind("def cpu_baseline") > before.rfind("\ndef main"), "oracle import outside cpu_baseline"
+
+
+def test_tile_kernels_keep_their_pass_out_of_scratch():
+    """The tile engine's pass has no register to spare, and a scratch access inside it waits behind the z ring for a memory
+    round trip each (measured: 13 us per pass instead of 4).  Compile gl_tile.hip with the shipped flags and read the
+    compiler's own resource report: the variants without the norms (what bench.py times) use no scratch at all, the
+    variants with them at most a few dwords (loop-invariant values of the rule's early look, outside the pass), and
+    nothing exceeds the 256 registers / 160 KiB of LDS of two waves per SIMD and one workgroup per CU."""
+    r = subprocess.run([os.path.join(ROOT, "tools", "build_tile.sh")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = [l for l in r.stdout.splitlines() if "k_tile" in l]
+    assert len(rows) == 15, r.stdout          # 3 variants x (U = 8, 16, 32 and the two rounds forms)
+    for l in rows:
+        f = l.split()
+        name = f[0]
+        vgpr, scratch, lds = int(f[f.index("vgpr") + 1]), int(f[f.index("scratch") + 1]), int(f[f.index("lds") + 1])
+        norms = re.search(r"k_tileILi\d+ELb[01]ELb([01])ELi", name).group(1) == "1"
+        assert vgpr <= 256 and lds <= 160 * 1024, l
+        assert scratch == 0 if not norms else scratch <= 32, l
