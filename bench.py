@@ -127,6 +127,16 @@ def other_configs(ctx):
                         # bytes >= 3 x 8 m^2 per node update (read C, write it back, read the ADMM matrix once)
                         "byte_floor_frac_of_hbm_peak": 3 * 8 * m * m / (dt / nodes) / 1e9 / HBM_PEAK_GBS,
                         "bound": "latency: 100 dependent ADMM steps per node update (DESIGN.md section 5)", "dtype": "f64"}
+        # the same input with a SPARSE adj_mask (the true support + 1 % extra candidate pairs): every node's QP is gathered
+        # to its active set (general path, lgmrf.py:191-202)
+        extra = np.triu(rng.uniform(size=(n, n)) < 0.01, 1)
+        mask = ((lap != 0) | extra | extra.T | np.eye(n, dtype=bool)).astype(np.float64)
+        time_node_updates(cov, 0, 8, adj_mask=mask, ctx=ctx)
+        dtm = time_node_updates(cov, lo, hi - lo, adj_mask=mask, ctx=ctx)
+        out["lgmrf_masked"] = {"workload": "LGMRF n=2048 d=512, sparse adj_mask (true support + 1 % extra pairs), general path, "
+                                           "QPs gathered to their active sets", "node_updates_timed": nodes,
+                               "candidates_per_node_mean": float(mask.sum(0).mean() - 1), "ms_per_node_update": dtm * 1e3 / nodes,
+                               "ms_per_cycle_projected": dtm * 1e3 / nodes * n, "dtype": "f64"}
     except Exception as exc:
         out["lgmrf_error"] = repr(exc)
     try:  # a lattice four times the headline's: what does not fit the register files streams (rounds)

@@ -26,6 +26,7 @@
 //     O(n^2) elementwise kernel instead of an O(n^3) factorisation.
 // Both produce the reference's iterates up to rounding; the stopping rules are the
 // reference's.
+#include <map>
 #include <vector>
 
 #include "gl_common.h"
@@ -161,19 +162,6 @@ __global__ __launch_bounds__(VT) void k_lg_qp_setup(LgDev D, int64_t u) {
         D.scal[0] = 0.0;
         D.scal[1] = 0.0;
     }
-}
-
-// general path: W = I + rho * M on the active set (identity elsewhere), M = C - c c'/c_uu
-__global__ void k_lg_build_w(LgDev D, int64_t u) {
-    const int64_t i = blockIdx.y;
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= D.n) return;
-    double w = (i == j) ? 1.0 : 0.0;
-    if (D.act[i] != 0.0 && D.act[j] != 0.0) {
-        const double m = D.C[i * D.n + j] - (D.C[i * D.n + u] * D.C[j * D.n + u]) / D.C[u * D.n + u];
-        w += D.rho * m;
-    }
-    D.W[i * D.n + j] = w;
 }
 
 // In-place Gauss-Jordan step k (no pivoting: the matrix is SPD).  After n steps A holds A^-1.
@@ -1457,7 +1445,7 @@ struct AdmmRes {
 // 500: 0.90 / 0.81 / 0.46,  1024: 0.96 / 0.89 / 0.56,  2048: 1.62 / 1.20 / 0.80;  single workgroup
 // against tagged at n = 32: 0.26 / 0.20, n = 64: 0.48 / 0.30.  To n = 64 the default is the single-wave form.
 
-int admm_res_plan(gl_ctx *ctx, int64_t n, AdmmRes &A) {
+int admm_res_plan(gl_ctx *ctx, int64_t n, AdmmRes &A, bool set_lds_limit = true) {
     A.on = A.one = A.wave = A.quad = A.tagged = false;
     const char *force = getenv("GRAPHLEARN_AMD_LGMRF_ADMM");
     auto is = [&](const char *v) { return force && !strcmp(force, v); };
@@ -1472,7 +1460,7 @@ int admm_res_plan(gl_ctx *ctx, int64_t n, AdmmRes &A) {
     }
     if (n <= ADMM_ONE_MAXN && is("one")) {
         A.lds = ((size_t)n * n + 2 * n + 6 * 16) * 8;
-        GL_HIP(ctx, hipFuncSetAttribute((const void *)k_lg_admm_one, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A.lds));
+        if (set_lds_limit) GL_HIP(ctx, hipFuncSetAttribute((const void *)k_lg_admm_one, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A.lds));
         A.one = true;
         return GL_OK;
     }
@@ -1499,10 +1487,11 @@ int admm_res_plan(gl_ctx *ctx, int64_t n, AdmmRes &A) {
     A.R = R;
     A.nwg = (int)((n + R - 1) / R);
     A.lds = lds;
-    GL_HIP(ctx, hipFuncSetAttribute(A.wide     ? (const void *)k_lg_admm_tag<512, 8>
-                                    : A.tagged ? (const void *)k_lg_admm_tag<256, 0>
-                                               : (const void *)k_lg_admm_res,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (set_lds_limit)
+        GL_HIP(ctx, hipFuncSetAttribute(A.wide     ? (const void *)k_lg_admm_tag<512, 8>
+                                        : A.tagged ? (const void *)k_lg_admm_tag<256, 0>
+                                                   : (const void *)k_lg_admm_res,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     A.on = true;
     return GL_OK;
 }
@@ -1732,6 +1721,46 @@ double np_pairwise_sum(const double *a, int64_t n) {
     int64_t n2 = n / 2;
     n2 -= n2 % 8;
     return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+// ---- general path, compact form.  The QP of node u only involves the entries its column of adj_mask allows
+// (lgmrf.py:191-202: M[nz][:, nz], k_u[nz]); the reference gathers exactly that submatrix.  So does this path: the host
+// knows every node's active list (the mask never changes), the device gathers W = I + rho M[nz, nz] (na x na, M = C -
+// c c'/c_uu formed on the fly), inverts THAT (one launch up to na = 128) and runs the ADMM on vectors of length na, with
+// whatever form of the loop fits na.  A sparse mask makes every QP tiny whatever n is; a full mask costs what the
+// n x n formulation cost (which inverted an identity block for the inactive entries).  Active entries keep their
+// ascending order, so eliminations and sums run in the reference's order.
+__global__ void k_lg_compact_w(LgDev D, LgDev Dc, int64_t u, const int *__restrict__ idx) {
+    const int64_t a = blockIdx.y;
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = D.n, na = Dc.n;
+    if (b >= na) return;
+    const int64_t i = idx[a], j = idx[b];
+    const double m = D.C[i * n + j] - (D.C[i * n + u] * D.C[j * n + u]) / D.C[u * n + u];
+    Dc.W[a * na + b] = ((a == b) ? 1.0 : 0.0) + D.rho * m;
+}
+// p = k_u[nz] / k_uu, ADMM start (x = z = u = 0, v = rho p)   (lgmrf.py:197-201, :55); na may be 0
+__global__ __launch_bounds__(VT) void k_lg_compact_vecs(LgDev D, LgDev Dc, int64_t u, const int *__restrict__ idx) {
+    const double kuu = D.K[u * D.n + u];
+    for (int64_t a = threadIdx.x; a < Dc.n; a += VT) {
+        const double pa = D.K[(int64_t)idx[a] * D.n + u] / kuu;
+        Dc.act[a] = 1.0;
+        Dc.p[a] = pa;
+        Dc.x[a] = 0.0;
+        Dc.z[a] = 0.0;
+        Dc.uu[a] = 0.0;
+        Dc.v[a] = (0.0 - 0.0) + D.rho * pa;
+    }
+    if (threadIdx.x == 0) {
+        D.scal[0] = 0.0;
+        D.scal[1] = 0.0;
+    }
+}
+// beta = -z on the active entries, 0 elsewhere (lgmrf.py:197-209)
+__global__ __launch_bounds__(VT) void k_lg_scatter_beta(LgDev D, LgDev Dc, const int *__restrict__ idx) {
+    for (int64_t i = threadIdx.x; i < D.n; i += VT) D.beta[i] = 0.0;
+    __syncthreads();
+    for (int64_t a = threadIdx.x; a < Dc.n; a += VT) D.beta[idx[a]] = -Dc.z[a];
 }
 
 struct Buf {
@@ -1998,7 +2027,7 @@ static int lgmrf_fit_impl(gl_ctx *ctx, const double *x, int64_t n, double norm_p
     GL_TRY(admm_res_plan(ctx, n, ares));
     ares.bar = (unsigned *)bBar.p;
     ares.gran = (lg_u4 *)bGran.p;
-    if (ares.on) GL_HIP(ctx, hipMalloc(&bCprev.p, (size_t)n * n * 8));
+    if (ares.on || !fast) GL_HIP(ctx, hipMalloc(&bCprev.p, (size_t)n * n * 8));
     GL_HIP(ctx, hipMemsetAsync(bVec.p, 0, (size_t)16 * n * 8, ctx->stream));
     GL_HIP(ctx, hipMemsetAsync(bScal.p, 0, 16 * 8, ctx->stream));
 
@@ -2038,6 +2067,39 @@ static int lgmrf_fit_impl(gl_ctx *ctx, const double *x, int64_t n, double norm_p
                                               regularization_type == 1 ? 2.0 : 1.0);
     GL_HIP(ctx, hipGetLastError());
 
+    // general path: every node's active list nz(u) = {i != u : adj_mask[i, u] == 1} in ascending order (lgmrf.py:191-193),
+    // known on the host once and for all; the device works on the gathered na x na problem (k_lg_compact_*)
+    std::vector<int64_t> nz_ptr;
+    Buf bIdx, bCvec;
+    LgDev Dc = D;
+    std::map<int64_t, AdmmRes> plans;  // the form of the ADMM loop by problem size na
+    unsigned shared_tag = 0;           // the tagged forms share one record buffer: one tag sequence over all of them
+    bool persistent_ok = true;         // false once a persistent form has found its workgroups not co-resident
+    if (!fast) {
+        std::vector<int> nz_idx;
+        nz_ptr.assign((size_t)n + 1, 0);
+        nz_idx.reserve((size_t)n * 8);
+        for (int64_t u = 0; u < n; ++u) {
+            for (int64_t i = 0; i < n; ++i)
+                if (i != u && (!adj_mask || full_mask || adj_mask[i * n + u] == 1.0)) nz_idx.push_back((int)i);
+            nz_ptr[(size_t)u + 1] = (int64_t)nz_idx.size();
+        }
+        GL_HIP(ctx, hipMalloc(&bIdx.p, std::max<size_t>(nz_idx.size(), 1) * sizeof(int)));
+        GL_HIP(ctx, hipMalloc(&bCvec.p, (size_t)10 * n * 8));
+        GL_HIP(ctx, hipMemcpyAsync(bIdx.p, nz_idx.data(), nz_idx.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        GL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // nz_idx is a local
+        double *Vc = (double *)bCvec.p;
+        Dc.p = Vc, Dc.x = Vc + n, Dc.z = Vc + 2 * n, Dc.uu = Vc + 3 * n, Dc.v = Vc + 4 * n, Dc.y = Vc + 5 * n, Dc.act = Vc + 6 * n;
+        Dc.gcol = Vc + 7 * n;
+        Dc.G = nullptr;
+        Dc.mask = nullptr;
+        // problems of many sizes share the persistent kernels: their dynamic-LDS limits cover the largest plan there is
+        const int lim = 150 * 1024, lim1 = (int)(((size_t)ADMM_ONE_MAXN * ADMM_ONE_MAXN + 2 * ADMM_ONE_MAXN + 6 * 16) * 8);
+        GL_HIP(ctx, hipFuncSetAttribute((const void *)k_lg_admm_tag<512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        GL_HIP(ctx, hipFuncSetAttribute((const void *)k_lg_admm_tag<256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        GL_HIP(ctx, hipFuncSetAttribute((const void *)k_lg_admm_res, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        GL_HIP(ctx, hipFuncSetAttribute((const void *)k_lg_admm_one, hipFuncAttributeMaxDynamicSharedMemorySize, lim1));
+    }
     const unsigned mvb = (unsigned)((n + 3) / 4);
     const int max_qp_iter = 100;  // default of nonnegative_qp_solver (lgmrf.py:24)
     int converged = -1, cycles = 0;
@@ -2083,7 +2145,7 @@ static int lgmrf_fit_impl(gl_ctx *ctx, const double *x, int64_t n, double norm_p
     }
     for (int cycle = 0; cycle < max_cycle; ++cycle) {
         GL_HIP(ctx, hipMemcpyAsync(D.ThPrev, D.Th, nn, hipMemcpyDeviceToDevice, ctx->stream));  // l_pre (:173)
-        if (ares.on) GL_HIP(ctx, hipMemcpyAsync(bCprev.p, D.C, nn, hipMemcpyDeviceToDevice, ctx->stream));  // to redo the cycle
+        if (bCprev.p) GL_HIP(ctx, hipMemcpyAsync(bCprev.p, D.C, nn, hipMemcpyDeviceToDevice, ctx->stream));  // to redo the cycle
         if (fast) {  // fresh G = (Theta + rho I)^-1 once per cycle; rank-2 corrections in between
             k_lg_shift<<<g2, 256, 0, ctx->stream>>>(D.Th, D.G, n, D.rho);
             GL_TRY(invert_spd_inplace(ctx, D.G, n, pivrow));
@@ -2091,21 +2153,45 @@ static int lgmrf_fit_impl(gl_ctx *ctx, const double *x, int64_t n, double norm_p
         const int64_t u_end = probe ? probe_to : n;
         for (int64_t u = 0; u < u_end; ++u) {
             if (probe && u == probe_from) GL_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-            k_lg_qp_setup<<<1, VT, 0, ctx->stream>>>(D, u);
-            const bool fused_winv = fast && (ares.wave || ares.quad || (ares.on && ares.tagged));  // the ADMM kernel forms its rows of the inverse itself
-            if (fused_winv) {
-            } else if (fast) {
-                k_lg_build_winv<<<g2, 256, 0, ctx->stream>>>(D, u);
+            bool fused_winv = false;
+            if (!fast) {  // the gathered na x na problem of this node
+                const int64_t na = nz_ptr[(size_t)u + 1] - nz_ptr[(size_t)u];
+                const int *idx = (const int *)bIdx.p + nz_ptr[(size_t)u];
+                Dc.n = na;
+                k_lg_compact_vecs<<<1, VT, 0, ctx->stream>>>(D, Dc, u, idx);
+                if (na > 0) {
+                    k_lg_compact_w<<<dim3((unsigned)((na + 255) / 256), (unsigned)na), 256, 0, ctx->stream>>>(D, Dc, u, idx);
+                    GL_TRY(invert_spd_inplace(ctx, Dc.W, na, pivrow));
+                    auto it = plans.find(na);
+                    if (it == plans.end()) {
+                        AdmmRes pl;
+                        GL_TRY(admm_res_plan(ctx, na, pl, false));  // (the LDS limits were raised once, below the lists)
+                        pl.bar = ares.bar;
+                        pl.gran = ares.gran;
+                        it = plans.emplace(na, pl).first;
+                    }
+                    AdmmRes &pl = it->second;
+                    if (pl.wave) GL_TRY(run_admm_wave(ctx, Dc, max_qp_iter));
+                    else if (pl.quad) GL_TRY(run_admm_quad(ctx, Dc, max_qp_iter));
+                    else if (pl.one) GL_TRY(run_admm_one(ctx, Dc, pl, max_qp_iter));
+                    else if (pl.on && persistent_ok) {
+                        pl.next_tag = shared_tag;
+                        GL_TRY(run_admm_res(ctx, Dc, pl, max_qp_iter));
+                        shared_tag = pl.next_tag;
+                    } else GL_TRY(run_admm(ctx, Dc, max_qp_iter));
+                }
+                k_lg_scatter_beta<<<1, VT, 0, ctx->stream>>>(D, Dc, idx);
             } else {
-                k_lg_build_w<<<g2, 256, 0, ctx->stream>>>(D, u);
-                GL_TRY(invert_spd_inplace(ctx, D.W, n, pivrow));
+                k_lg_qp_setup<<<1, VT, 0, ctx->stream>>>(D, u);
+                fused_winv = ares.wave || ares.quad || (ares.on && ares.tagged);  // the ADMM kernel forms its rows of the inverse itself
+                if (!fused_winv) k_lg_build_winv<<<g2, 256, 0, ctx->stream>>>(D, u);
+                GL_TRY(ares.wave ? run_admm_wave(ctx, D, max_qp_iter, fused_winv ? u : -1)
+                       : ares.quad ? run_admm_quad(ctx, D, max_qp_iter, fused_winv ? u : -1)
+                                 : (ares.one ? run_admm_one(ctx, D, ares, max_qp_iter)
+                                             : (ares.on ? run_admm_res(ctx, D, ares, max_qp_iter, fused_winv ? u : -1)
+                                                        : run_admm(ctx, D, max_qp_iter))));
+                if (!fused_winv) k_lg_beta<<<1, VT, 0, ctx->stream>>>(D, u);  // else written by the ADMM kernel, with the snapshot
             }
-            GL_TRY(ares.wave ? run_admm_wave(ctx, D, max_qp_iter, fused_winv ? u : -1)
-                   : ares.quad ? run_admm_quad(ctx, D, max_qp_iter, fused_winv ? u : -1)
-                             : (ares.one ? run_admm_one(ctx, D, ares, max_qp_iter)
-                                         : (ares.on ? run_admm_res(ctx, D, ares, max_qp_iter, fused_winv ? u : -1)
-                                                    : run_admm(ctx, D, max_qp_iter))));
-            if (!fused_winv) k_lg_beta<<<1, VT, 0, ctx->stream>>>(D, u);  // else written by the ADMM kernel, with the snapshot
             k_matvec<<<mvb, 256, 0, ctx->stream>>>(D.C, D.beta, D.t, n, D.scal, 0);
             if (!fused_winv) k_lg_snap_col<<<1, VT, 0, ctx->stream>>>(D, u);
             k_lg_node_update<<<1, VT, 0, ctx->stream>>>(D, u);
@@ -2125,7 +2211,7 @@ static int lgmrf_fit_impl(gl_ctx *ctx, const double *x, int64_t n, double norm_p
             GL_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
             *probe_seconds = (double)ms * 1e-3;
         }
-        if (ares.on) {  // error word of the persistent ADMM launches of this cycle
+        if (ares.on || (!fast && persistent_ok)) {  // error word of the persistent ADMM launches of this cycle
             double flag = 0;
             GL_HIP(ctx, hipMemcpyAsync(&flag, D.scal + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
             GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -2135,6 +2221,7 @@ static int lgmrf_fit_impl(gl_ctx *ctx, const double *x, int64_t n, double norm_p
                 GL_HIP(ctx, hipMemcpyAsync(D.C, bCprev.p, nn, hipMemcpyDeviceToDevice, ctx->stream));
                 GL_HIP(ctx, hipMemsetAsync(D.scal, 0, 16 * 8, ctx->stream));
                 ares.on = false;
+                persistent_ok = false;
                 --cycle;
                 continue;
             }

@@ -1803,15 +1803,15 @@ void gl_tile_dump_stamps(gl_logdeg *s) {
             if (!o[0] || !o[5]) continue;
             ++cnt;
             for (int q = 0; q < 6; ++q) {
+                if (!o[q]) continue;  // (stamps 1, 2 are not taken: a store between the bulk loads and the first pass would cost it its counted waits)
                 const double d = (double)(o[q] - t0) / 100.0;
                 mean[q] += d, last[q] = std::max(last[q], d);
             }
         }
         if (cnt)
-            fprintf(stderr, "[tile call stamps] us after the first wave's entry, mean / latest wave: entry %.1f / %.1f  loads done %.1f / %.1f  "
-                            "rendezvous %.1f / %.1f  first iteration done %.1f / %.1f  loop done %.1f / %.1f  stored %.1f / %.1f\n",
-                    mean[0] / cnt, last[0], mean[1] / cnt, last[1], mean[2] / cnt, last[2], mean[3] / cnt, last[3], mean[4] / cnt, last[4],
-                    mean[5] / cnt, last[5]);
+            fprintf(stderr, "[tile call stamps] us after the first wave's entry, mean / latest wave: entry %.1f / %.1f  first iteration done %.1f / %.1f  "
+                            "loop done %.1f / %.1f  stored %.1f / %.1f\n",
+                    mean[0] / cnt, last[0], mean[3] / cnt, last[3], mean[4] / cnt, last[4], mean[5] / cnt, last[5]);
     }
     {  // per-wave pass durations: mean, and mean over workgroups of (slowest - fastest wave of the workgroup)
         const unsigned long long *pw = h.data() + (size_t)NWG * 16 * 6;

@@ -409,9 +409,34 @@ def gen_lgmrf_c3():
     save("lgmrf_c3", **arrays)
 
 
+def gen_lgmrf_mask():
+    """LGMRF with a SPARSE adj_mask (lgmrf.py:191-202: every node's QP runs on M[nz][:, nz] only): the support of the true
+    graph plus 6 % random extra candidate pairs, n = 64 and n = 96, well-conditioned input (precision L + I, 40 n samples),
+    default parameters, run to convergence."""
+    arrays = {}
+    for n in (64, 96):
+        rng = default_rng(11)
+        lap = sample_er_laplacian(n, 6.0 / n, 0.3, 2.0, seed=rng)
+        x = rng.multivariate_normal(np.zeros(n), np.linalg.inv(lap + np.eye(n)), size=40 * n)
+        cov = x.T @ x / x.shape[0]
+        extra = np.triu(rng.uniform(size=(n, n)) < 0.06, 1)
+        mask = ((lap != 0) | extra | extra.T | np.eye(n, dtype=bool)).astype(float)
+        m = ref_lgmrf.LGMRF(adj_mask=mask.copy()).fit(cov.copy())
+        arrays[f"cov_{n}"], arrays[f"mask_{n}"] = cov, mask
+        arrays[f"lapl_{n}"], arrays[f"inv_{n}"] = m.laplacian_, m.inv_laplacian_
+        arrays[f"conv_{n}"] = np.int64(m.converged_)
+        deg = (mask.sum(0) - 1)
+        print(f"n={n}: candidates per node {deg.min():.0f}..{deg.max():.0f}, converged_ = {m.converged_}, "
+              f"edges learned {(np.abs(np.triu(m.laplacian_, 1)) > 1e-8).sum()}", flush=True)
+    save("lgmrf_mask", **arrays)
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["lgmrf_c3"]:      # the two-minute one on its own
         gen_lgmrf_c3()
+        sys.exit(0)
+    if sys.argv[1:] == ["lgmrf_mask"]:
+        gen_lgmrf_mask()
         sys.exit(0)
     gen_sum_squareform()
     gen_theta()
@@ -421,4 +446,5 @@ if __name__ == "__main__":
     gen_operators()
     gen_graphdict()
     gen_clustering()
+    gen_lgmrf_mask()
     gen_lgmrf_c3()

@@ -90,6 +90,52 @@ def test_lgmrf_mask_and_cycle_cap(golden):
     assert close(m.laplacian_, g["lapl_16_cyc3"])
 
 
+@pytest.mark.parametrize("n,fused", [(64, "1"), (64, "0"), (96, "1")])
+def test_lgmrf_sparse_mask_against_reference_golden(golden, admm_form, monkeypatch, n, fused):
+    """A SPARSE adj_mask (the true support plus 6 % extra candidates: 4..19 per node) run to convergence, against what the
+    reference produced (tests/golden/make_golden.py::gen_lgmrf_mask; lgmrf.py:191-202).  n = 64 through the single-launch
+    fit and, with it switched off, through the launch path; n = 96 through the launch path: there every node's QP is
+    gathered to its na x na active set (k_lg_compact_*), inverted in one launch and solved by the form that fits na."""
+    if fused == "0" or n > 64:
+        if admm_form not in ("auto", "launch", "wave"):
+            pytest.skip("the gathered problems have 4..19 unknowns: the single-wave form serves them, or one launch per step")
+    elif admm_form != "auto":
+        pytest.skip("the single-launch fit has one form")
+    monkeypatch.setenv("GRAPHLEARN_AMD_LGMRF_FUSED", fused)
+    g = golden("lgmrf_mask")
+    mask = g[f"mask_{n}"]
+    m = LGMRF(adj_mask=mask.copy()).fit(g[f"cov_{n}"].copy())
+    assert m.converged_ == int(g[f"conv_{n}"]) == 5
+    err = np.abs(m.laplacian_ - g[f"lapl_{n}"]).max() / np.abs(g[f"lapl_{n}"]).max()
+    print(f"[lgmrf sparse mask n={n} fused={fused} form={admm_form}] max|Theta - ref| / max|ref| = {err:.1e}")
+    assert close(m.laplacian_, g[f"lapl_{n}"]) and close(m.inv_laplacian_, g[f"inv_{n}"])
+    assert (m.laplacian_[mask == 0] == 0).all()                    # masked-out pairs stay disconnected
+    assert np.array_equal(m.laplacian_, m.laplacian_.T)
+
+
+def test_lgmrf_sparse_mask_n256_against_oracle(admm_form):
+    """n = 256 with a sparse mask (true support + 3 % extra pairs), three cycles against the oracle: the launch path with
+    gathered QPs (4..25 unknowns each), and a node whose column of the mask is empty (its QP has no unknown at all)."""
+    if admm_form not in ("auto", "launch"):
+        pytest.skip("the gathered problems are served by the single-wave form (auto) or by one launch per step")
+    n = 256
+    rng = np.random.default_rng(21)
+    lap = er_laplacian(n, 6.0 / n, 0.3, 2.0, seed=rng)
+    x = rng.multivariate_normal(np.zeros(n), np.linalg.inv(lap + np.eye(n)), size=20 * n)
+    cov = x.T @ x / x.shape[0]
+    extra = np.triu(rng.uniform(size=(n, n)) < 0.03, 1)
+    mask = ((lap != 0) | extra | extra.T | np.eye(n, dtype=bool)).astype(float)
+    mask[7, :] = mask[:, 7] = 0.0                                   # node 7: no candidate neighbour
+    mask[7, 7] = 1.0
+    o = olg.LGMRFOracle(adj_mask=mask.copy(), max_cycle=3).fit(cov.copy())
+    m = LGMRF(adj_mask=mask.copy(), max_cycle=3).fit(cov.copy())
+    assert m.converged_ == o.converged_ == -1 and m.n_cycles_ == 3
+    err = np.abs(m.laplacian_ - o.laplacian_).max() / np.abs(o.laplacian_).max()
+    print(f"[lgmrf sparse mask n=256 form={admm_form}] max|Theta - oracle| / max = {err:.1e}")
+    assert close(m.laplacian_, o.laplacian_, 1e-9) and close(m.inv_laplacian_, o.inv_laplacian_, 1e-9)
+    assert (m.laplacian_[mask == 0] == 0).all() and (np.delete(m.laplacian_[7], 7) == 0).all()
+
+
 def test_lgmrf_errors():
     x = np.eye(4) + 1.0
     with pytest.raises(ValueError):

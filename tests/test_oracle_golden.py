@@ -157,6 +157,16 @@ def test_lgmrf_mask_and_cycle_cap(golden):
     assert np.array_equal(m.laplacian_, g["lapl_16_cyc3"])
 
 
+@pytest.mark.parametrize("n", [64, 96])
+def test_lgmrf_sparse_mask_equals_reference(golden, n):
+    """Sparse adj_mask (4..19 candidate neighbours per node): every node's QP runs on M[nz][:, nz] (lgmrf.py:191-202)."""
+    g = golden("lgmrf_mask")
+    m = olg.LGMRFOracle(adj_mask=g[f"mask_{n}"].copy()).fit(g[f"cov_{n}"].copy())
+    assert m.converged_ == int(g[f"conv_{n}"]) == 5
+    # (this fixture was made with ONE BLAS thread; numpy.linalg.inv of the tiny per-node systems does not thread: equal)
+    assert np.array_equal(m.laplacian_, g[f"lapl_{n}"]) and np.array_equal(m.inv_laplacian_, g[f"inv_{n}"])
+
+
 def test_lgmrf_errors():
     x = np.eye(4) + 1.0
     with pytest.raises(ValueError):

@@ -1,7 +1,7 @@
 """Dev tool: where a kernel touches scratch (per basic block), from the -save-temps assembly.
 usage: python tools/scratch_sites.py <mangled-name-substring> [asm file]"""
 import re, sys
-asm = sys.argv[2] if len(sys.argv) > 2 else "graph_learning_amd/csrc/build/gl_tile-hip-amdgcn-amd-amdhsa-gfx950.s"
+asm = sys.argv[2] if len(sys.argv) > 2 else "graph_learning_amd/csrc/build/report/gl_tile-hip-amdgcn-amd-amdhsa-gfx950.s"
 s = open(asm).read()
 m = re.search(r"^(\S*%s\S*):" % re.escape(sys.argv[1]), s, flags=re.M)
 i = m.start(); j = s.index(".Lfunc_end", i)

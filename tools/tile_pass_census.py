@@ -18,7 +18,7 @@ ap.add_argument("--no-build", action="store_true")
 a = ap.parse_args()
 if not a.no_build:
     subprocess.run([os.path.join(ROOT, "tools", "build_tile.sh")], check=True, stdout=subprocess.DEVNULL)
-asm = os.path.join(ROOT, "graph_learning_amd", "csrc", "build", "gl_tile-hip-amdgcn-amd-amdhsa-gfx950.s")
+asm = os.path.join(ROOT, "graph_learning_amd", "csrc", "build", "report", "gl_tile-hip-amdgcn-amd-amdhsa-gfx950.s")
 s = open(asm).read()
 m = re.search(r"^(\S*k_tile%s\S*):" % re.escape(a.kernel), s, flags=re.M)
 body = s[m.start():s.index(".Lfunc_end", m.start())].split("\n")
