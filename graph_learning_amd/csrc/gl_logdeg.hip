@@ -17,6 +17,7 @@
 // wave-wide 16-B load); a persistent grid of G = 8 x #CU single-wave workgroups
 // takes equal contiguous ranges of it, so every CU streams the same number of
 // bytes and the launch has no tail.
+#include "gl_bracket.h"
 #include "gl_lanes.h"
 #include "gl_logdeg.h"
 
@@ -473,11 +474,12 @@ __device__ __forceinline__ void node_body(const LogdegDev &P, const int64_t B) {
                     r0 += s_red[0][v];
                     r1 += s_red[1][v];
                 }
+                // (write-through: the batched node pass hands these to the launch's last workgroup inside the launch)
                 double *bn = P.bnorm + (it & 1) * 4 * P.nb + 4 * B;
-                bn[0] = r0;
-                bn[1] = r1;
-                bn[2] = dq2;
-                bn[3] = d2;
+                __hip_atomic_store(bn + 0, r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(bn + 1, r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(bn + 2, dq2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(bn + 3, d2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (B == 0) P.ctr[2] = it + 1;  // the next edge pass runs iteration it + 1
             }
         }
@@ -488,9 +490,96 @@ template <bool INIT>
 __global__ __launch_bounds__(NODE_WAVES * 64) void k_node(LogdegDev P) {
     node_body<INIT>(P, (int64_t)blockIdx.x);
 }
-__global__ __launch_bounds__(NODE_WAVES * 64) void k_node_batch(const LogdegDev *__restrict__ devs) {
+// State of a batched (2-D) call on the device: the coupled rule's screen runs there, so that the host looks once per
+// chunk of iterations instead of once per iteration.
+struct BatchState {
+    int halt;             // 0 running; 1: the screen cannot rule out that the coupled rule holds (host: exact spectral norms);
+                          // 2: the call's iteration budget is used up
+    int ran;              // iterations completed in this call
+    int first;            // 1 until the call's first iteration is done (the rule is not evaluated for it, :156)
+    int remaining;        // iterations this call may still run
+    unsigned done_blocks; // workgroups of the current node pass that have finished ("last block" pattern)
+    int decide_here;      // 1: an iterate the screen cannot rule out is judged on the device (k_batch_dots .. k_batch_brackets
+                          // behind the node pass) instead of halting for the host
+    int want_brackets;    // ... set by the screen for the kernels behind it, cleared by the last of them
+    int pad[1];
+    double diag[4];       // scratch of the deciding workgroup: max and trace of the four diagonals are formed from LDS
+};
+// The node pass of a batch (blockIdx.y = problem).  With `st`: the LAST workgroup of the launch to finish -- whichever it
+// is: what it computes does not depend on that -- sums every problem's norm partials of the iteration just completed (the
+// four squared norms ||dW_a||^2, ||W_a||^2, ||dD_a||^2, ||D_a||^2 = the diagonals of the four B x B Gram matrices) and
+// screens the coupled rule of smooth_learning.py:158-159,166-167: lambda_max of a Gram matrix lies in [max diagonal,
+// trace], so rel_p^2 >= max_a ||dW_a||^2 / sum_a ||W_a||^2 (and likewise rel_d): above tol^2 the rule cannot hold and the
+// batch goes on; otherwise every problem's done flag is raised, the launches queued behind this one fall through, and the
+// host forms the exact spectral norms for exactly this iterate.
+__global__ __launch_bounds__(NODE_WAVES * 64) void k_node_batch(const LogdegDev *__restrict__ devs, BatchState *st, int nprob, double t2) {
+    __shared__ int s_last;
+    __shared__ double s_mx[4][NODE_WAVES], s_tr[4][NODE_WAVES];
     const LogdegDev P = devs[blockIdx.y];
+    if (st && P.ctr[0] != 0) return;  // halted: nothing moves (every problem carries the same flag)
     node_body<false>(P, (int64_t)blockIdx.x);
+    if (!st) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Hand-off of the norm partials inside the launch (CDNA4 guide, Guideline 16: sc1 stores, the storing lane drains, ONE
+    // agent-scope add per workgroup, the workgroup whose add came last reads with sc1 loads behind a workgroup barrier).
+    // Thread 0 is the lane that stored this workgroup's partials (node_body).
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned arrived = __hip_atomic_fetch_add(&st->done_blocks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        s_last = arrived == gridDim.x * gridDim.y ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const long long it = devs[0].ctr[3];  // the iteration this pass completed (handed over by the edge pass)
+    double mx[4] = {0, 0, 0, 0}, tr[4] = {0, 0, 0, 0};
+    for (int a = wave; a < nprob; a += NODE_WAVES) {
+        const LogdegDev Q = devs[a];
+        const double *bn = Q.bnorm + (it & 1) * 4 * Q.nb;
+        double b[4] = {0, 0, 0, 0};
+        for (int64_t bb = lane; bb < Q.nb; bb += 64)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b[q] += __hip_atomic_load(bn + 4 * bb + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double v = wave_sum(b[q]);
+            mx[q] = fmax(mx[q], v);
+            tr[q] += v;
+        }
+    }
+    if (lane == 0)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s_mx[q][wave] = mx[q], s_tr[q][wave] = tr[q];
+    __syncthreads();
+    if (tid == 0) {
+        double m[4], t[4];
+        for (int q = 0; q < 4; ++q) {
+            m[q] = s_mx[q][0], t[q] = s_tr[q][0];
+            for (int v = 1; v < NODE_WAVES; ++v) m[q] = fmax(m[q], s_mx[q][v]), t[q] += s_tr[q][v];
+        }
+        const bool degenerate = !(m[1] > 0) || !(m[3] > 0);
+        // rel_p^2 in [m0 / t1, t0 / m1], rel_d^2 in [m2 / t3, t2 / m3]; a margin for rounding
+        const bool surely_not = !degenerate && (m[0] / t[1] > t2 * (1 + 1e-9) || m[2] / t[3] > t2 * (1 + 1e-9));
+        int halt = 0;
+        if (!st->first && !surely_not) {
+            if (st->decide_here) st->want_brackets = 1;
+            else halt = 1;
+        }
+        st->first = 0;
+        st->ran += 1;
+        if (--st->remaining <= 0 && !halt) halt = 2;  // (with a bracket decision pending too: the host looks at this iterate itself)
+        if (halt) st->want_brackets = 0;
+        st->done_blocks = 0u;
+        if (halt) {
+            for (int a = 0; a < nprob; ++a) devs[a].ctr[0] = 1;
+            st->halt = halt;
+        }
+    }
+}
+// after the host has looked: the problems' done flags belong to the batch's screen, not to them
+__global__ void k_batch_rearm(const LogdegDev *__restrict__ devs, int nprob, BatchState *st) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < nprob) devs[a].ctr[0] = 0, devs[a].ctr[1] = 0;
+    if (a == 0) st->halt = 0;
 }
 
 // After a batch of launches: rel. changes of the last completed iteration, and
@@ -672,9 +761,14 @@ __global__ __launch_bounds__(256) void k_pair_dots(const double *__restrict__ wa
 struct BatchPtrs {
     const double *w_new, *w_old, *d_new, *d_old;
 };
+// want != nullptr (inside a chunk of batched iterations): only when the screen of the node pass asked for the brackets, and
+// the operands' parity comes from the device (it_done[0] = iterations completed), ptrs holding both parities ([2][nprob]).
 __global__ __launch_bounds__(256) void k_batch_dots(const BatchPtrs *__restrict__ ptrs, const int2 *__restrict__ pairs,
-                                                    int64_t n_tiled, int64_t n_nodes, double *__restrict__ part) {
+                                                    int64_t n_tiled, int64_t n_nodes, double *__restrict__ part,
+                                                    const int *want = nullptr, const long long *it_done = nullptr, int nprob = 0) {
     __shared__ double sh[4][4];
+    if (want && want[0] == 0) return;
+    if (it_done) ptrs += (size_t)(it_done[0] & 1) * nprob;
     const int2 pr = pairs[blockIdx.x];  // pairs on grid x (up to B (B + 1) / 2 of them), blocks on y
     const BatchPtrs A = ptrs[pr.x], Bq = ptrs[pr.y];
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
@@ -705,13 +799,55 @@ __global__ __launch_bounds__(256) void k_batch_dots(const BatchPtrs *__restrict_
             ((sh[threadIdx.x][0] + sh[threadIdx.x][1]) + sh[threadIdx.x][2]) + sh[threadIdx.x][3];
 }
 // out[pair][q] = sum over the blocks of part[pair][block][q], fixed order
-__global__ void k_batch_dots_reduce(const double *__restrict__ part, int npairs, int blocks, double *__restrict__ out) {
+__global__ void k_batch_dots_reduce(const double *__restrict__ part, int npairs, int blocks, double *__restrict__ out,
+                                    const int *want = nullptr) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (want && want[0] == 0) return;
     if (t >= npairs * 4) return;
     const int pr = t >> 2, q = t & 3;
     double acc = 0;
     for (int k = 0; k < blocks; ++k) acc += part[((size_t)pr * blocks + k) * 4 + q];
     out[t] = acc;
+}
+
+// The coupled rule judged on the device (inside a chunk of batched iterations, behind k_batch_dots and its reduce): the
+// four B x B Gram matrices go to LDS, wave q brackets lambda_max of matrix q by repeated squaring (gl_bracket.h; rigorous,
+// to ~1e-9 relative), and the rule of smooth_learning.py:166-167 is decided for every value the four spectral norms can
+// take: met -> every problem's done flag is raised (halt = 3: the host reports the exact values); surely not met -> the
+// batch goes on; a tie inside the brackets' width -> halt = 1, the host decides.  B <= 32.
+constexpr int BATCH_BRACKET_MAXB = 32;
+__global__ __launch_bounds__(256) void k_batch_brackets(const double *__restrict__ dots, const int2 *__restrict__ pairs, int npairs,
+                                                        const LogdegDev *__restrict__ devs, int nprob, double t2, BatchState *st) {
+    __shared__ double gA[4 * BATCH_BRACKET_MAXB * BATCH_BRACKET_MAXB];
+    __shared__ double br[8];
+    if (st->want_brackets == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, B = nprob;
+    for (int k = tid; k < npairs; k += 256) {
+        const int2 pr = pairs[k];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gA[(q * B + pr.x) * B + pr.y] = gA[(q * B + pr.y) * B + pr.x] = dots[(size_t)k * 4 + q];
+    }
+    __syncthreads();
+    {
+        double lo, hi;
+        if (B <= 16)
+            sm_lambda_bracket<4>(gA + wave * B * B, B, lane, lo, hi);
+        else
+            sm_lambda_bracket<16>(gA + wave * B * B, B, lane, lo, hi);
+        if (lane == 0) br[2 * wave] = lo, br[2 * wave + 1] = hi;
+    }
+    __syncthreads();
+    if (tid == 0) {  // {lo, hi} x {update, iterate, dual update, dual}
+        const double tp = t2 * (1 + 1e-9), tm = t2 * (1 - 1e-9);
+        const bool not_yet = br[0] > tp * br[3] || br[4] > tp * br[7];
+        const bool met = br[2] > 0 && br[6] > 0 && br[1] < tm * br[2] && br[5] < tm * br[6];
+        st->want_brackets = 0;
+        const int halt = met ? 3 : (not_yet ? 0 : 1);
+        if (halt) {
+            for (int a = 0; a < nprob; ++a) devs[a].ctr[0] = 1;
+            st->halt = halt;
+        }
+    }
 }
 
 int check(gl_logdeg *s) { return (s && s->ctx) ? GL_OK : GL_E_INVALID; }
@@ -1456,7 +1592,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
         auto up = [](size_t b) { return (b + 255) / 256 * 256; };
         const bool small_path = maxit >= 8 && gl_small_applicable(sessions[0]) && B <= ctx->prop.multiProcessorCount;
         const size_t b_pairs = up((size_t)npairs * sizeof(int2)), b_ptrs = up((size_t)2 * B * sizeof(BatchPtrs));
-        const size_t b_part = up((size_t)npairs * blocks * 4 * 8), b_out = up((size_t)npairs * 4 * 8);
+        const size_t b_part = 256 + up((size_t)npairs * blocks * 4 * 8), b_out = up((size_t)npairs * 4 * 8);
         const size_t b_devs = up((size_t)B * sizeof(LogdegDev));
         const size_t b_small = small_path ? up(gl_small_batch_scratch_bytes(B, (int)sessions[0]->n)) : 0;
         char *at = nullptr;
@@ -1542,76 +1678,118 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
         }
     }
 
-    // the B x 4 diagonal entries land in the context's pinned staging area (no staged copy runs in this loop)
-    if ((size_t)4 * B * 8 > GL_STAGE_BYTES) return gl_set_error(ctx, GL_E_INVALID, "batch too large (B = %d)", B);
+    // Larger graphs: two batched launches per iteration (edge pass, node pass; blockIdx.y = graph), enqueued a CHUNK of
+    // iterations at a time as one captured graph.  The screen of the coupled rule runs on the device, in the node pass's
+    // last workgroup (k_node_batch): while it can rule the rule out nothing stops; when it cannot -- or when the call's
+    // budget is used up -- every problem's done flag is raised, the rest of the chunk falls through, and the host, which
+    // looks once per chunk, forms the exact spectral norms for exactly that iterate.  (Round 2 synchronised after every
+    // iteration: 45-57 us per iteration at n = 256, against ~10 us for the two launches.)
     if (ctx->stage_busy) {
         GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->stage_busy = false;
     }
-    double *diag = (double *)((char *)ctx->pinned + GL_STATUS_BYTES);
-    const bool use_graph = maxit >= 8 && !getenv("GRAPHLEARN_AMD_NO_GRAPH");
-    struct Graphs {
-        hipGraphExec_t g[2] = {nullptr, nullptr};
-        ~Graphs() {
-            for (hipGraphExec_t e : g)
-                if (e) (void)hipGraphExecDestroy(e);
+    BatchState *st_dev = (BatchState *)sc.part;  // (the partials of the exact evaluation live behind it)
+    sc.part = (char *)sc.part + 256;
+    BatchState *st_host = (BatchState *)((char *)ctx->pinned + GL_STATUS_BYTES);
+    {
+        BatchState init{};
+        init.first = 1;
+        init.remaining = (int)std::min<int64_t>(maxit, 1 << 30);
+        *st_host = init;
+        GL_HIP(ctx, hipMemcpyAsync(st_dev, st_host, sizeof(BatchState), hipMemcpyHostToDevice, ctx->stream));
+        GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    const double t2 = tol * tol;
+    const int chunk = (int)std::min<int64_t>(maxit, getenv("GRAPHLEARN_AMD_BATCH_CHUNK") ? std::max(1, atoi(getenv("GRAPHLEARN_AMD_BATCH_CHUNK"))) : 16);
+    struct Graph {
+        hipGraphExec_t g = nullptr;
+        ~Graph() {
+            if (g) (void)hipGraphExecDestroy(g);
         }
-    } graphs;
-    auto step_and_diag = [&](int par_after) {
+    } graph;
+    // Two forms of an iteration.  "Cruise": edge pass + node pass (whose last workgroup screens the rule and halts the batch
+    // when it cannot rule it out).  "Decide": the same two, and behind them the pair products, their reduction and the
+    // brackets of the four spectral norms -- three launches that fall through unless the screen asked for them --, so that
+    // the stretch of a run in which the cheap bounds straddle tol (about its last third) is judged on the device too.
+    // A call cruises until the screen halts it for the first time, then continues in the other form (B <= 32).
+    const bool can_decide = B <= BATCH_BRACKET_MAXB && !getenv("GRAPHLEARN_AMD_BATCH_HOST_RULE");
+    auto one_iteration = [&](bool decide) {  // (the kernels take the iteration index from device memory: the same launches every time)
         k_edge_batch<<<dim3((unsigned)D0.G, (unsigned)B), dim3(64), 0, ctx->stream>>>((const LogdegDev *)sc.devs);
-        k_node_batch<<<dim3((unsigned)D0.nb, (unsigned)B), dim3(NODE_WAVES * 64), 0, ctx->stream>>>((const LogdegDev *)sc.devs);
-        k_batch_dots<<<dim3((unsigned)B, (unsigned)blocks), 256, 0, ctx->stream>>>(
-            (const BatchPtrs *)sc.ptrs + (size_t)par_after * B, (const int2 *)sc.pairs, n_tiled, sessions[0]->n,
-            (double *)sc.part);
-        k_batch_dots_reduce<<<dim3((unsigned)((B * 4 + 255) / 256)), 256, 0, ctx->stream>>>((const double *)sc.part, B, blocks,
-                                                                                      (double *)sc.out);
-        (void)hipMemcpyAsync(diag, sc.out, (size_t)B * 4 * 8, hipMemcpyDeviceToHost, ctx->stream);
-    };
-    if (use_graph)
-        for (int par = 0; par < 2; ++par) {
-            hipGraph_t graph = nullptr;
-            GL_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-            step_and_diag(par);
-            hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
-            if (e == hipSuccess) e = hipGraphInstantiate(&graphs.g[par], graph, nullptr, nullptr, 0);
-            if (graph) (void)hipGraphDestroy(graph);
-            if (e != hipSuccess) return gl_set_error(ctx, GL_E_HIP, "batch graph capture failed: %s", hipGetErrorString(e));
+        k_node_batch<<<dim3((unsigned)D0.nb, (unsigned)B), dim3(NODE_WAVES * 64), 0, ctx->stream>>>((const LogdegDev *)sc.devs, st_dev, B, t2);
+        if (decide) {
+            k_batch_dots<<<dim3((unsigned)npairs, (unsigned)blocks), 256, 0, ctx->stream>>>(
+                (const BatchPtrs *)sc.ptrs, (const int2 *)sc.pairs, n_tiled, sessions[0]->n, (double *)sc.part, &st_dev->want_brackets,
+                D0.ctr + 2, B);
+            k_batch_dots_reduce<<<dim3((unsigned)((npairs * 4 + 255) / 256)), 256, 0, ctx->stream>>>(
+                (const double *)sc.part, npairs, blocks, (double *)sc.out, &st_dev->want_brackets);
+            k_batch_brackets<<<1, 256, 0, ctx->stream>>>((const double *)sc.out, (const int2 *)sc.pairs, npairs,
+                                                         (const LogdegDev *)sc.devs, B, t2, st_dev);
         }
+    };
+    const bool use_graph = chunk >= 4 && !getenv("GRAPHLEARN_AMD_NO_GRAPH");
+    struct Graph2 {
+        hipGraphExec_t g = nullptr;
+        ~Graph2() {
+            if (g) (void)hipGraphExecDestroy(g);
+        }
+    } graph_decide;
+    auto capture = [&](bool decide, hipGraphExec_t *out) -> int {
+        hipGraph_t gr = nullptr;
+        GL_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        for (int k = 0; k < chunk; ++k) one_iteration(decide);
+        hipError_t e = hipStreamEndCapture(ctx->stream, &gr);
+        if (e == hipSuccess) e = hipGraphInstantiate(out, gr, nullptr, nullptr, 0);
+        if (gr) (void)hipGraphDestroy(gr);
+        if (e != hipSuccess) return gl_set_error(ctx, GL_E_HIP, "batch graph capture failed: %s", hipGetErrorString(e));
+        return GL_OK;
+    };
+    if (use_graph) GL_TRY(capture(false, &graph.g));
+    bool deciding = false;  // the form the call is in
+    auto rearm = [&]() -> int {
+        k_batch_rearm<<<dim3((unsigned)((B + 63) / 64)), 64, 0, ctx->stream>>>((const LogdegDev *)sc.devs, B, st_dev);
+        GL_HIP(ctx, hipGetLastError());
+        return GL_OK;
+    };
 
     double rp = std::numeric_limits<double>::infinity(), rd = rp;
     bool have_exact = false, converged = false;
     int64_t n_iter = 0;
-    for (int64_t i = 0; i < maxit; ++i) {
-        const int par_after = (int)((sessions[0]->it + 1) & 1);
+    const int64_t it0 = sessions[0]->it;
+    while (n_iter < maxit) {
         if (use_graph)
-            GL_HIP(ctx, hipGraphLaunch(graphs.g[par_after], ctx->stream));
+            GL_HIP(ctx, hipGraphLaunch(deciding ? graph_decide.g : graph.g, ctx->stream));
         else
-            step_and_diag(par_after);
-        for (int a = 0; a < B; ++a) sessions[a]->it += 1;
+            for (int k = 0; k < chunk; ++k) one_iteration(deciding);
         GL_HIP(ctx, hipGetLastError());
+        GL_HIP(ctx, hipMemcpyAsync(st_host, st_dev, sizeof(BatchState), hipMemcpyDeviceToHost, ctx->stream));
         GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        n_iter = i + 1;
-        have_exact = false;
-        if (i == 0) continue;  // :156 `if i > 0`
-        double mx[4] = {0, 0, 0, 0}, tr[4] = {0, 0, 0, 0};
-        for (int a = 0; a < B; ++a)
-            for (int q = 0; q < 4; ++q) {
-                mx[q] = std::max(mx[q], diag[(size_t)a * 4 + q]);
-                tr[q] += diag[(size_t)a * 4 + q];
+        if (st_host->ran > n_iter) have_exact = false;
+        n_iter = st_host->ran;
+        for (int a = 0; a < B; ++a) sessions[a]->it = it0 + n_iter;
+        if (st_host->halt == 0) continue;  // the whole chunk ran
+        if (st_host->halt == 1 || st_host->halt == 3) {  // the rule could not be ruled out for this iterate (3: the device found it met)
+            GL_TRY(exact(rp, rd));
+            have_exact = true;
+            if (st_host->halt == 3 || (rp < tol && rd < tol)) {  // :166-167, after the update
+                converged = true;
+                break;
             }
-        const bool degenerate = !(mx[1] > 0) || !(mx[3] > 0);
-        // rel_p^2 in [mx0 / tr1, tr0 / mx1], rel_d^2 in [mx2 / tr3, tr2 / mx3]; a margin for rounding
-        const double t2 = tol * tol;
-        const bool surely_not = !degenerate && (mx[0] / tr[1] > t2 * (1 + 1e-9) || mx[2] / tr[3] > t2 * (1 + 1e-9));
-        if (surely_not) continue;
-        GL_TRY(exact(rp, rd));
-        have_exact = true;
-        if (rp < tol && rd < tol) {  // :166-167, after the update
-            converged = true;
-            break;
         }
+        if (n_iter >= maxit) break;
+        if (can_decide && !deciding) {  // from here on the device judges such iterates itself
+            deciding = true;
+            if (use_graph) GL_TRY(capture(true, &graph_decide.g));
+            st_host->decide_here = 1;
+            GL_HIP(ctx, hipMemcpyAsync(&st_dev->decide_here, &st_host->decide_here, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        }
+        GL_TRY(rearm());
     }
-    if (!have_exact && n_iter > 1) GL_TRY(exact(rp, rd));  // the values the caller sees
+    GL_TRY(rearm());  // the done flags belong to this call's screen
+    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!have_exact && n_iter > 1) {  // the values the caller sees; the budget's last iteration is judged like any other (:166-167)
+        GL_TRY(exact(rp, rd));
+        if (rp < tol && rd < tol) converged = true;
+    }
     if (n_iter_out) *n_iter_out = n_iter;
     if (converged_out) *converged_out = converged ? 1 : 0;
     if (rel_out) {

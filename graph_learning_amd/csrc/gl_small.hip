@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <vector>
 
+#include "gl_bracket.h"
 #include "gl_gridbar.h"
 #include "gl_lanes.h"
 #include "gl_logdeg.h"
@@ -70,53 +71,6 @@ __device__ __forceinline__ double sm_ld(const double *p) {
 __device__ __forceinline__ double sm_wave_max(double v) { return wave_max(v); }  // gl_lanes.h (DPP)
 __device__ __forceinline__ void sm_st(double *p, double v) {
     __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// One wave: rigorous bracket [lo, hi] of the largest eigenvalue of the symmetric positive semi-definite
-// B x B matrix A (LDS, destroyed), B <= 32.  With A_0 = A / tr A and A_{k+1} = A_k^2 / t_k, t_k = tr A_k^2:
-// mu_k = lambda_max(A_k) obeys mu_k = sqrt(t_k mu_{k+1}), and a trace-1 PSD matrix has tr A^2 <= mu <= sqrt(tr A^2).
-// So log mu_0 = sum_k 2^-(k+1) log t_k + 2^-m log mu_m with mu_m in [t_m, sqrt t_m]: the width of the bracket
-// is 2^-(m+1) |log t_m| <= 2^-(m+1) log B in the logarithm.  Stops early once A_k is rank one (t_k -> 1).
-template <int EPL>  // matrix entries per lane: 4 (B <= 16) or 16 (B <= 32)
-__device__ __forceinline__ void sm_lambda_bracket(double *A, int B, int lane, double &lo, double &hi) {
-    const int nn = B * B;
-    double tr = 0.0;
-    for (int i = lane; i < B; i += 64) tr += A[i * B + i];
-    tr = wave_sum(tr);
-    if (!(tr > 0.0)) {
-        lo = hi = 0.0;
-        return;
-    }
-    for (int idx = lane; idx < nn; idx += 64) A[idx] = A[idx] / tr;
-    double L = 0.0, wgt = 0.5;
-    for (int k = 0; k < 34; ++k) {
-        double sv[EPL], dsum = 0.0;
-#pragma unroll
-        for (int r = 0; r < EPL; ++r) {
-            const int idx = lane + 64 * r;
-            sv[r] = 0.0;
-            if (idx < nn) {
-                const int i = idx / B, j = idx - i * B;
-                double acc = 0.0;
-                for (int l = 0; l < B; ++l) acc += A[i * B + l] * A[l * B + j];
-                sv[r] = acc;
-                if (i == j) dsum += acc;
-            }
-        }
-        const double t = wave_sum(dsum);  // tr A_k^2, in (1/B, 1]
-#pragma unroll
-        for (int r = 0; r < EPL; ++r)
-            if (lane + 64 * r < nn) A[lane + 64 * r] = sv[r] / t;
-        L += wgt * log(t);
-        wgt *= 0.5;
-        if (t > 1.0 - 1e-13) break;
-    }
-    double fro = 0.0;
-    for (int idx = lane; idx < nn; idx += 64) fro += A[idx] * A[idx];
-    const double tm = fmin(wave_sum(fro), 1.0);  // tr A_m^2 (A_m symmetric)
-    const double lt = log(tm);                   // <= 0
-    lo = tr * exp(L + 2.0 * wgt * lt) * (1.0 - 1e-12);
-    hi = tr * exp(L + wgt * lt) * (1.0 + 1e-12);
 }
 
 // The in-kernel tightening of the coupled rule's brackets (see the header).  Kept out of line and fed from LDS

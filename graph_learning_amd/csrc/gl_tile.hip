@@ -51,6 +51,7 @@
 // the owners), so a launch whose workgroups are not all co-resident (start-up rendezvous, bounded by the wall
 // clock) leaves the session untouched and the host redoes the call on the streaming engine.
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "gl_gridbar.h"
@@ -636,8 +637,10 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     auto fringe_off = [&](int ln) -> int64_t { return gl_tile_id(fB, fB, P.nb) * GL_TILE_ELEMS + (ln >> 5) * TB + 2 * (ln & 31); };
     if (has) zb = (unsigned)(chunk_off(lane) * 8);
     // The bulk loads of the prologue, in the order the first pass wants them: the LDS-resident part of z (straight into
-    // LDS: zg is stored pre-multiplied, so nothing has to pass through registers), the head of the z ring, the fringe, w.
-    // Nothing here waits: the first pass consumes w row pair by row pair as it arrives.
+    // LDS: zg is stored pre-multiplied, so nothing has to pass through registers) -- waited for at once: the compiler
+    // treats an LDS-DMA as a FLAT access that may touch both memories, and while one is pending every vmcnt wait of the wave
+    // becomes vmcnt(0) --, then the head of the z ring, the fringe and w, which nothing waits for: the first pass consumes w
+    // row pair by row pair as it arrives.
     auto bulk_loads = [&]() {
         const int64_t tb0 = chunk_off(lane), ftb = fringe_off(lane);
         if (has) {
@@ -651,9 +654,22 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 for (int s = WRG; s < U; ++s)  // (rounds: the last row pairs of w live in LDS)
                     tl_dma16(P.w + tb0 + s * (2 * TB), &s_z[wave][ZLN + s - WRG][0]);
             }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): the DMAs have landed
+        // The ring and w in ONE straight-line block, in the order of use, the fringe (used after the pass) behind them: the
+        // compiler counts pending loads per static path, and with the ring in a block of its own there is a path on which
+        // the ring loads are the youngest -- the first row pair would wait for everything (vmcnt(3)).  The empty asm
+        // statements keep the scheduler from re-ordering the loads.
+        if (has) {
             if (NS > 0 && !BIG) {
 #pragma unroll
                 for (int k = 0; k < RING; ++k) zr[k] = tl_ldz(P.zg, zb + (unsigned)(2 * k * (2 * TB) * 8));
+                asm volatile("" ::: "memory");
+            }
+#pragma unroll
+            for (int s = 0; s < (BIG ? WRG : U); ++s) {
+                wreg[s] = *reinterpret_cast<const double2 *>(P.w + tb0 + s * (2 * TB));
+                asm volatile("" ::: "memory");
             }
         }
 #pragma unroll
@@ -662,10 +678,6 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 fw[f] = *reinterpret_cast<const double2 *>(P.w + ftb + (int64_t)(fa0 + f) * (2 * TB));
                 fgz[f] = *reinterpret_cast<const double2 *>(P.zg + ftb + (int64_t)(fa0 + f) * (2 * TB));
             }
-        if (has) {
-#pragma unroll
-            for (int s = 0; s < (BIG ? WRG : U); ++s) wreg[s] = *reinterpret_cast<const double2 *>(P.w + tb0 + s * (2 * TB));
-        }
     };
     if (U < SLOTS) s_part[wave][0][lane] = 0.0;  // rows of the tile outside my chunk contribute nothing to my row vector
     // rounds (BIG): my tiles are (I + r, J), r < my_nr; round 0 is the resident one when `has`
@@ -776,13 +788,20 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         }
         return true;
     };
-    for (int it = 0; met && it <= P.maxit; ++it) {
+    // One iteration.  FIRST (iteration 0 of the call) is an instantiation of its own, in front of the loop: it takes its node
+    // values from the prologue instead of polling for them, and -- the point of the copy -- nothing but the bulk loads of the
+    // prologue is pending when its pass starts, so the pass waits for w row pair by row pair (vmcnt(31), vmcnt(30), ...) and
+    // runs underneath the loads.  Inside the loop the same pass sees, on some path, a store or a poll in front of it, and
+    // with loads and stores both pending a wave can only wait for all of them (gfx9 returns them out of order with respect
+    // to each other).  false: the call ends here (stopped, failed, or all iterations done).
+    auto iteration = [&](auto first_c, const int it) __attribute__((always_inline)) -> bool {
+        constexpr bool FIRST = decltype(first_c)::value;
         const unsigned tag_in = P.tag0 + (unsigned)it;        // node values that are the input of iteration `it`
         const unsigned tag_out = P.tag0 + (unsigned)it + 1u;  // what iteration `it` produces
         const bool last_pass = it == P.maxit;
         // does this workgroup evaluate the rule of iteration it - 1 now?
-        const bool want_rule = NORMS && it >= 1 && (last_pass ? wg == 0 : rule_on);
-        if (last_pass && !want_rule) break;
+        const bool want_rule = !FIRST && NORMS && it >= 1 && (last_pass ? wg == 0 : rule_on);
+        if (last_pass && !want_rule) return false;
         const bool stamp = P.dbg != nullptr && it >= 8 && it < 24 && !last_pass;
         unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
         if (stamp) ts[0] = __builtin_amdgcn_s_memrealtime();
@@ -791,7 +810,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         {
             bool good = true;
             if (!last_pass) {
-                if (it == 0) {  // (the state the previous call, or init, left in memory: in s_node since the prologue)
+                if constexpr (FIRST) {  // (the state the previous call, or init, left in memory: in s_node since the prologue)
                 } else if (wave < nblk) {
                     // (two probes in flight, half a round trip apart, measured slower: their registers push the pass into
                     //  scratch, and most first probes succeed anyway)
@@ -888,7 +907,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         if (s_flag[1]) {
             failed = true;
             fail_it = it;
-            break;
+            return false;
         }
         if (want_rule) {
             exact = (s_flag[3] & 1) != 0;
@@ -899,7 +918,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             }
             if (s_flag[2]) stopped = 1;
         }
-        if (stopped || last_pass) break;  // the rule of iteration it - 1 holds: its iterate is the result
+        if (stopped || last_pass) return false;  // the rule of iteration it - 1 holds: its iterate is the result
 
         // ================= edge phase =================
         if (stamp) ts[1] = __builtin_amdgcn_s_memrealtime();
@@ -1194,7 +1213,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             if (s_flag[1]) {
                 failed = true;
                 fail_it = it;
-                break;
+                return false;
             }
             if (wave == 0) {
                 // (addresses formed from the lane number here and now: kept over the pass they end up in scratch in the
@@ -1281,7 +1300,11 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             unsigned long long *o = P.dbg + ((size_t)wg * 16 + (it - 8)) * 6;
             for (int q = 0; q < 6; ++q) o[q] = ts[q];
         }
-    }
+        return true;
+    };
+    if (met && iteration(std::true_type{}, 0))
+        for (int it = 1; it <= P.maxit; ++it)
+            if (!iteration(std::false_type{}, it)) break;
 
     if (failed) {  // nothing of the session's state has been written
         if (wg == 0 && tid == 0) {

@@ -79,7 +79,7 @@ def test_batched_paths_agree_and_fall_back(golden, engine, monkeypatch):
 
 @pytest.mark.parametrize("rule", ["device", "host"])
 @pytest.mark.parametrize("n,b", [(2, 3), (5, 1), (5, 300), (64, 5), (65, 4), (128, 3), (129, 3), (30, 20), (64, 16),
-                                 (100, 32), (128, 20), (128, 32)])
+                                 (100, 32), (128, 20), (128, 32), (256, 8), (300, 5)])
 def test_batched_sizes_against_oracle(n, b, rule, monkeypatch):
     """Both sides of the small-engine limits (64 / 128 nodes), a batch of one, tiny graphs, batches on both
     sides of what the in-kernel evaluation of the coupled rule takes (B <= 32, LDS permitting): same stopping
@@ -96,6 +96,27 @@ def test_batched_sizes_against_oracle(n, b, rule, monkeypatch):
     np.testing.assert_allclose(out, ref, rtol=0, atol=1e-10)
     assert got["rel_primal"] == pytest.approx(info["rel"][0], rel=1e-8)
     assert got["rel_dual"] == pytest.approx(info["rel"][1], rel=1e-8)
+
+
+@pytest.mark.parametrize("chunk", ["1", "5", "16"])
+def test_batched_launch_path_chunks_and_budget(chunk, monkeypatch):
+    """Above n = 128 the coupled loop runs as chunks of batched launches with the rule's screen on the device (the node
+    pass's last workgroup raises every problem's done flag; the rest of the chunk falls through).  Whatever the chunk
+    length: the iteration budget is kept exactly (maxit not a multiple of the chunk), a call with tol = 0 never stops
+    early, a second call continues the first, and the stopping iteration of a run to tol equals the oracle's."""
+    monkeypatch.setenv("GRAPHLEARN_AMD_BATCH_CHUNK", chunk)
+    n, b = 200, 3
+    rng = default_rng(5)
+    z = rng.uniform(0.1, 3.0, size=(b, n * (n - 1) // 2))
+    ref, info = old.learn_log_degrees(z, 1.0, 1.0, maxit=37, tol=0.0, edge_tol=-np.inf, return_info=True)
+    out, got = gsp_learn_graph_log_degrees(z, 1.0, 1.0, maxit=37, tol=0.0, edge_tol=-np.inf, return_info=True)
+    assert got["n_iter"] == 37 and not got["converged"]
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-10)
+    assert got["rel_primal"] == pytest.approx(info["rel"][0], rel=1e-8)
+    ref, info = old.learn_log_degrees(z, 1.0, 1.0, maxit=1000, tol=2e-4, edge_tol=-np.inf, return_info=True)
+    out, got = gsp_learn_graph_log_degrees(z, 1.0, 1.0, maxit=1000, tol=2e-4, edge_tol=-np.inf, return_info=True)
+    assert got["converged"] and got["n_iter"] == info["n_iter"]
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-10)
 
 
 def test_batch_gram_entry_point():

@@ -46,6 +46,15 @@ def census(lines):
                 break
     return c
 pass_blocks = [b for b in blocks if sum("v_max_f64" in l for l in b) >= 8]
+# the kernel holds the pass twice: iteration 0 is an instantiation of its own in front of the loop (it runs underneath the
+# prologue's loads); the census is of the loop's copy, the last 64 v_max_f64 in program order
+keep, cnt = [], 0
+for b in reversed(pass_blocks):
+    if cnt >= 64:
+        break
+    keep.append(b)
+    cnt += sum("v_max_f64" in l for l in b)
+pass_blocks = keep[::-1]
 tot = {}
 for b in pass_blocks:
     for k, v in census(b).items():
