@@ -229,7 +229,7 @@ def main():
 
     engine = sess.engine                                 # "resident" (n=4096 default) or "stream"
     engine_kernel = sess.engine_kernel                   # "k_tile" (default), "k_resident" or "k_edge"
-    if engine == "resident" and args.steps < 16:         # calls shorter than 16 iterations run on the streaming engine
+    if engine == "resident" and args.steps < (4 if engine_kernel == "k_tile" else 16):   # shorter calls run on the streaming engine
         engine, engine_kernel = "stream", "k_edge"
     # steady state and fixed cost per call: a long call (2000 steps, or the timed one if it is longer) gives the
     # per-iteration rate; what the timed call took beyond steps x that rate is the call's fixed cost

@@ -84,6 +84,7 @@ void gl_resident_free(gl_logdeg *s);
 int gl_resident_launch(gl_logdeg *s, int64_t iters, double tol);
 int gl_resident_finish(gl_logdeg *s, int64_t *iters_done, bool *stopped, bool *not_resident);
 // gl_tile.hip
+constexpr int GL_TILE_MIN_CALL = 4;  // shortest call (iterations) the tile engine takes; shorter ones stream
 int gl_tile_prepare(gl_logdeg *s);
 void gl_tile_free(gl_logdeg *s);
 int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int final_parity);

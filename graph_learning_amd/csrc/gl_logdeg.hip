@@ -1186,7 +1186,11 @@ GL_API int gl_logdeg_init(gl_logdeg *s, double alpha, double beta, double step_s
 // The resident engine (gl_resident.hip) takes over when it applies and the call is long enough
 // to amortise loading / storing the register-held iterate.  GRAPHLEARN_AMD_ENGINE=stream disables it.
 static bool use_small(const gl_logdeg *s, int64_t iters) { return iters >= 8 && gl_small_applicable(s); }
-static bool use_resident(const gl_logdeg *s, int64_t iters) { return (s->tile != nullptr || s->res != nullptr) && iters >= 16; }
+// (a call of the tile engine costs ~30 us beyond its iterations -- loading w and half of z, storing w -- and 5-7 us per
+//  iteration, the streaming engine 10-40 us per iteration: from four iterations on the tile engine is never slower)
+static bool use_resident(const gl_logdeg *s, int64_t iters) {
+    return s->tile != nullptr ? iters >= GL_TILE_MIN_CALL : (s->res != nullptr && iters >= 16);
+}
 // the persistent launch of the session's resident-family engine: the tile engine where it applies
 static int persistent_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int final_parity = -1) {
     return s->tile ? gl_tile_launch(s, iters, tol, norms, final_parity) : gl_resident_launch(s, iters, tol);
@@ -1717,6 +1721,8 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
         k_edge_batch<<<dim3((unsigned)D0.G, (unsigned)B), dim3(64), 0, ctx->stream>>>((const LogdegDev *)sc.devs);
         k_node_batch<<<dim3((unsigned)D0.nb, (unsigned)B), dim3(NODE_WAVES * 64), 0, ctx->stream>>>((const LogdegDev *)sc.devs, st_dev, B, t2);
         if (decide) {
+            // (a one-pass Gram kernel -- every vector staged once in LDS, all pairs from there -- measured slower than these
+            //  B-fold re-reads from L2: it is bound by its LDS reads, two per multiply-add)
             k_batch_dots<<<dim3((unsigned)npairs, (unsigned)blocks), 256, 0, ctx->stream>>>(
                 (const BatchPtrs *)sc.ptrs, (const int2 *)sc.pairs, n_tiled, sessions[0]->n, (double *)sc.part, &st_dev->want_brackets,
                 D0.ctr + 2, B);

@@ -73,6 +73,9 @@
 #ifndef GL_TILE_PROBE_GAP
 #define GL_TILE_PROBE_GAP 12  // s_sleep units (64 cycles) between the two: about half a round trip
 #endif
+#ifndef GL_TILE_ZNT_MASK
+#define GL_TILE_ZNT_MASK 0
+#endif
 #ifndef GL_TILE_ROWGROUP
 #define GL_TILE_ROWGROUP 8     // row pairs whose row sums share one halving butterfly (4: 1.5 adds per row pair, 8: 1.125)
 #endif
@@ -293,7 +296,12 @@ __device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[
                 const int pos = (s / 2) % RING;
                 gz = zr[pos];
                 // refill with the RING-th next streamed row pair (2 RING row pairs ahead; wraps into the next iteration)
-                if (WRAP || s + 2 * RING < SLOTS) zr[pos] = tl_ldz<ZNT>(P.zg, zbv + (unsigned)(((s + 2 * RING) % SLOTS) * (2 * TB) * 8));
+                if (WRAP || s + 2 * RING < SLOTS) {
+                    const unsigned off = zbv + (unsigned)(((s + 2 * RING) % SLOTS) * (2 * TB) * 8);
+                    // (GL_TILE_ZNT_MASK: ring slots whose loads carry the non-temporal hint -- experiment: the streamed half of z
+                    //  is 4.2 MB per XCD, just over its 4 MB L2, and a cyclic stream through an LRU cache never hits)
+                    zr[pos] = (ZNT || ((GL_TILE_ZNT_MASK >> pos) & 1)) ? tl_ldz<true>(P.zg, off) : tl_ldz<false>(P.zg, off);
+                }
             } else {
                 gz = zl_n;
             }
@@ -956,8 +964,10 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             if (my_nr > 0) {
                 const double2 *rows = &s_node[my_rs & 15][0];
                 if (has) {
+                    unsigned zb0 = zb;  // (not loop-invariant for the compiler: it would keep the ring's 64-bit addresses over the iteration, in scratch)
+                    asm volatile("" : "+v"(zb0));
 #pragma unroll
-                    for (int k = 0; k < RING; ++k) zr[k] = tl_ldz<NT>(P.zg, zb + (unsigned)(RoundsSplit<NORMS>::slot(k) * (2 * TB) * 8));
+                    for (int k = 0; k < RING; ++k) zr[k] = tl_ldz<NT>(P.zg, zb0 + (unsigned)(RoundsSplit<NORMS>::slot(k) * (2 * TB) * 8));
                     tl_resident_pass_rounds<MASKW, NORMS, NT>(P, wreg, zr, &s_z[wave][0][lane], zb, rows, cv0.x, cv1.x, cv0.y, cv1.y, m0, m1,
                                                               &s_part[wave][0][0], col, lane, wave >= TW / 2, nqy, nw);
                 } else {  // (a column whose first tile here is its diagonal tile)
@@ -1126,7 +1136,9 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             if (!have) look = norms_of(it - 1, b) ? 0 : -1;
             double lp = INFINITY, ld = INFINITY;
             if (look == 0 && P.it0 + it - 1 >= 1) {  // never for iteration 0 (:156-161)
-                const double t2 = P.tol * P.tol, u2 = (1.25 * P.tol) * (1.25 * P.tol);
+                double tl = P.tol;
+                asm volatile("" : "+s"(tl));  // (formed here: hoisted out of the iteration loop the squares live in scratch)
+                const double t2 = tl * tl, u2 = (1.25 * tl) * (1.25 * tl);
                 if (b[0] < t2 * b[1] && b[2] < t2 * b[3]) {
                     lp = sqrt(b[0]) / sqrt(b[1]), ld = sqrt(b[2]) / sqrt(b[3]);
                     look = (lp < P.tol && ld < P.tol) ? 1 : 2;
@@ -1282,12 +1294,14 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     }
                 }
                 const double n0 = wave_sum(nmine ? tl_val(na) : 0.0), n1 = wave_sum(nmine ? tl_val(nb2) : 0.0);
+                int l2 = lane;
+                asm volatile("" : "+v"(l2));  // (addresses formed from the lane number here and now, as in wave 0's update)
                 if (!got) {
-                    if (lane == 0) s_flag[1] = 1;  // (seen at the next top)
-                } else if (lane < 2) {
-                    const double v = lane == 0 ? n0 : n1;
-                    s_bn[lane] = v;
-                    __builtin_amdgcn_raw_buffer_store_b128(tl_gran(v, tag_out), r_bn, ((((it & 3) * (int)P.nb + own) * 4) + lane) * 16, 0, 16);
+                    if (l2 == 0) s_flag[1] = 1;  // (seen at the next top)
+                } else if (l2 < 2) {
+                    const double v = l2 == 0 ? n0 : n1;
+                    s_bn[l2] = v;
+                    __builtin_amdgcn_raw_buffer_store_b128(tl_gran(v, tag_out), r_bn, ((((it & 3) * (int)P.nb + own) * 4) + l2) * 16, 0, 16);
                 }
             }
             tl_barrier();  // s_own has been read: s_part is free for the next pass (its zeros first, below)

@@ -132,7 +132,7 @@ def test_resume_equals_single_run(golden):
         s.iterate_async(30)
         assert s.total_iterations == 50
         w = s.weights_condensed()
-    # with the resident engine forced, short calls (< 16 iterations) still run on the streaming
+    # with the resident engine forced, short calls (< 4 iterations; round 1's engine: < 16) still run on the streaming
     # engine: same iterates up to the order of the degree sums
     np.testing.assert_allclose(w, raw_iterate(zt, 1, 1, 50)[0], rtol=0, atol=1e-13)
     np.testing.assert_allclose(w, g["raw_w_it50"], rtol=0, atol=ATOL)
@@ -449,7 +449,7 @@ def test_rounds_of_the_tile_engine_in_converge_mode_against_the_streaming_engine
 
 def test_large_lattice_n8192_against_dense_restatement(engine):
     """n = 8192 (beyond the Infinity Cache: 3 x 268 MB): the streaming engine (3 iterations) and the tile engine (5 rounds
-    per iteration; 16 iterations, its shortest call) against a dense NumPy restatement of :146-167 (S w = row sums of
+    per iteration; 16 iterations) against a dense NumPy restatement of :146-167 (S w = row sums of
     the symmetric matrix, S'd = d_i + d_j), which needs no sparse operator at this size."""
     if engine not in ("stream", "resident"):
         pytest.skip("once on the streaming engine, once on the tile engine")
@@ -537,7 +537,7 @@ def test_async_variant_equals_synchronous_variant_bit_for_bit(engine, n, iters):
 
 def test_tile_engine_falls_back_after_the_session_has_advanced_on_the_streaming_engine(golden, engine, monkeypatch):
     """a synchronous tile-engine call whose workgroups never meet must fall back to the streaming engine also
-    when the session has already advanced (a short call, < 16 iterations, runs on the streaming engine and leaves the
+    when the session has already advanced (a short call, < 4 iterations, runs on the streaming engine and leaves the
     counters where a stale comparison would mistake the failure for a mid-run one)."""
     if engine != "resident":
         pytest.skip("tile engine only")
@@ -547,7 +547,10 @@ def test_tile_engine_falls_back_after_the_session_has_advanced_on_the_streaming_
     with _lib.LogDegreeSession(64) as s:
         s.set_distances(zt)
         s.init(1, 1, 0.5, None)
-        s.iterate(10, 0.0)                     # streaming engine (short call)
+        s.iterate(3, 0.0)                      # streaming engine (short call)
+        s.iterate(3, 0.0)
+        s.iterate(3, 0.0)
+        s.iterate(1, 0.0)
         assert s.engine == "resident" and s.total_iterations == 10
         n_it, conv, _ = s.iterate(40, 0.0)     # tile engine: rendezvous fails, nothing touched, streaming engine redoes it
         assert n_it == 40 and not conv and s.engine == "stream" and s.total_iterations == 50

@@ -63,14 +63,14 @@ lines = ["# rocprofv3 summary (r03) -- LogModel n=4096 d=1024, tile engine (k_ti
 for d, steps in (("trace20", 20), ("trace2000", 2000)):
     b = bench_line(d)
     durs, rows = launches(d)
-    # bench.py's launches of the timed instantiation in order: [warm-up when >= 16 steps,] first call (`steps`), timed call (`steps`),
+    # bench.py's launches of the timed instantiation in order: warm-up (>= 4 steps), first call (`steps`), timed call (`steps`),
     # long call (max(steps, 2000)); time-to-converge runs the instantiation with the norms
     lines += [f"## `bench.py --steps {steps}`" + (" --warmup 5" if steps == 20 else ""), ""]
     table(d, lines)
     lines += ["", f"{TIMED} launches in order (us): " + ", ".join(f"{x:.1f}" for x in durs),
               f"VGPR {rows[1]['VGPR_Count']}, SGPR {rows[1]['SGPR_Count']}, grid {rows[1]['Grid_Size_X']} x wg {rows[1]['Workgroup_Size_X']}, "
               f"LDS {rows[1]['LDS_Block_Size']}, scratch {rows[1]['Scratch_Size']}"]
-    ti = 1 if steps == 20 else 2   # the default run's 100 warm-up steps are a launch of their own
+    ti = 2   # the warm-up steps (5 or 100: at least the engine's shortest call of 4) are a launch of their own
     timed = durs[ti]
     r = b["roofline"]
     out[f"steps{steps}"] = {"launch_us": durs, "timed_launch_us": timed, "us_per_iteration": timed / steps,
@@ -81,7 +81,7 @@ for d, steps in (("trace20", 20), ("trace2000", 2000)):
               f"SURVEY 8d's algorithmic-bytes figure {r['hbm_algorithmic']['frac']:.2f} x 8 TB/s)", ""]
 
 lines += ["## fabric traffic of the timed launches (PMC, separate passes; FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024 bytes)", ""]
-for steps, ti in ((20, 1), (2000, 2)):
+for steps, ti in ((20, 2), (2000, 2)):
     f, w = counter(f"fetch{steps}", "FETCH_SIZE"), counter(f"write{steps}", "WRITE_SIZE")
     rb, wb = f[ti] * 2 * 1024, w[ti] * 1024
     out["traffic_bytes_per_launch"]["k_tile"][str(steps)] = rb + wb
