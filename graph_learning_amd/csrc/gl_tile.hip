@@ -73,14 +73,12 @@
 #ifndef GL_TILE_PROBE_GAP
 #define GL_TILE_PROBE_GAP 12  // s_sleep units (64 cycles) between the two: about half a round trip
 #endif
-#ifndef GL_TILE_ZNT_MASK
-#define GL_TILE_ZNT_MASK 0
-#endif
 #ifndef GL_TILE_ROWGROUP
 #define GL_TILE_ROWGROUP 8     // row pairs whose row sums share one halving butterfly (4: 1.5 adds per row pair, 8: 1.125)
 #endif
 #ifndef GL_TILE_ROUNDS_ZEV
-#define GL_TILE_ROUNDS_ZEV 8         // rounds: every 8th row pair of the resident tile keeps its z in LDS ...
+#define GL_TILE_ROUNDS_ZEV 4         // rounds: every 4th row pair of the resident tile keeps its z in LDS (25 row pairs of w in registers) ...
+                                     // (8: 21 row pairs in registers; measured 15.1 / 28.3 / 105.8 us per iteration at n = 4160 / 5000 / 8192 against 13.8 / 27.0 / 104.2)
 #endif
 #ifndef GL_TILE_ROUNDS_ZEV_NORMS
 #define GL_TILE_ROUNDS_ZEV_NORMS 64  // ... none in the variants with the norms (more row pairs of w in LDS instead)
@@ -104,6 +102,7 @@ constexpr int FRMAX = 2;       // fringe row pairs per wave
 constexpr int RING = 4;        // register ring of streamed z row pairs (U = 32)
 constexpr int NACQ = (NBW + TW - 1) / TW;  // node blocks one wave fetches
 constexpr int RND = 4;         // records per wave and round of an owner's poll
+constexpr int XMAX = 3;        // split extra tiles per workgroup (rounds just past the register files)
 
 typedef unsigned int tl_u4 __attribute__((ext_vector_type(4)));
 
@@ -130,7 +129,12 @@ struct WgDesc {  // 128 ints
     int active;                   // this workgroup has edges or owns a block (the others leave after the rendezvous)
     int nrnd;                     // rounds of this workgroup (n > 4096; rowmask holds 8 bits per round, rowmask2 rounds 4 .. 7)
     int rowmask2[NBW];
-    int pad[128 - 8 - 5 * NBW];
+    // rounds, "split extras" (just past the register files): tiles (beyond the rectangle) that ALL eight waves of the
+    // workgroup stream together, 4 row pairs each
+    int nx;            // how many (<= XMAX)
+    int xt[4];         // their tile ids
+    int xs[4];         // slots of their row block (bits 0..7) and column block (8..15) in the workgroup's block list; bit 16: diagonal tile
+    int pad[128 - 8 - 5 * NBW - 9];
 };
 static_assert(sizeof(WaveDesc) == 64 && sizeof(WgDesc) == 512, "descriptor sizes");
 
@@ -296,12 +300,7 @@ __device__ __forceinline__ void tl_chunk_pass(const TileDev &P, double2 (&wreg)[
                 const int pos = (s / 2) % RING;
                 gz = zr[pos];
                 // refill with the RING-th next streamed row pair (2 RING row pairs ahead; wraps into the next iteration)
-                if (WRAP || s + 2 * RING < SLOTS) {
-                    const unsigned off = zbv + (unsigned)(((s + 2 * RING) % SLOTS) * (2 * TB) * 8);
-                    // (GL_TILE_ZNT_MASK: ring slots whose loads carry the non-temporal hint -- experiment: the streamed half of z
-                    //  is 4.2 MB per XCD, just over its 4 MB L2, and a cyclic stream through an LRU cache never hits)
-                    zr[pos] = (ZNT || ((GL_TILE_ZNT_MASK >> pos) & 1)) ? tl_ldz<true>(P.zg, off) : tl_ldz<false>(P.zg, off);
-                }
+                if (WRAP || s + 2 * RING < SLOTS) zr[pos] = tl_ldz<ZNT>(P.zg, zbv + (unsigned)(((s + 2 * RING) % SLOTS) * (2 * TB) * 8));
             } else {
                 gz = zl_n;
             }
@@ -359,7 +358,9 @@ struct RoundsSplit {
     static constexpr int WRG = SLOTS - (SLICE - ZLN); // row pairs of w in registers; the others in LDS behind the z
     static constexpr int slot(int t) { return t + t / (ZEV - 1); }  // the t-th streamed row pair
 };
-template <bool MASKW, bool NORMS, bool ZNT>
+// WRAPR (variants without the norms: they have the 16 registers): the ring's last refills are next iteration's first row
+// pairs, so the ring is full when the pass starts (filled right before the pass it costs a memory round trip per iteration).
+template <bool MASKW, bool NORMS, bool ZNT, bool WRAPR>
 __device__ __forceinline__ void tl_resident_pass_rounds(const TileDev &P, double2 (&wreg)[SLOTS], double2 (&zr)[RING], double2 *zw,
                                                         const unsigned zb, const double2 *s_rows, const double aj0, const double aj1,
                                                         const double bj0, const double bj1, const double m0, const double m1,
@@ -385,7 +386,7 @@ __device__ __forceinline__ void tl_resident_pass_rounds(const TileDev &P, double
                 const int t = s - (s + 1) / ZEV;  // streamed row pairs before this one
                 const int pos = t % RING;
                 gz = zr[pos];
-                if (t + RING < NSTR) zr[pos] = tl_ldz<ZNT>(P.zg, zbv + (unsigned)(RoundsSplit<NORMS>::slot(t + RING) * (2 * TB) * 8));
+                if (WRAPR || t + RING < NSTR) zr[pos] = tl_ldz<ZNT>(P.zg, zbv + (unsigned)(RoundsSplit<NORMS>::slot((t + RING) % NSTR) * (2 * TB) * 8));
             } else {
                 gz = zw[(s / ZEV) * 64];
             }
@@ -475,21 +476,22 @@ __device__ __forceinline__ void tl_stream_pass(const TileDev &P, double2 (&wq)[R
                                                const unsigned nxt, const double2 *s_rows, const double aj0, const double aj1,
                                                const double bj0, const double bj1, const bool diag, const bool jv0, const bool jv1,
                                                double *s_row, double (&col)[2], const int lane, double &nqy, double &nw,
-                                               const int g0) {
+                                               const int g0, const int ng = SLOTS / RS) {
+    // (ng < SLOTS / RS: only the groups g0 .. g0 + ng - 1 of the tile -- a tile split between the waves of a workgroup)
     const int half = lane >> 5, c0 = 2 * (lane & 31);
     const double c = P.c, omc = P.omc;
     char *wbase = reinterpret_cast<char *>(P.w);
     const char *zbase = reinterpret_cast<const char *>(P.zg);
     double colp0 = col[0], colp1 = col[1];
 #pragma unroll 1
-    for (int gi = 0; gi < SLOTS / RS; ++gi) {
+    for (int gi = 0; gi < ng; ++gi) {
         // the waves of the chip start their tiles at different row pairs (g0): tiles are 32 KiB apart, and waves that walk
         // them in step would all be on the same few memory channels
         const int gr = (gi + g0) & (SLOTS / RS - 1);
         // what the ring requests next: the following group of this tile, at the end the first group of the next tile
         // (`nxt`; the caller passes this tile again when there is none: a harmless re-read keeps the loop free of branches)
-        const unsigned nbase = gi < SLOTS / RS - 1 ? tb + (unsigned)((((gr + 1) & (SLOTS / RS - 1)) * RS) * (2 * TB) * 8)
-                                                   : nxt + (unsigned)((g0 * RS) * (2 * TB) * 8);
+        const unsigned nbase = gi < ng - 1 ? tb + (unsigned)((((gr + 1) & (SLOTS / RS - 1)) * RS) * (2 * TB) * 8)
+                                           : nxt + (unsigned)((g0 * RS) * (2 * TB) * 8);
 #pragma unroll
         for (int gh = 0; gh < RS / 4; ++gh) {
             const int gq = gr * (RS / 4) + gh;
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     constexpr int NS = U - ZRES;                      // streamed ones
     __shared__ double2 s_z[TW][ZRES][64];             // up to 128 KiB
     __shared__ double2 s_node[BIGV != 0 ? NBW : NBW_FIT][TB];  // {gamma d, gamma u} of the node blocks this workgroup touches
-    __shared__ double s_part[TW][2][TB];              // per chunk: row sums of p, column sums of p (owner phase: s_own)
+    __shared__ double s_part[TW][BIGV != 0 ? 4 : 2][TB];  // per chunk: row sums of p, column sums of p (owner phase: s_own); rounds: the same for a split extra tile
     __shared__ double s_dual[5][TB];                  // owner workgroups: d, ybar, pbar, d of the previous iteration, gamma S w
     __shared__ double s_bn[4];                        // ... and the norm partials of its last update
     __shared__ double s_gu;                           // ... and gamma sum_j u_j over all nodes (inputs of the current iteration)
@@ -584,6 +586,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     auto gd_int = [&](int idx) { return idx < 64 ? __builtin_amdgcn_readlane(gdw0, idx) : __builtin_amdgcn_readlane(gdw1, idx - 64); };
     constexpr int GD_BLK = 4, GD_ENT = GD_BLK + NBW, GD_ROW = GD_ENT + NBW, GD_COL = GD_ROW + NBW;
     constexpr int GD_SLICE = GD_COL + NBW, GD_ACTIVE = GD_SLICE + 2, GD_NRND = GD_ACTIVE + 1, GD_ROW2 = GD_NRND + 1;
+    constexpr int GD_NX = GD_ROW2 + NBW, GD_XT = GD_NX + 1, GD_XS = GD_XT + 4;
     const int nblk = gd_int(0), own = gd_int(1), own_e0 = gd_int(2), own_e1 = gd_int(3);
     const unsigned long long slice_mask = ((unsigned long long)(unsigned)gd_int(GD_SLICE + 1) << 32) | (unsigned)gd_int(GD_SLICE);
     const bool active = gd_int(GD_ACTIVE) != 0;
@@ -674,6 +677,11 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 for (int k = 0; k < RING; ++k) zr[k] = tl_ldz(P.zg, zb + (unsigned)(2 * k * (2 * TB) * 8));
                 asm volatile("" ::: "memory");
             }
+            if (BIG && !NORMS) {  // (the rounds' resident pass without the norms: its ring wraps too)
+#pragma unroll
+                for (int k = 0; k < RING; ++k) zr[k] = tl_ldz<NT>(P.zg, zb + (unsigned)(RoundsSplit<NORMS>::slot(k) * (2 * TB) * 8));
+                asm volatile("" ::: "memory");
+            }
 #pragma unroll
             for (int s = 0; s < (BIG ? WRG : U); ++s) {
                 wreg[s] = *reinterpret_cast<const double2 *>(P.w + tb0 + s * (2 * TB));
@@ -698,12 +706,16 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     const bool jv0 = (int64_t)wdv.J * TB + c0 < P.n, jv1 = (int64_t)wdv.J * TB + c0 + 1 < P.n;
     // where this wave starts its streamed tiles
     const int g0 = GL_TILE_STAGGER ? (int)(((unsigned)(wg * TW + wave) * 5u) & (unsigned)(SLOTS / RS - 1)) : 0;
-    auto ring_load = [&](double2 (&wq)[RS], double2 (&zq)[RS], unsigned base) {
+    auto ring_load = [&](double2 (&wq)[RS], double2 (&zq)[RS], unsigned base, int grp) {
 #pragma unroll
         for (int k = 0; k < RS; ++k) {
-            wq[k] = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(P.w) + base + (unsigned)((g0 * RS + k) * (2 * TB) * 8));
-            zq[k] = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(P.zg) + base + (unsigned)((g0 * RS + k) * (2 * TB) * 8));
+            wq[k] = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(P.w) + base + (unsigned)((grp * RS + k) * (2 * TB) * 8));
+            zq[k] = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(P.zg) + base + (unsigned)((grp * RS + k) * (2 * TB) * 8));
         }
+    };
+    const int nx = BIG ? gd_int(GD_NX) : 0;  // split extra tiles of this workgroup
+    auto xtile_off = [&](int k) -> unsigned {  // byte offset of this lane's first pair of extra tile k
+        return (unsigned)(((int64_t)gd_int(GD_XT + k) * GL_TILE_ELEMS + (lane_s >> 5) * TB + 2 * (lane_s & 31)) * 8);
     };
     // ragged last block column: 0 / 1 factors of my two columns (only the variants with the norms keep them over the pass)
     auto col_valid = [&](int e) { return (RAGGED && has) ? ((int64_t)wdv.J * TB + c0 + e < P.n ? 1.0 : 0.0) : 1.0; };
@@ -746,6 +758,17 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 const char *b = reinterpret_cast<const char *>(P.w) + tile_off(r);
 #pragma unroll 4
                 for (int s2 = 0; s2 < SLOTS; ++s2) {
+                    const double2 v = *reinterpret_cast<const double2 *>(b + s2 * (2 * TB) * 8);
+                    acc = __builtin_fma(v.y, v.y, __builtin_fma(v.x, v.x, acc));
+                }
+            }
+        }
+        if (BIG) {
+#pragma unroll 1
+            for (int k = 0; k < nx; ++k) {  // my four row pairs of every split extra tile
+                const char *b = reinterpret_cast<const char *>(P.w) + xtile_off(k) + (unsigned)(wave * RS * (2 * TB) * 8);
+#pragma unroll
+                for (int s2 = 0; s2 < RS; ++s2) {
                     const double2 v = *reinterpret_cast<const double2 *>(b + s2 * (2 * TB) * 8);
                     acc = __builtin_fma(v.y, v.y, __builtin_fma(v.x, v.x, acc));
                 }
@@ -964,16 +987,18 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             if (my_nr > 0) {
                 const double2 *rows = &s_node[my_rs & 15][0];
                 if (has) {
-                    unsigned zb0 = zb;  // (not loop-invariant for the compiler: it would keep the ring's 64-bit addresses over the iteration, in scratch)
-                    asm volatile("" : "+v"(zb0));
+                    if (NORMS) {  // (without the norms the ring wraps: it was filled by the previous pass, or by the prologue)
+                        unsigned zb0 = zb;  // (not loop-invariant for the compiler: it would keep the ring's 64-bit addresses over the iteration, in scratch)
+                        asm volatile("" : "+v"(zb0));
 #pragma unroll
-                    for (int k = 0; k < RING; ++k) zr[k] = tl_ldz<NT>(P.zg, zb0 + (unsigned)(RoundsSplit<NORMS>::slot(k) * (2 * TB) * 8));
-                    tl_resident_pass_rounds<MASKW, NORMS, NT>(P, wreg, zr, &s_z[wave][0][lane], zb, rows, cv0.x, cv1.x, cv0.y, cv1.y, m0, m1,
+                        for (int k = 0; k < RING; ++k) zr[k] = tl_ldz<NT>(P.zg, zb0 + (unsigned)(RoundsSplit<NORMS>::slot(k) * (2 * TB) * 8));
+                    }
+                    tl_resident_pass_rounds<MASKW, NORMS, NT, !NORMS>(P, wreg, zr, &s_z[wave][0][lane], zb, rows, cv0.x, cv1.x, cv0.y, cv1.y, m0, m1,
                                                               &s_part[wave][0][0], col, lane, wave >= TW / 2, nqy, nw);
                 } else {  // (a column whose first tile here is its diagonal tile)
                     asm volatile("" : "+v"(lane_s));  // (as below)
                     double2 wq[RS], zq[RS];
-                    ring_load(wq, zq, tile_off(0));
+                    ring_load(wq, zq, tile_off(0), g0);
                     tl_stream_pass<NORMS, NT>(P, wq, zq, tile_off(0), tile_off(0), rows, cv0.x, cv1.x, cv0.y, cv1.y, wdv.I == wdv.J, jv0, jv1,
                                               &s_part[wave][0][0], col, lane_s, nqy, nw, g0);
                 }
@@ -988,7 +1013,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 double2 wq[RS], zq[RS];
 #pragma unroll
                 for (int k = 0; k < RS; ++k) wq[k] = zq[k] = double2{0.0, 0.0};
-                if (my_nr > 1) ring_load(wq, zq, tile_off(1));
+                if (my_nr > 1) ring_load(wq, zq, tile_off(1), g0);
 #pragma unroll 1
                 for (int r = 1; r < nrw; ++r) {
                     if (r < my_nr) {
@@ -1004,6 +1029,41 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 }
             }
             if (my_nr > 0) tl_put_cols(col, &s_part[wave][1][0], lane);
+            // Split extra tiles: every wave streams four row pairs (group `wave`) of the same tile -- one ring fill per wave
+            // instead of eight ring turns of one wave, and a CU's share of the stream stays at one tile.  Their row and
+            // column vectors go to s_part[.][3] and [2] and are folded into the records' accumulators at once.
+            if (nx > 0) {
+            asm volatile("" : "+v"(lane_s));
+            double2 xwq[RS], xzq[RS];
+            ring_load(xwq, xzq, xtile_off(0), wave);
+#pragma unroll 1
+            for (int k = 0; k < nx; ++k) {
+                const int xs = gd_int(GD_XS + k), xsi = xs & 255, xsj = (xs >> 8) & 255;
+                const int xJ = gd_int(GD_BLK + xsj);
+                const unsigned tb = xtile_off(k), nxt = k + 1 < nx ? xtile_off(k + 1) : tb;  // (the ring's last requests: the next extra's rows)
+                const int cl = 2 * (lane_s & 31);
+                const double2 xv0 = s_node[xsj][cl], xv1 = s_node[xsj][cl + 1];
+                double colx[2] = {0.0, 0.0};
+                s_part[wave][3][lane] = 0.0;  // (my group fills its own 8 rows)
+                tl_stream_pass<NORMS, NT>(P, xwq, xzq, tb, nxt, &s_node[xsi][0], xv0.x, xv1.x, xv0.y, xv1.y, ((xs >> 16) & 1) != 0,
+                                          (int64_t)xJ * TB + cl < P.n, (int64_t)xJ * TB + cl + 1 < P.n, &s_part[wave][3][0], colx, lane_s, nqy, nw,
+                                          wave, 1);
+                tl_put_cols(colx, &s_part[wave][2][0], lane_s);
+                tl_barrier();
+#pragma unroll
+                for (int j = 0; j < NACQ; ++j) {
+                    const int kb = wave + TW * j;
+                    if (kb < nblk && (kb == xsi || kb == xsj)) {
+#pragma unroll
+                        for (int cs2 = 0; cs2 < TW; ++cs2) {
+                            if (kb == xsj) accp[j] += s_part[cs2][2][lane];
+                            if (kb == xsi) accp[j] += s_part[cs2][3][lane];
+                        }
+                    }
+                }
+                tl_barrier();
+            }
+            }
         }
         if (fcnt > 0) {  // my fringe row pairs (diagonal tile: entries i < j < n only; zg is ZG_OUTSIDE elsewhere: p = 0 there)
             const double c = P.c, omc = P.omc;
@@ -1508,6 +1568,7 @@ static int tile_finish(gl_logdeg *s, std::vector<WaveDesc> &wd, std::vector<WgDe
     if (big) {  // what streams per iteration: w and z of every tile no wave keeps in registers
         int64_t streamed = 0;
         for (const WaveDesc &w : wd) streamed += w.nr - (w.tile >= 0 ? 1 : 0);
+        for (const WgDesc &G : gd) streamed += G.nx;
         // (the hint on z pays from n ~ 6400 on: w + z of the streamed tiles ~ 200 MB, see tl_ld_stream)
         t->nt = streamed * GL_TILE_ELEMS * 16 > ((int64_t)200 << 20);
         if (const char *e = getenv("GRAPHLEARN_AMD_TILE_NT")) t->nt = atoi(e) != 0;
@@ -1529,7 +1590,7 @@ static int tile_finish(gl_logdeg *s, std::vector<WaveDesc> &wd, std::vector<WgDe
 // Column strip t holds block columns 8 t .. 8 t + 7 and the block rows 0 .. its last column; it is cut into groups of
 // R rows, R the smallest number of rounds with which the chip's workgroups cover the lattice (R + 8 <= NBW node
 // blocks per workgroup).  Wave v of a workgroup takes column J = 8 t + v: tiles (I, J), I = I0 .. min(I0 + R - 1, J).
-static int tile_prepare_rounds(gl_logdeg *s) {
+static int tile_prepare_rounds(gl_logdeg *s, bool allow_split = true) {
     auto why = [&](int code) {  // (GRAPHLEARN_AMD_TILE_DEBUG: which condition sent the session to the streaming engine)
         if (getenv("GRAPHLEARN_AMD_TILE_DEBUG")) fprintf(stderr, "[tile] rounds do not apply to n = %lld: condition %d\n", (long long)s->dev.n, code);
         return GL_OK;
@@ -1547,8 +1608,41 @@ static int tile_prepare_rounds(gl_logdeg *s) {
         c += wdt;
     }
     const int nstrips = (int)sc0.size();
+    struct Rect {
+        int t, I0, I1;
+    };
+    std::vector<Rect> rects;
+    std::vector<std::pair<int, int>> extras;  // split extra tiles (I, J)
+    // "Split" decomposition, for lattices just past the register files: ONE block row per rectangle (every wave's tile is
+    // resident), and the rectangles the chip has no workgroup for -- the ones with the fewest tiles, along the diagonal --
+    // are dissolved: their tiles become split extras, streamed by all eight waves of a workgroup together (k_tile).  With
+    // whole streamed rounds instead, the few workgroups that get a second block row stream eight tiles each and the chip
+    // waits for them: 21 us per iteration at n = 4160 against 7 at n = 4096.
+    if (allow_split && !getenv("GRAPHLEARN_AMD_TILE_NO_SPLIT")) {
+        std::vector<std::pair<int, Rect>> all;  // (tiles, rectangle)
+        for (int t = 0; t < nstrips; ++t)
+            for (int I = 0; I < sc1[(size_t)t]; ++I) all.push_back({sc1[(size_t)t] - std::max(sc0[(size_t)t], I), Rect{t, I, I + 1}});
+        const int over = (int)all.size() - ncu;
+        if (over > 0 && ncu >= nb) {
+            std::stable_sort(all.begin(), all.end(), [](const std::pair<int, Rect> &a, const std::pair<int, Rect> &b) { return a.first < b.first; });
+            int64_t nex = 0;
+            for (int q = 0; q < over; ++q) nex += all[(size_t)q].first;
+            for (size_t q = (size_t)over; q < all.size(); ++q)  // (the diagonal tiles of the rectangles that stay are split too)
+                nex += all[q].second.I0 >= sc0[(size_t)all[q].second.t] ? 1 : 0;
+            if (nex <= (int64_t)XMAX * ncu * 3 / 4) {  // (a quarter to spare: the node-block lists do not always allow the densest packing)
+                for (int q = 0; q < over; ++q) {
+                    const Rect &rc = all[(size_t)q].second;
+                    for (int J = std::max(sc0[(size_t)rc.t], rc.I0); J < sc1[(size_t)rc.t]; ++J) extras.push_back({rc.I0, J});
+                }
+                for (size_t q = (size_t)over; q < all.size(); ++q) rects.push_back(all[q].second);
+                std::sort(rects.begin(), rects.end(), [](const Rect &a, const Rect &b) { return a.t != b.t ? a.t < b.t : a.I0 < b.I0; });
+            }
+        }
+    }
+    const bool split = !rects.empty();
     int R = 0, NWG = 0;
-    for (int r = 1; r <= NBW - TW && r <= 8; ++r) {
+    if (split) R = 1, NWG = (int)rects.size();
+    for (int r = 1; rects.empty() && r <= NBW - TW && r <= 8; ++r) {
         int cnt = 0;
         for (int t = 0; t < nstrips; ++t) cnt += (sc1[(size_t)t] + r - 1) / r;
         if (cnt <= ncu) {
@@ -1561,7 +1655,7 @@ static int tile_prepare_rounds(gl_logdeg *s) {
     // tiles in registers, fewer streamed)
     std::vector<int> grp((size_t)nstrips);
     for (int t = 0; t < nstrips; ++t) grp[(size_t)t] = (sc1[(size_t)t] + R - 1) / R;
-    if (!getenv("GRAPHLEARN_AMD_TILE_NO_SPREAD"))
+    if (rects.empty() && !getenv("GRAPHLEARN_AMD_TILE_NO_SPREAD"))
         for (; NWG < ncu; ++NWG) {
             int best = -1;
             double most = 1.0;
@@ -1582,11 +1676,16 @@ static int tile_prepare_rounds(gl_logdeg *s) {
         w.fB = -1;
     }
     for (WgDesc &G : gd) memset(&G, 0, sizeof G);
-    int g = 0;
-    for (int t = 0; t < nstrips; ++t) {
-        const int h = sc1[(size_t)t], ng = grp[(size_t)t];
-        for (int q = 0; q < ng; ++q, ++g) {
-            const int I0 = (int)((int64_t)q * h / ng), I1 = (int)((int64_t)(q + 1) * h / ng);  // block rows [I0, I1)
+    if (rects.empty())  // whole rounds: strip t cut into grp[t] groups of block rows
+        for (int t = 0; t < nstrips; ++t) {
+            const int h = sc1[(size_t)t], ng = grp[(size_t)t];
+            for (int q = 0; q < ng; ++q) rects.push_back(Rect{t, (int)((int64_t)q * h / ng), (int)((int64_t)(q + 1) * h / ng)});
+        }
+    if ((int)rects.size() > NWG) return why(8);
+    {
+        for (int g = 0; g < (int)rects.size(); ++g) {
+            const int t = rects[(size_t)g].t, I0 = rects[(size_t)g].I0, I1 = rects[(size_t)g].I1;  // block rows [I0, I1)
+            {
             WgDesc &G = gd[(size_t)g];
             auto slot_of = [&](int B) -> int {
                 for (int k = 0; k < G.nblk; ++k)
@@ -1598,6 +1697,10 @@ static int tile_prepare_rounds(gl_logdeg *s) {
             for (int v = 0; v < TW; ++v) {
                 const int J = sc0[(size_t)t] + v;
                 if (J >= sc1[(size_t)t] || J < I0) continue;  // (below the diagonal: nothing)
+                if (split && J == I0) {  // a diagonal tile is never one wave's streamed tile here (eight ring turns: 15 us)
+                    extras.push_back({I0, J});
+                    continue;
+                }
                 WaveDesc &w = wd[(size_t)(g * TW + v)];
                 w.I = I0;
                 w.J = J;
@@ -1616,7 +1719,34 @@ static int tile_prepare_rounds(gl_logdeg *s) {
                     G.nrnd = std::max(G.nrnd, r + 1);
                 }
             }
+            }
         }
+    }
+    // split extras: each goes to the workgroup with the fewest so far that has room for its node blocks (the ones that know
+    // both blocks already first)
+    for (const std::pair<int, int> &ex : extras) {
+        int best = -1, best_cost = 1 << 30;
+        for (int q = 0; q < (int)rects.size(); ++q) {
+            const WgDesc &G = gd[(size_t)q];
+            if (G.nx >= XMAX) continue;
+            int add = 2 - (ex.first == ex.second ? 1 : 0);
+            for (int k = 0; k < G.nblk; ++k) add -= (G.blk[k] == ex.first) + (G.blk[k] == ex.second && ex.first != ex.second);
+            if (G.nblk + add > NBW) continue;
+            const int cost = G.nx * 4 + add;
+            if (cost < best_cost) best_cost = cost, best = q;
+        }
+        if (best < 0) return tile_prepare_rounds(s, false);  // (no room in the block lists: whole rounds instead)
+        WgDesc &G = gd[(size_t)best];
+        auto slot_of = [&](int B) -> int {
+            for (int k = 0; k < G.nblk; ++k)
+                if (G.blk[k] == B) return k;
+            G.blk[G.nblk] = B;
+            return G.nblk++;
+        };
+        const int si = slot_of(ex.first), sj = slot_of(ex.second);
+        G.xt[G.nx] = (int)gl_tile_id(ex.first, ex.second, nb);
+        G.xs[G.nx] = si | (sj << 8) | (ex.first == ex.second ? 1 << 16 : 0);
+        ++G.nx;
     }
     for (int q = 0; q < NWG; ++q) {
         gd[(size_t)q].own = q < nb ? q : -1;
