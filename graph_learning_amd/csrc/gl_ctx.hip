@@ -131,7 +131,12 @@ GL_API int gl_ctx_timer_stop(gl_ctx *ctx, double *elapsed_ms) {
     if (!ctx || !elapsed_ms) return GL_E_INVALID;
     GL_HIP(ctx, hipSetDevice(ctx->device));
     GL_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-    GL_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    // (polled, not slept on: hipEventSynchronize wakes the caller several microseconds after the event has completed, and
+    //  the callers of this timer bracket calls of a few hundred microseconds with the wall clock too)
+    hipError_t q;
+    while ((q = hipEventQuery(ctx->ev1)) == hipErrorNotReady) {
+    }
+    GL_HIP(ctx, q);
     float ms = 0.f;
     GL_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *elapsed_ms = (double)ms;
