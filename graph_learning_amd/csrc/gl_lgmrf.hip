@@ -1845,10 +1845,223 @@ __global__ __launch_bounds__(1024) void k_gj_lds(double *__restrict__ A, int n) 
         }
 }
 
+// ---- blocked Gauss-Jordan (n > 128): the same in-place inversion in steps of BG = 64 pivots, two launches per step
+// instead of two per pivot (n = 2048: 65 launches instead of 4096).  Step k, K = [64 k, 64 k + 64), P_k = inv(A_KK):
+//   k_bgj_panel  R_j = P_k A_Kj -> A_Kj,  C_i = A_iK (old),  A_iK = -C_i P_k              (2 nb workgroups)
+//   k_bgj_update A_ij += (-C_i) R_j for i, j != k;  A_KK = P_k;  the workgroup of tile (k + 1, k + 1) goes on to invert
+//                its result in registers (unblocked elimination): P_{k+1}, ready when the other tiles are  (nb^2 workgroups)
+// (P_0 by k_bgj_pivot0.)  The 64 x 64 x 64 products run on v_mfma_f64_16x16x4_f64: at the same peak as the vector unit on
+// this part it takes one operand pair per 16 multiply-adds per lane where a 4 x 4 register block reads eight -- the vector
+// form of these kernels was bound by LDS reads (39 us per update; profiles/r03_lgmrf_inverse.md).  No pivoting (the matrices
+// are symmetric positive definite); every sum in a fixed order: bit-stable run to run.  The rounding differs from the
+// unblocked elimination's (other association, the pivot's reciprocal instead of quotients), as that one's does from LAPACK's.
+constexpr int BG = 64, BGS = BG + 2;  // block size; LDS row stride in doubles (operand reads at most 2-way bank conflicts)
+typedef double bgj_d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double bgj_ld(const double *A, int64_t n, int64_t i, int64_t j) {  // rows / columns >= n: identity
+    return (i < n && j < n) ? A[i * n + j] : (i == j ? 1.0 : 0.0);
+}
+// acc (16 x 16: lane l, element e -> row (l >> 4) + 4 e, column l & 15) += a (16 x 4: lane l -> [l & 15][l >> 4]) b (4 x 16:
+// lane l -> [l >> 4][l & 15])
+__device__ __forceinline__ bgj_d4 bgj_mfma(double a, double b, bgj_d4 acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+#else
+    return acc;
+#endif
+}
+// 1 / x as the compiler's division forms it before its final correction: v_rcp_f64 and two Newton steps (exact for x = 1,
+// the pivots of the identity padding); <= 1 ulp
+__device__ __forceinline__ double bgj_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x), e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+// A 64 x 64 block inverted in the REGISTERS of one workgroup of NW waves: lane = row, wave w holds columns CW w .. CW w + CW - 1
+// of its row (CW = 64 / NW).  Per pivot k the pivot row reaches the lanes through v_readlane (every wave broadcasts its own
+// columns of row k from lane k), the pivot column through LDS (64 doubles, double-buffered: one workgroup barrier per pivot).
+// The kernel is bound by instruction issue (64 dependent pivots), so the special cases of k_gj_pivot / k_gj_eliminate are
+// folded into ONE multiply and ONE multiply-add per entry:  a_ij <- t_i a_kj + m_i a_ij  with  t_i = -a_ik / piv, m_i = 1
+// (rows i != k),  t_k = 1 / piv, m_k = 0  (the pivot row: a_kj / piv),  after column k was replaced by the unit vector e_k
+// (its entries become -a_ik / piv and 1 / piv).
+template <int NW>
+__device__ __forceinline__ void bgj_invert_regs(double (&a)[BG / NW], double (*s_col)[BG], int lane, int wave) {
+    constexpr int CW = BG / NW;
+    for (int kw = 0; kw < NW; ++kw) {
+#pragma unroll
+        for (int kc = 0; kc < CW; ++kc) {  // (unrolled: the pivot column's register is a compile-time choice)
+            const int k = kw * CW + kc;
+            if (wave == kw) {
+                s_col[kc & 1][lane] = a[kc];
+                a[kc] = (lane == k) ? 1.0 : 0.0;
+            }
+            __syncthreads();
+            const double rpiv = bgj_rcp(s_col[kc & 1][k]), pc = s_col[kc & 1][lane];
+            const bool prow = lane == k;
+            const double m = prow ? 0.0 : 1.0, t = (prow ? 1.0 : -pc) * rpiv;
+#pragma unroll
+            for (int c = 0; c < CW; ++c) a[c] = __builtin_fma(t, lg_bcast(a[c], k), a[c] * m);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_bgj_pivot0(const double *__restrict__ A, int64_t n, double *__restrict__ P) {
+    __shared__ double s_col[2][BG];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = bgj_ld(A, n, lane, 16 * wave + c);
+    bgj_invert_regs<4>(a, s_col, lane, wave);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) P[lane * BG + 16 * wave + c] = a[c];
+}
+// blockIdx.y = 0: R_b = P A_Kb -> Rbuf and A_Kb;  blockIdx.y = 1: C_b = A_bK (old) -> Cbuf, A_bK = -C_b P.  16 waves, one
+// 16 x 16 tile of the product each.
+__global__ __launch_bounds__(1024) void k_bgj_panel(double *__restrict__ A, int64_t n, int64_t kb, const double *__restrict__ P,
+                                                    double *__restrict__ Rbuf, double *__restrict__ Cbuf) {
+    __shared__ double sp[BG][BGS], sx[BG][BGS];  // P; the other operand (A_Kb or A_bK), both row-major
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool row_part = blockIdx.y == 0;
+    const int64_t b = blockIdx.x, k0 = kb * BG, b0 = b * BG, ld = (int64_t)gridDim.x * BG;
+    if (b == kb) return;  // (A_KK = P: the update kernel)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 1024 * q, i = e / BG, j = e % BG;
+        const double x = row_part ? bgj_ld(A, n, k0 + i, b0 + j) : bgj_ld(A, n, b0 + i, k0 + j);
+        sp[i][j] = P[e];
+        sx[i][j] = x;
+        if (!row_part) Cbuf[b0 * BG + e] = x;                          // C_b: rows b0 .. b0 + 63, 64 columns, row-major
+    }
+    __syncthreads();
+    const int r = lane & 15, q4 = lane >> 4, i0 = 16 * (wave >> 2), j0 = 16 * (wave & 3);
+    const double(*sa)[BGS] = row_part ? sp : sx, (*sb)[BGS] = row_part ? sx : sp;
+    bgj_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int ks = 0; ks < BG / 4; ++ks) acc = bgj_mfma(sa[i0 + r][4 * ks + q4], sb[4 * ks + q4][j0 + r], acc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int64_t i = i0 + q4 + 4 * e, j = j0 + r;
+        if (row_part) {
+            Rbuf[i * ld + b0 + j] = acc[e];  // R: 64 x (nb 64), row-major
+            if (k0 + i < n && b0 + j < n) A[(k0 + i) * n + b0 + j] = acc[e];
+        } else if (b0 + i < n && k0 + j < n) {
+            A[(b0 + i) * n + k0 + j] = -acc[e];
+        }
+    }
+}
+// one workgroup per 64 x 64 tile, one wave per 32 x 32 quadrant: the tile's old values are the accumulators' start.  The 64
+// pivots of the step are taken in two halves of 32 through 34 KB of LDS (the second half is fetched into registers while the
+// first is multiplied), so that four workgroups share a CU and all nb^2 are resident at once: with the whole 64 in LDS (two per
+// CU, two rounds) the kernel waited on its loads for 27 us where the products need 6.4.  Block (0, 0) -- the first to be
+// scheduled -- is tile (k + 1, k + 1), which then inverts its result for the next step.
+constexpr int BGH = BG / 2;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_bgj_update(double *__restrict__ A, int64_t n, int64_t kb, const double *__restrict__ P,
+                                                    double *__restrict__ Pnext, const double *__restrict__ Rbuf,
+                                                    const double *__restrict__ Cbuf, int nbk) {
+    constexpr int SCS = BGH + 2;                               // row stride of the C half
+    __shared__ double smem[BG * SCS + BGH * BGS], s_col[2][BG];
+    static_assert(BG * SCS + BGH * BGS >= BG * BGS, "the next pivot block is staged in the same LDS");
+    double(*sc)[SCS] = reinterpret_cast<double(*)[SCS]>(smem);            // -C_i [i][l - 32 h]
+    double(*sr)[BGS] = reinterpret_cast<double(*)[BGS]>(smem + BG * SCS);  // R_j [l - 32 h][j]
+    const int64_t ib = (blockIdx.y + kb + 1) % nbk, jb = (blockIdx.x + kb + 1) % nbk, k0 = kb * BG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (ib == kb || jb == kb) {
+        if (ib == kb && jb == kb)
+            for (int e = tid; e < BG * BG; e += 256) {
+                const int64_t i = k0 + e / BG, j = k0 + e % BG;
+                if (i < n && j < n) A[i * n + j] = P[e];
+            }
+        return;
+    }
+    const double *Ci = Cbuf + ib * BG * BG, *Rj = Rbuf + jb * BG;
+    const int64_t ldr = (int64_t)nbk * BG;
+    double cv[8], rv[8];
+    auto fetch = [&](int h) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + 256 * q;
+            cv[q] = Ci[(e / BGH) * BG + BGH * h + e % BGH];
+            rv[q] = Rj[(int64_t)(BGH * h + e / BG) * ldr + e % BG];
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + 256 * q;
+            sc[e / BGH][e % BGH] = -cv[q];
+            sr[e / BG][e % BG] = rv[q];
+        }
+    };
+    fetch(0);
+    const int r = lane & 15, q4 = lane >> 4, i0 = 32 * (wave >> 1), j0 = 32 * (wave & 1);
+    bgj_d4 acc[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t i = ib * BG + i0 + 16 * u + q4 + 4 * e, j = jb * BG + j0 + 16 * v + r;
+                acc[u][v][e] = (i < n && j < n) ? A[i * n + j] : 0.0;
+            }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h) __syncthreads();  // (the first half has been read)
+        stage();
+        __syncthreads();
+        if (h == 0) fetch(1);
+#pragma unroll 2
+        for (int ks = 0; ks < BGH / 4; ++ks) {
+            const int l = 4 * ks + q4;
+            const double a0 = sc[i0 + r][l], a1 = sc[i0 + 16 + r][l], b0 = sr[l][j0 + r], b1 = sr[l][j0 + 16 + r];
+            acc[0][0] = bgj_mfma(a0, b0, acc[0][0]);
+            acc[0][1] = bgj_mfma(a0, b1, acc[0][1]);
+            acc[1][0] = bgj_mfma(a1, b0, acc[1][0]);
+            acc[1][1] = bgj_mfma(a1, b1, acc[1][1]);
+        }
+    }
+    const bool next_pivot = blockIdx.x == 0 && blockIdx.y == 0 && kb + 1 < nbk;  // tile (k + 1, k + 1)
+    double(*st)[BGS] = reinterpret_cast<double(*)[BGS]>(smem);
+    if (next_pivot) __syncthreads();                                            // (the operands are about to be overwritten)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ti = i0 + 16 * u + q4 + 4 * e, tj = j0 + 16 * v + r;
+                const int64_t i = ib * BG + ti, j = jb * BG + tj;
+                if (i < n && j < n) A[i * n + j] = acc[u][v][e];
+                if (next_pivot) st[ti][tj] = (i < n && j < n) ? acc[u][v][e] : (ti == tj ? 1.0 : 0.0);
+            }
+    if (!next_pivot) return;
+    __builtin_amdgcn_s_setprio(3);  // (64 dependent pivots on the step's critical path, among three other workgroups' MFMAs)
+    __syncthreads();
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = st[lane][16 * wave + c];
+    bgj_invert_regs<4>(a, s_col, lane, wave);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) Pnext[lane * BG + 16 * wave + c] = a[c];
+}
+
 // pivrow: 2 n doubles of scratch (scaled pivot row, then the pivot column)
 int invert_spd_inplace(gl_ctx *ctx, double *A, int64_t n, double *pivrow) {
     if (n <= GJ_LDS_MAXN && !getenv("GRAPHLEARN_AMD_LGMRF_GJ_LAUNCH")) {
         k_gj_lds<<<1, 1024, 0, ctx->stream>>>(A, (int)n);
+        GL_HIP(ctx, hipGetLastError());
+        return GL_OK;
+    }
+    if (!getenv("GRAPHLEARN_AMD_LGMRF_GJ_LAUNCH")) {  // blocked
+        const int nbk = (int)((n + BG - 1) / BG);
+        double *scr = nullptr;
+        GL_TRY(gl_ctx_scratch(ctx, ((size_t)2 * nbk * BG * BG + 2 * BG * BG) * 8, (void **)&scr));
+        double *P[2] = {scr, scr + BG * BG}, *Rbuf = scr + 2 * BG * BG, *Cbuf = Rbuf + (size_t)nbk * BG * BG;
+        k_bgj_pivot0<<<1, 256, 0, ctx->stream>>>(A, n, P[0]);
+        for (int kb = 0; kb < nbk; ++kb) {
+            k_bgj_panel<<<dim3((unsigned)nbk, 2), 1024, 0, ctx->stream>>>(A, n, kb, P[kb & 1], Rbuf, Cbuf);
+            k_bgj_update<<<dim3((unsigned)nbk, (unsigned)nbk), 256, 0, ctx->stream>>>(A, n, kb, P[kb & 1], P[(kb + 1) & 1], Rbuf,
+                                                                                      Cbuf, nbk);
+        }
         GL_HIP(ctx, hipGetLastError());
         return GL_OK;
     }

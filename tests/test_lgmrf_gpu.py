@@ -209,6 +209,22 @@ def test_qp_solver_mid_sizes(n):
             np.testing.assert_allclose(z, zr, rtol=0, atol=1e-10)
 
 
+@pytest.mark.parametrize("n", [200, 300, 1000])
+def test_qp_solver_blocked_inverse_sizes(n):
+    """n > 128: (I + rho M)^-1 by the BLOCKED Gauss-Jordan elimination (k_bgj_*: 64-pivot steps, f64 MFMA products, the
+    next pivot block inverted by the update kernel), blocks padded by the identity (n = 200, 300, 1000 are not multiples
+    of 64): against the oracle (numpy.linalg.inv + the same ADMM steps), and bit-identical run to run."""
+    rng = np.random.default_rng(n)
+    a = rng.standard_normal((n, n + 5))
+    q, p = a @ a.T / n + 0.05 * np.eye(n), rng.standard_normal(n)
+    z, iters = nonnegative_qp_solver(q, p, step=0.1, tol=0.0, max_iter=12, return_iters=True)
+    zr, ref_iters = olg.nonneg_qp_admm(q, p, step=0.1, tol=0.0, max_iter=12, return_iters=True)
+    assert iters == ref_iters == 12
+    np.testing.assert_allclose(z, zr, rtol=0, atol=1e-10)
+    z2 = nonnegative_qp_solver(q, p, step=0.1, tol=0.0, max_iter=12)
+    assert np.array_equal(z, z2)
+
+
 # ------------------------------------------------------------------ BASELINE configs[2] shape
 LARGE_FORMS = ("auto", "tagged", "wide", "resident", "launch")
 
