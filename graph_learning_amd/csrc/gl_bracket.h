@@ -9,19 +9,28 @@
 // mu_k = lambda_max(A_k) obeys mu_k = sqrt(t_k mu_{k+1}), and a trace-1 PSD matrix has tr A^2 <= mu <= sqrt(tr A^2).
 // So log mu_0 = sum_k 2^-(k+1) log t_k + 2^-m log mu_m with mu_m in [t_m, sqrt t_m]: the width of the bracket
 // is 2^-(m+1) |log t_m| <= 2^-(m+1) log B in the logarithm.  Stops early once A_k is rank one (t_k -> 1).
+// The same in stages (the bracket halves its logarithmic width with every squaring, and most decisions need a few):
+// sm_bracket_begin, then sm_bracket_advance (up to `steps` more squarings) and sm_bracket_bounds (reads A only) as often
+// as needed.
+struct SmBracket {
+    double tr, L, wgt;
+    int k;        // squarings done
+    bool done;    // rank one reached (or the 34 squarings of the full bracket): no further step changes anything
+};
 template <int EPL>  // matrix entries per lane: 4 (B <= 16) or 16 (B <= 32)
-__device__ __forceinline__ void sm_lambda_bracket(double *A, int B, int lane, double &lo, double &hi) {
+__device__ __forceinline__ void sm_bracket_begin(double *A, int B, int lane, SmBracket &S) {
     const int nn = B * B;
     double tr = 0.0;
     for (int i = lane; i < B; i += 64) tr += A[i * B + i];
     tr = wave_sum(tr);
-    if (!(tr > 0.0)) {
-        lo = hi = 0.0;
-        return;
-    }
+    S.tr = tr, S.L = 0.0, S.wgt = 0.5, S.k = 0, S.done = !(tr > 0.0);
+    if (S.done) return;
     for (int idx = lane; idx < nn; idx += 64) A[idx] = A[idx] / tr;
-    double L = 0.0, wgt = 0.5;
-    for (int k = 0; k < 34; ++k) {
+}
+template <int EPL>
+__device__ __forceinline__ void sm_bracket_advance(double *A, int B, int lane, SmBracket &S, int steps) {
+    const int nn = B * B;
+    for (int q = 0; q < steps && !S.done; ++q) {
         double sv[EPL], dsum = 0.0;
 #pragma unroll
         for (int r = 0; r < EPL; ++r) {
@@ -39,15 +48,30 @@ __device__ __forceinline__ void sm_lambda_bracket(double *A, int B, int lane, do
 #pragma unroll
         for (int r = 0; r < EPL; ++r)
             if (lane + 64 * r < nn) A[lane + 64 * r] = sv[r] / t;
-        L += wgt * log(t);
-        wgt *= 0.5;
-        if (t > 1.0 - 1e-13) break;
+        S.L += S.wgt * log(t);
+        S.wgt *= 0.5;
+        ++S.k;
+        if (t > 1.0 - 1e-13 || S.k >= 34) S.done = true;
     }
+}
+template <int EPL>
+__device__ __forceinline__ void sm_bracket_bounds(const double *A, int B, int lane, const SmBracket &S, double &lo, double &hi) {
+    if (!(S.tr > 0.0)) {
+        lo = hi = 0.0;
+        return;
+    }
+    const int nn = B * B;
     double fro = 0.0;
     for (int idx = lane; idx < nn; idx += 64) fro += A[idx] * A[idx];
     const double tm = fmin(wave_sum(fro), 1.0);  // tr A_m^2 (A_m symmetric)
     const double lt = log(tm);                   // <= 0
-    lo = tr * exp(L + 2.0 * wgt * lt) * (1.0 - 1e-12);
-    hi = tr * exp(L + wgt * lt) * (1.0 + 1e-12);
+    lo = S.tr * exp(S.L + 2.0 * S.wgt * lt) * (1.0 - 1e-12);
+    hi = S.tr * exp(S.L + S.wgt * lt) * (1.0 + 1e-12);
 }
-
+template <int EPL>
+__device__ __forceinline__ void sm_lambda_bracket(double *A, int B, int lane, double &lo, double &hi) {
+    SmBracket S;
+    sm_bracket_begin<EPL>(A, B, lane, S);
+    sm_bracket_advance<EPL>(A, B, lane, S, 34);
+    sm_bracket_bounds<EPL>(A, B, lane, S, lo, hi);
+}

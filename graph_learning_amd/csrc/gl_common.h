@@ -31,6 +31,9 @@ struct gl_ctx {
     // device scratch for the batched entry points (grown on demand, kept: no hipMalloc / hipFree per call)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
+    // the batched solver's stand-in session for the tile engine (gl_logdeg.hip: BatchCruise), kept for the next call
+    void *batch_cruise = nullptr;
+    void (*batch_cruise_free)(void *) = nullptr;
 };
 
 // At least `bytes` of device scratch, valid until the next gl_ctx_scratch call on this context (the stream is in

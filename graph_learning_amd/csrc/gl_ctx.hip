@@ -79,6 +79,7 @@ GL_API int gl_ctx_destroy(gl_ctx *ctx) {
     if (!ctx) return GL_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->batch_cruise && ctx->batch_cruise_free) ctx->batch_cruise_free(ctx->batch_cruise);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

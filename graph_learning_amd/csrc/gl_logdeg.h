@@ -86,6 +86,8 @@ int gl_resident_finish(gl_logdeg *s, int64_t *iters_done, bool *stopped, bool *n
 // gl_tile.hip
 constexpr int GL_TILE_MIN_CALL = 4;  // shortest call (iterations) the tile engine takes; shorter ones stream
 int gl_tile_prepare(gl_logdeg *s);
+int gl_tile_prepare_batch(gl_logdeg *s, int B);  // s stands for B graphs of dev.n nodes (gl_logdeg.hip: the batch's cruise)
+int gl_tile_batch_make_zg(gl_logdeg *s, const LogdegDev *devs_dev, int B);
 void gl_tile_free(gl_logdeg *s);
 int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int final_parity);
 bool gl_tile_writes_final_parity(const gl_logdeg *s);

@@ -88,19 +88,22 @@ __device__ __forceinline__ EdgeStep edge_step_at(int64_t p, int64_t pend) {
 // addresses and are fetched with SCALAR loads (s_load, counted by lgkmcnt).  Vector loads for
 // them would sit in the in-order vector-memory queue behind the prefetch just issued by the
 // previous slot, and waiting for them would cost a full memory round trip per slot.
+// par >= 0 (the batched launches): the parity of the iteration index comes with the launch, so the first loads do not wait
+// for a round trip to the counter; the done flag is looked at once they are on their way, before anything is stored.
 template <bool INIT, int ABL = 0>
 __device__ __forceinline__ void edge_body(const LogdegDev &P, const double *__restrict__ dvar,
-                                          const double *__restrict__ pbar, const int b) {
-    if (!INIT && P.ctr[0] != 0) return;  // converged earlier: leave everything as is
-    const long long it = INIT ? 0 : P.ctr[2];
+                                          const double *__restrict__ pbar, const int b, const int par = -1) {
+    if (!INIT && par < 0 && P.ctr[0] != 0) return;  // converged earlier: leave everything as is
+    const long long it = (INIT || par >= 0) ? 0 : P.ctr[2];
 
     const int lane = threadIdx.x;
     const int half = lane >> 5;
     const int c0 = 2 * (lane & 31);
-    if (!INIT && b == 0 && lane == 0) P.ctr[3] = it;  // hand the index to the node pass
+    if (!INIT && par < 0 && b == 0 && lane == 0) P.ctr[3] = it;  // hand the index to the node pass
 
-    const double *__restrict__ wsrc = P.w[it & 1];
-    double *__restrict__ wdst = P.w[(it + 1) & 1];
+    const int pin = par >= 0 ? par : (int)(it & 1);
+    const double *__restrict__ wsrc = P.w[pin];
+    double *__restrict__ wdst = P.w[pin ^ 1];
     const double c = P.c, g = P.gamma, g2 = P.g2;
 
     int64_t p = ((int64_t)b * P.npairs) / P.G;
@@ -235,6 +238,10 @@ __device__ __forceinline__ void edge_body(const LogdegDev &P, const double *__re
         fetch_tile(cur.t, I, J, dj, pj);
         full = (I < J) && ((int64_t)J * TB + TB <= P.n);
     }
+    if (!INIT && par >= 0) {
+        if (P.ctr[0] != 0) return;                  // (a halted batch: nothing has been stored yet)
+        if (b == 0 && lane == 0) P.ctr[3] = P.ctr[2];  // the index for the node pass (which moves ctr[2] itself)
+    }
 
     while (cur.cnt > 0) {
         const EdgeStep nxt = edge_step_at(p + cur.cnt, pend);
@@ -330,9 +337,9 @@ __global__ __launch_bounds__(64, GL_EDGE_WAVES_PER_SIMD) void k_edge(LogdegDev P
 }
 // the same pass for a batch of problems of one size in ONE launch (blockIdx.y = problem): small
 // graphs then run side by side instead of one latency-bound launch after the other
-__global__ __launch_bounds__(64, GL_EDGE_WAVES_PER_SIMD) void k_edge_batch(const LogdegDev *__restrict__ devs) {
+__global__ __launch_bounds__(64, GL_EDGE_WAVES_PER_SIMD) void k_edge_batch(const LogdegDev *__restrict__ devs, const int par) {
     const LogdegDev P = devs[blockIdx.y];
-    edge_body<false, 0>(P, P.dvar, P.pbar, (int)blockIdx.x);
+    edge_body<false, 0>(P, P.dvar, P.pbar, (int)blockIdx.x, par);
 }
 
 // ---------------------------------------------------------------------------
@@ -344,19 +351,21 @@ __global__ __launch_bounds__(64, GL_EDGE_WAVES_PER_SIMD) void k_edge_batch(const
 // buffers keep the iterate the rule refers to intact.
 constexpr int NODE_WAVES = 16;
 
+// par >= 0 (the batched launches): as in edge_body; the single-graph rule is not evaluated (the batch has its own), and
+// false comes back when the batch was halted (nothing written).
 template <bool INIT>
-__device__ __forceinline__ void node_body(const LogdegDev &P, const int64_t B) {
+__device__ __forceinline__ bool node_body(const LogdegDev &P, const int64_t B, const int par = -1) {
     __shared__ double s_sum[2][NODE_WAVES][TB];
     __shared__ double s_red[2][NODE_WAVES];
     __shared__ int s_stop;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     long long it = 0;
-    if (!INIT) {
-        if (P.ctr[0] != 0) return;
+    if (!INIT && par < 0) {
+        if (P.ctr[0] != 0) return false;
         it = P.ctr[3];
     }
-    const bool chk = !INIT && it >= 2;  // rule of iteration it-1 >= 1 (the reference skips i == 0)
+    const bool chk = !INIT && par < 0 && it >= 2;  // rule of iteration it-1 >= 1 (the reference skips i == 0)
     const int64_t i = B * TB + lane;
 
     // loads first: stopping-rule partials, my node's state, then the slabs
@@ -409,6 +418,10 @@ __device__ __forceinline__ void node_body(const LogdegDev &P, const int64_t B) {
         }
     }
     if (tid == 0) s_stop = 0;
+    if (!INIT && par >= 0) {  // (the loads above are on their way; every thread reads the same two words)
+        if (P.ctr[0] != 0) return false;
+        it = P.ctr[3];  // (handed over by the edge pass)
+    }
     __syncthreads();
     if (chk && wave == 1) {
         b0 = wave_sum(b0);
@@ -431,7 +444,7 @@ __device__ __forceinline__ void node_body(const LogdegDev &P, const int64_t B) {
         }
     }
     if (chk) __syncthreads();
-    if (s_stop) return;
+    if (s_stop) return false;
 
     if (wave == 0) {
         sp = 0;
@@ -484,6 +497,7 @@ __device__ __forceinline__ void node_body(const LogdegDev &P, const int64_t B) {
             }
         }
     }
+    return true;
 }
 
 template <bool INIT>
@@ -502,7 +516,7 @@ struct BatchState {
     int decide_here;      // 1: an iterate the screen cannot rule out is judged on the device (k_batch_dots .. k_batch_brackets
                           // behind the node pass) instead of halting for the host
     int want_brackets;    // ... set by the screen for the kernels behind it, cleared by the last of them
-    int pad[1];
+    unsigned gram_blocks; // workgroups of the current k_batch_gram that have finished
     double diag[4];       // scratch of the deciding workgroup: max and trace of the four diagonals are formed from LDS
 };
 // The node pass of a batch (blockIdx.y = problem).  With `st`: the LAST workgroup of the launch to finish -- whichever it
@@ -512,12 +526,12 @@ struct BatchState {
 // trace], so rel_p^2 >= max_a ||dW_a||^2 / sum_a ||W_a||^2 (and likewise rel_d): above tol^2 the rule cannot hold and the
 // batch goes on; otherwise every problem's done flag is raised, the launches queued behind this one fall through, and the
 // host forms the exact spectral norms for exactly this iterate.
-__global__ __launch_bounds__(NODE_WAVES * 64) void k_node_batch(const LogdegDev *__restrict__ devs, BatchState *st, int nprob, double t2) {
+__global__ __launch_bounds__(NODE_WAVES * 64) void k_node_batch(const LogdegDev *__restrict__ devs, BatchState *st, int nprob, double t2,
+                                                                const int par) {
     __shared__ int s_last;
     __shared__ double s_mx[4][NODE_WAVES], s_tr[4][NODE_WAVES];
     const LogdegDev P = devs[blockIdx.y];
-    if (st && P.ctr[0] != 0) return;  // halted: nothing moves (every problem carries the same flag)
-    node_body<false>(P, (int64_t)blockIdx.x);
+    if (!node_body<false>(P, (int64_t)blockIdx.x, par)) return;  // halted: nothing moves (every problem carries the same flag)
     if (!st) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Hand-off of the norm partials inside the launch (CDNA4 guide, Guideline 16: sc1 stores, the storing lane drains, ONE
@@ -530,11 +544,10 @@ __global__ __launch_bounds__(NODE_WAVES * 64) void k_node_batch(const LogdegDev 
     }
     __syncthreads();
     if (!s_last) return;
-    const long long it = devs[0].ctr[3];  // the iteration this pass completed (handed over by the edge pass)
     double mx[4] = {0, 0, 0, 0}, tr[4] = {0, 0, 0, 0};
     for (int a = wave; a < nprob; a += NODE_WAVES) {
         const LogdegDev Q = devs[a];
-        const double *bn = Q.bnorm + (it & 1) * 4 * Q.nb;
+        const double *bn = Q.bnorm + par * 4 * Q.nb;  // (the iteration this pass completed has the launch's parity)
         double b[4] = {0, 0, 0, 0};
         for (int64_t bb = lane; bb < Q.nb; bb += 64)
 #pragma unroll
@@ -843,6 +856,191 @@ __global__ __launch_bounds__(256) void k_batch_brackets(const double *__restrict
         const bool met = br[2] > 0 && br[6] > 0 && br[1] < tm * br[2] && br[5] < tm * br[6];
         st->want_brackets = 0;
         const int halt = met ? 3 : (not_yet ? 0 : 1);
+        if (halt) {
+            for (int a = 0; a < nprob; ++a) devs[a].ctr[0] = 1;
+            st->halt = halt;
+        }
+    }
+}
+
+// The same decision in ONE launch (inside a chunk of batched iterations): the four Gram matrices on the matrix cores, their
+// reduction and the brackets in the workgroup that finishes last.  G = sum over the entries e of a_e a_e' with a_e the B values
+// of entry e: v_mfma_f64_16x16x4_f64 takes four entries of 16 graphs at a time -- lane (i = l & 15, k = l >> 4) holds entry k of
+// graph i, which is its A operand (i, k) and its B operand (k, j = i) at once -- so a vector is read ONCE (k_batch_dots reads it
+// B + 1 times; at B = 20 its 210 pairs cost 45 us per iteration against 6 here).  NG groups of 16 graphs: B <= 16 NG.
+// Workgroups 0 .. gridDim.x - 2 share the tiled edge vectors (dW = W_new - W_old, W_old), the last one takes the node vectors.
+// Every sum in a fixed order: per wave over its entries, per workgroup over its waves (LDS), then over the workgroups.
+typedef double bg_d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bg_d4 bg_mfma(double a, double b, bg_d4 acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+#else
+    return acc;
+#endif
+}
+constexpr int GRAM_WAVES = 8;
+template <int NG>
+__global__ __launch_bounds__(GRAM_WAVES * 64) void k_batch_gram(const BatchPtrs *__restrict__ ptrs, int nprob, int64_t n_tiled, int64_t n_pad,
+                                                                const long long *__restrict__ it_done, double *__restrict__ part,
+                                                                const LogdegDev *__restrict__ devs, double t2, BatchState *st) {
+    constexpr int NBLK = NG == 1 ? 1 : 3;  // 16 x 16 blocks of the upper triangle: (0, 0) [, (0, 1), (1, 1)]
+    constexpr int SLOT = 2 * NBLK * 256;   // doubles of one wave's accumulators {update, iterate} x blocks
+    __shared__ double smem[(GRAM_WAVES / 2) * SLOT];
+    __shared__ double br[8];
+    __shared__ int s_last;
+    if (st->want_brackets == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gi = lane & 15, kq = lane >> 4;
+    const bool node_blk = blockIdx.x == gridDim.x - 1;
+    const double *vn[NG], *vo[NG];
+    {  // (both parities' pointers are requested beside the parity itself: one round trip instead of two)
+        BatchPtrs q0[NG], q1[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int a = 16 * g + gi;
+            q0[g] = q1[g] = BatchPtrs{nullptr, nullptr, nullptr, nullptr};
+            if (a < nprob) q0[g] = ptrs[a], q1[g] = ptrs[nprob + a];
+        }
+        const bool odd = (it_done[0] & 1) != 0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const BatchPtrs q = odd ? q1[g] : q0[g];
+            vn[g] = node_blk ? q.d_new : q.w_new;
+            vo[g] = node_blk ? q.d_old : q.w_old;
+        }
+    }
+    const int64_t units = (node_blk ? n_pad : n_tiled) / 16;
+    const int nw = node_blk ? GRAM_WAVES : ((int)gridDim.x - 1) * GRAM_WAVES, w0 = node_blk ? wave : (int)blockIdx.x * GRAM_WAVES + wave;
+    bg_d4 acc[2 * NBLK];  // [update: blocks][iterate: blocks]
+#pragma unroll
+    for (int b = 0; b < 2 * NBLK; ++b) acc[b] = bg_d4{0.0, 0.0, 0.0, 0.0};
+    // (the next unit's loads are in flight while this one's eight products run)
+    double2 cn[NG][2], co[NG][2];
+    auto fetch = [&](int64_t u, double2 (&fn)[NG][2], double2 (&fo)[NG][2]) {
+        const int64_t e = 16 * u + 4 * kq;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            fn[g][0] = fn[g][1] = fo[g][0] = fo[g][1] = double2{0.0, 0.0};
+            if (vn[g] && u < units) {
+                fn[g][0] = *reinterpret_cast<const double2 *>(vn[g] + e), fn[g][1] = *reinterpret_cast<const double2 *>(vn[g] + e + 2);
+                fo[g][0] = *reinterpret_cast<const double2 *>(vo[g] + e), fo[g][1] = *reinterpret_cast<const double2 *>(vo[g] + e + 2);
+            }
+        }
+    };
+    fetch(w0, cn, co);
+    for (int64_t u = w0; u < units; u += nw) {
+        double2 nn[NG][2], no[NG][2];
+        fetch(u + nw, nn, no);
+        double dn[NG][4], od[NG][4];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            od[g][0] = co[g][0].x, od[g][1] = co[g][0].y, od[g][2] = co[g][1].x, od[g][3] = co[g][1].y;
+            dn[g][0] = cn[g][0].x - co[g][0].x, dn[g][1] = cn[g][0].y - co[g][0].y;
+            dn[g][2] = cn[g][1].x - co[g][1].x, dn[g][3] = cn[g][1].y - co[g][1].y;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc[0] = bg_mfma(dn[0][t], dn[0][t], acc[0]);
+            acc[NBLK] = bg_mfma(od[0][t], od[0][t], acc[NBLK]);
+            if (NG == 2) {
+                acc[1] = bg_mfma(dn[0][t], dn[NG - 1][t], acc[1]);
+                acc[NBLK - 1] = bg_mfma(dn[NG - 1][t], dn[NG - 1][t], acc[NBLK - 1]);
+                acc[NBLK + 1] = bg_mfma(od[0][t], od[NG - 1][t], acc[NBLK + 1]);
+                acc[2 * NBLK - 1] = bg_mfma(od[NG - 1][t], od[NG - 1][t], acc[2 * NBLK - 1]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) cn[g][0] = nn[g][0], cn[g][1] = nn[g][1], co[g][0] = no[g][0], co[g][1] = no[g][1];
+    }
+    // waves -> workgroup: a fixed tree (wave w + h adds into wave w, h = 8, 4, 2, 1).  Element x of a block: lane x / 4,
+    // register x % 4 -> row (lane >> 4) + 4 (x % 4), column lane & 15.
+    for (int h = GRAM_WAVES / 2; h >= 1; h >>= 1) {
+        if (wave >= h && wave < 2 * h)
+#pragma unroll
+            for (int b = 0; b < 2 * NBLK; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) smem[(wave - h) * SLOT + b * 256 + lane * 4 + r] = acc[b][r];
+        __syncthreads();
+        if (wave < h)
+#pragma unroll
+            for (int b = 0; b < 2 * NBLK; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[b][r] += smem[wave * SLOT + b * 256 + lane * 4 + r];
+        __syncthreads();
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int b = 0; b < 2 * NBLK; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                __hip_atomic_store(part + ((size_t)blockIdx.x * 2 * NBLK + b) * 256 + lane * 4 + r, acc[b][r], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {  // (wave 0 is the only one that stored; its lanes share the counter of outstanding stores)
+            const unsigned arrived = __hip_atomic_fetch_add(&st->gram_blocks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            s_last = arrived == gridDim.x ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // ---- the last workgroup: the four B x B matrices {dW, W, dD, D} into LDS, brackets, decision (as k_batch_brackets).
+    //      Thread = (matrix k, entry x), 2 NBLK x 256 of them in passes of 512.
+    double *gA = smem;
+    const int B = nprob, ne = (int)gridDim.x - 1;
+    for (int kx = tid; kx < 2 * NBLK * 256; kx += GRAM_WAVES * 64) {
+        const int k = kx >> 8, x = kx & 255;
+        const int which = k / NBLK, b = k % NBLK;  // 0: update, 1: iterate
+        const int ln = x >> 2, r = x & 3;          // (the lane and register this entry came from)
+        const int row = (ln >> 4) + 4 * r + (b == 2 ? 16 : 0), col = (ln & 15) + (b >= 1 ? 16 : 0);
+        if (row >= B || col >= B) continue;
+        double ve = 0.0;
+#pragma unroll 8
+        for (int blk = 0; blk < ne; ++blk)
+            ve += __hip_atomic_load(part + ((size_t)blk * 2 * NBLK + k) * 256 + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double vd = __hip_atomic_load(part + ((size_t)ne * 2 * NBLK + k) * 256 + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gA[((which + 0) * B + row) * B + col] = ve;
+        gA[((which + 2) * B + row) * B + col] = vd;
+        if (b == 1) {  // (the off-diagonal block fills both triangles; the diagonal blocks are symmetric as computed)
+            gA[((which + 0) * B + col) * B + row] = ve;
+            gA[((which + 2) * B + col) * B + row] = vd;
+        }
+    }
+    __syncthreads();
+    // brackets in stages of eight squarings (each halves the logarithmic width): an iterate clearly short of the rule -- most
+    // of them -- is decided after the first; the full 34 are only run out by a tie
+    __shared__ int s_dec;
+    SmBracket S{};
+    if (wave < 4) {
+        if (B <= 16)
+            sm_bracket_begin<4>(gA + wave * B * B, B, lane, S);
+        else
+            sm_bracket_begin<16>(gA + wave * B * B, B, lane, S);
+    }
+    for (int round = 0; round < 5; ++round) {
+        if (wave < 4) {
+            double lo, hi;
+            if (B <= 16) {
+                sm_bracket_advance<4>(gA + wave * B * B, B, lane, S, 8);
+                sm_bracket_bounds<4>(gA + wave * B * B, B, lane, S, lo, hi);
+            } else {
+                sm_bracket_advance<16>(gA + wave * B * B, B, lane, S, 8);
+                sm_bracket_bounds<16>(gA + wave * B * B, B, lane, S, lo, hi);
+            }
+            if (lane == 0) br[2 * wave] = lo, br[2 * wave + 1] = hi;
+        }
+        __syncthreads();
+        if (tid == 0) {  // {lo, hi} x {update, iterate, dual update, dual}
+            const double tp = t2 * (1 + 1e-9), tm = t2 * (1 - 1e-9);
+            const bool not_yet = br[0] > tp * br[3] || br[4] > tp * br[7];
+            const bool met = br[2] > 0 && br[6] > 0 && br[1] < tm * br[2] && br[5] < tm * br[6];
+            s_dec = met ? 3 : (not_yet ? 0 : 1);
+        }
+        __syncthreads();
+        if (s_dec != 1) break;  // (1: undecided at this width)
+    }
+    if (tid == 0) {
+        st->want_brackets = 0;
+        st->gram_blocks = 0u;
+        const int halt = s_dec;
         if (halt) {
             for (int a = 0; a < nprob; ++a) devs[a].ctr[0] = 1;
             st->halt = halt;
@@ -1541,6 +1739,107 @@ double sym_lambda_max(std::vector<double> &a, int B) {
 }
 }  // namespace
 
+// ---- the batch's cruise on the tile engine -----------------------------------------------------------------------------
+// While the coupled rule is out of reach the B graphs advance as ONE block-diagonal lattice in one persistent launch of the
+// tile engine (gl_tile.hip, k_tile<..., BATCH>: 5 us per iteration where the two batched launches take 18): a stand-in
+// session holds the batch's state graph after graph, the sessions' buffers are copied in before and out after (their tiled
+// layouts agree, so these are plain copies), and the launch ends at the first iteration whose screen no longer rules the
+// rule out with 5 % to spare -- from there the chunked launches below take over, exact spectral norms and all.
+struct BatchCruise {
+    gl_logdeg cs;
+    int B = 0;
+    int64_t n = 0;
+    void *arena = nullptr;
+};
+static void batch_cruise_free(void *p) {
+    BatchCruise *bc = (BatchCruise *)p;
+    if (!bc) return;
+    gl_tile_free(&bc->cs);
+    if (bc->arena) (void)hipFree(bc->arena);
+    delete bc;
+}
+namespace {
+// dir 0: sessions -> stand-in (iterate of parity par, dual state); dir 1: back, and the sessions' counters stand at `itf`
+__global__ __launch_bounds__(256) void k_batch_copy_state(const LogdegDev *__restrict__ devs, LogdegDev C, int64_t tiled1, int64_t npad1,
+                                                          int64_t nb1, int par, int dir, long long itf) {
+    const LogdegDev S = devs[blockIdx.y];
+    const int64_t g = blockIdx.y, stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double *cw = C.w[par] + g * tiled1, *sw = S.w[par];
+    for (int64_t e = t0; e < tiled1; e += stride) {
+        if (dir == 0) cw[e] = sw[e];
+        else sw[e] = cw[e];
+    }
+    for (int64_t i = t0; i < npad1; i += stride) {
+        const int64_t k = g * npad1 + i;
+        if (dir == 0) {
+            C.dvar[k] = S.dvar[i], C.ybar[k] = S.ybar[i], C.pbar[k] = S.pbar[i], C.dprev[k] = S.dprev[i];
+        } else {
+            S.dvar[i] = C.dvar[k], S.ybar[i] = C.ybar[k], S.pbar[i] = C.pbar[k], S.dprev[i] = C.dprev[k];
+        }
+    }
+    if (dir == 1) {
+        for (int64_t i = t0; i < 2 * nb1 * 4; i += stride) {  // [parity][block][4]
+            const int64_t pr = i / (nb1 * 4), r = i % (nb1 * 4);
+            S.bnorm[i] = C.bnorm[pr * C.nb * 4 + g * nb1 * 4 + r];
+        }
+        if (t0 == 0) {
+            S.ctr[0] = 0, S.ctr[1] = 0, S.ctr[2] = itf, S.ctr[3] = itf > 0 ? itf - 1 : 0, S.ctr[4] = 0;
+        }
+    }
+}
+}  // namespace
+
+// the stand-in session for (n, B) on this context: built once, kept (GL_OK with *out == nullptr: the engine does not apply)
+static int batch_cruise_get(gl_ctx *ctx, gl_logdeg **sessions, int B, BatchCruise **out) {
+    *out = nullptr;
+    const int64_t n = sessions[0]->n;
+    BatchCruise *bc = (BatchCruise *)ctx->batch_cruise;
+    if (bc && (bc->B != B || bc->n != n)) {
+        GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        batch_cruise_free(bc);
+        ctx->batch_cruise = bc = nullptr;
+    }
+    if (!bc) {
+        bc = new (std::nothrow) BatchCruise();
+        if (!bc) return GL_E_NOMEM;
+        bc->B = B;
+        bc->n = n;
+        ctx->batch_cruise = bc;
+        ctx->batch_cruise_free = batch_cruise_free;
+        gl_logdeg &cs = bc->cs;
+        cs.ctx = ctx;
+        cs.n = n;
+        cs.n_edges = n * (n - 1) / 2;
+        LogdegDev &D = cs.dev;
+        const LogdegDev &D0 = sessions[0]->dev;
+        D.n = n;
+        D.nb = D0.nb * B;
+        D.n_pad = D.nb * GL_TB;
+        D.ntiles = D0.ntiles * B;
+        D.npairs = D.ntiles * PAIRS_PER_TILE;
+        const size_t tiled = (size_t)D.ntiles * GL_TILE_ELEMS * 8, nodes = (size_t)D.n_pad * 8;
+        struct Part {
+            void **p;
+            size_t bytes;
+        };
+        const Part parts[] = {{(void **)&D.w[0], tiled},  {(void **)&D.w[1], tiled},  {(void **)&D.dvar, nodes},
+                              {(void **)&D.ybar, nodes},  {(void **)&D.pbar, nodes},  {(void **)&D.dprev, nodes},
+                              {(void **)&D.bnorm, (size_t)2 * D.nb * 4 * 8}, {(void **)&D.dstat, 8 * 8}, {(void **)&D.ctr, 8 * 8}};
+        size_t total = 0;
+        for (const Part &q : parts) total += (q.bytes + 255) / 256 * 256;
+        if (hipMalloc(&bc->arena, total) != hipSuccess) return GL_OK;  // (no room: the launches below serve the batch)
+        char *at = (char *)bc->arena;
+        for (const Part &q : parts) {
+            *q.p = at;
+            at += (q.bytes + 255) / 256 * 256;
+        }
+        GL_HIP(ctx, hipMemsetAsync(bc->arena, 0, total, ctx->stream));
+        GL_TRY(gl_tile_prepare_batch(&cs, B));
+    }
+    if (bc->cs.tile && bc->arena) *out = bc;
+    return GL_OK;
+}
+
 // The 2-D (batched) branch of gsp_learn_graph_log_degrees (smooth_learning.py:128-129,146-167): B
 // graphs advance in lockstep and ALL stop at the iteration where both spectral-norm ratios
 //   ||Q - Y||_2 / ||W_old||_2  and  ||Qbar - Ybar||_2 / ||D_old||_2      ((E x B) and (n x B) matrices)
@@ -1596,7 +1895,8 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
         auto up = [](size_t b) { return (b + 255) / 256 * 256; };
         const bool small_path = maxit >= 8 && gl_small_applicable(sessions[0]) && B <= ctx->prop.multiProcessorCount;
         const size_t b_pairs = up((size_t)npairs * sizeof(int2)), b_ptrs = up((size_t)2 * B * sizeof(BatchPtrs));
-        const size_t b_part = 256 + up((size_t)npairs * blocks * 4 * 8), b_out = up((size_t)npairs * 4 * 8);
+        // (pair partials of k_batch_dots, or the 16 x 16 block partials of k_batch_gram: up to 257 workgroups x 6 blocks)
+        const size_t b_part = 256 + std::max(up((size_t)npairs * blocks * 4 * 8), (size_t)257 * 6 * 256 * 8), b_out = up((size_t)npairs * 4 * 8);
         const size_t b_devs = up((size_t)B * sizeof(LogdegDev));
         const size_t b_small = small_path ? up(gl_small_batch_scratch_bytes(B, (int)sessions[0]->n)) : 0;
         char *at = nullptr;
@@ -1692,64 +1992,113 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
         GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->stage_busy = false;
     }
+    // The cruise (above): everything but the call's last iteration at most -- the values reported at the end need the last
+    // two iterates side by side, which only the launches below keep.
+    int64_t cruised = 0;
+    {
+        bool same = sessions[0]->it == 0 && maxit >= 64 && !getenv("GRAPHLEARN_AMD_BATCH_NO_CRUISE");
+        for (int a = 1; a < B && same; ++a) {
+            const LogdegDev &Da = sessions[a]->dev;
+            same = Da.gamma == D0.gamma && Da.c == D0.c && Da.a4g == D0.a4g;
+        }
+        BatchCruise *bc = nullptr;
+        if (same) GL_TRY(batch_cruise_get(ctx, sessions, B, &bc));
+        if (bc) {
+            gl_logdeg &cs = bc->cs;
+            LogdegDev &C = cs.dev;
+            C.gamma = D0.gamma, C.c = D0.c, C.g2 = D0.g2, C.a4g = D0.a4g;
+            cs.it = 0;
+            cs.inited = true;
+            ++cs.init_version;
+            const int64_t tiled1 = D0.ntiles * GL_TILE_ELEMS;
+            const dim3 cgrid((unsigned)std::min<int64_t>(64, (tiled1 + 2047) / 2048), (unsigned)B);
+            GL_HIP(ctx, hipMemsetAsync(C.ctr, 0, 8 * 8, ctx->stream));
+            k_batch_copy_state<<<cgrid, 256, 0, ctx->stream>>>((const LogdegDev *)sc.devs, C, tiled1, D0.n_pad, D0.nb, 0, 0, 0);
+            GL_HIP(ctx, hipGetLastError());
+            GL_TRY(gl_tile_batch_make_zg(&cs, (const LogdegDev *)sc.devs, B));
+            GL_TRY(gl_tile_launch(&cs, maxit - 1, tol, true, -1));
+            int64_t ran = 0;
+            bool stopped = false, not_resident = false;
+            GL_TRY(gl_resident_finish(&cs, &ran, &stopped, &not_resident));
+            bool keep = !not_resident && ran > 0;
+            if (keep && stopped) {  // (dstat[0] = 1: the screen of the stopping iteration could not rule the rule out at all)
+                double *slot = (double *)ctx->pinned;
+                GL_HIP(ctx, hipMemcpyAsync(slot, C.dstat, 8, hipMemcpyDeviceToHost, ctx->stream));
+                GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                keep = slot[0] == 0.0;
+            }
+            if (getenv("GRAPHLEARN_AMD_BATCH_DEBUG"))
+                fprintf(stderr, "[batch cruise] n %lld B %d: ran %lld of %lld, stopped %d, not resident %d, kept %d\n", (long long)sessions[0]->n, B,
+                        (long long)ran, (long long)(maxit - 1), (int)stopped, (int)not_resident, (int)keep);
+            if (not_resident) {  // shared GPU: this context's batches stay on the launches below
+                batch_cruise_free(bc);
+                ctx->batch_cruise = nullptr;
+            } else if (keep) {
+                k_batch_copy_state<<<cgrid, 256, 0, ctx->stream>>>((const LogdegDev *)sc.devs, C, tiled1, D0.n_pad, D0.nb, (int)(ran & 1), 1,
+                                                                   (long long)ran);
+                GL_HIP(ctx, hipGetLastError());
+                cruised = ran;
+                for (int a = 0; a < B; ++a) sessions[a]->it = ran;
+            }
+        }
+    }
     BatchState *st_dev = (BatchState *)sc.part;  // (the partials of the exact evaluation live behind it)
     sc.part = (char *)sc.part + 256;
     BatchState *st_host = (BatchState *)((char *)ctx->pinned + GL_STATUS_BYTES);
     {
         BatchState init{};
-        init.first = 1;
-        init.remaining = (int)std::min<int64_t>(maxit, 1 << 30);
+        init.first = cruised == 0 ? 1 : 0;
+        init.ran = (int)cruised;
+        init.remaining = (int)std::min<int64_t>(maxit - cruised, 1 << 30);
         *st_host = init;
         GL_HIP(ctx, hipMemcpyAsync(st_dev, st_host, sizeof(BatchState), hipMemcpyHostToDevice, ctx->stream));
         GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     const double t2 = tol * tol;
     const int chunk = (int)std::min<int64_t>(maxit, getenv("GRAPHLEARN_AMD_BATCH_CHUNK") ? std::max(1, atoi(getenv("GRAPHLEARN_AMD_BATCH_CHUNK"))) : 16);
-    struct Graph {
-        hipGraphExec_t g = nullptr;
-        ~Graph() {
-            if (g) (void)hipGraphExecDestroy(g);
-        }
-    } graph;
     // Two forms of an iteration.  "Cruise": edge pass + node pass (whose last workgroup screens the rule and halts the batch
-    // when it cannot rule it out).  "Decide": the same two, and behind them the pair products, their reduction and the
-    // brackets of the four spectral norms -- three launches that fall through unless the screen asked for them --, so that
-    // the stretch of a run in which the cheap bounds straddle tol (about its last third) is judged on the device too.
+    // when it cannot rule it out).  "Decide": the same two, and behind them ONE launch that forms the four Gram matrices on
+    // the matrix cores and brackets their largest eigenvalues (k_batch_gram; it falls through unless the screen asked for
+    // it), so that the stretch of a run in which the cheap bounds straddle tol (a third to a half of it) is judged on the
+    // device too.
     // A call cruises until the screen halts it for the first time, then continues in the other form (B <= 32).
     const bool can_decide = B <= BATCH_BRACKET_MAXB && !getenv("GRAPHLEARN_AMD_BATCH_HOST_RULE");
-    auto one_iteration = [&](bool decide) {  // (the kernels take the iteration index from device memory: the same launches every time)
-        k_edge_batch<<<dim3((unsigned)D0.G, (unsigned)B), dim3(64), 0, ctx->stream>>>((const LogdegDev *)sc.devs);
-        k_node_batch<<<dim3((unsigned)D0.nb, (unsigned)B), dim3(NODE_WAVES * 64), 0, ctx->stream>>>((const LogdegDev *)sc.devs, st_dev, B, t2);
+    auto one_iteration = [&](bool decide, int par) {  // par: parity of the iteration's index (its input lives in w[par])
+        k_edge_batch<<<dim3((unsigned)D0.G, (unsigned)B), dim3(64), 0, ctx->stream>>>((const LogdegDev *)sc.devs, par);
+        k_node_batch<<<dim3((unsigned)D0.nb, (unsigned)B), dim3(NODE_WAVES * 64), 0, ctx->stream>>>((const LogdegDev *)sc.devs, st_dev, B, t2, par);
         if (decide) {
-            // (a one-pass Gram kernel -- every vector staged once in LDS, all pairs from there -- measured slower than these
-            //  B-fold re-reads from L2: it is bound by its LDS reads, two per multiply-add)
-            k_batch_dots<<<dim3((unsigned)npairs, (unsigned)blocks), 256, 0, ctx->stream>>>(
-                (const BatchPtrs *)sc.ptrs, (const int2 *)sc.pairs, n_tiled, sessions[0]->n, (double *)sc.part, &st_dev->want_brackets,
-                D0.ctr + 2, B);
-            k_batch_dots_reduce<<<dim3((unsigned)((npairs * 4 + 255) / 256)), 256, 0, ctx->stream>>>(
-                (const double *)sc.part, npairs, blocks, (double *)sc.out, &st_dev->want_brackets);
-            k_batch_brackets<<<1, 256, 0, ctx->stream>>>((const double *)sc.out, (const int2 *)sc.pairs, npairs,
-                                                         (const LogdegDev *)sc.devs, B, t2, st_dev);
+            // (the four Gram matrices on the matrix cores, reduced and bracketed by the launch's last workgroup: k_batch_gram)
+            const int64_t units = n_tiled / 16;  // (about four of them per wave, on up to 128 workgroups of 8 waves)
+            const unsigned ge = (unsigned)std::max<int64_t>(1, std::min<int64_t>(128, units / (4 * GRAM_WAVES)));
+            if (B <= 16)
+                k_batch_gram<1><<<ge + 1, GRAM_WAVES * 64, 0, ctx->stream>>>((const BatchPtrs *)sc.ptrs, B, n_tiled, D0.n_pad, D0.ctr + 2,
+                                                                              (double *)sc.part, (const LogdegDev *)sc.devs, t2, st_dev);
+            else
+                k_batch_gram<2><<<ge + 1, GRAM_WAVES * 64, 0, ctx->stream>>>((const BatchPtrs *)sc.ptrs, B, n_tiled, D0.n_pad, D0.ctr + 2,
+                                                                              (double *)sc.part, (const LogdegDev *)sc.devs, t2, st_dev);
         }
     };
-    const bool use_graph = chunk >= 4 && !getenv("GRAPHLEARN_AMD_NO_GRAPH");
-    struct Graph2 {
-        hipGraphExec_t g = nullptr;
-        ~Graph2() {
-            if (g) (void)hipGraphExecDestroy(g);
+    // (the launches carry the parity of their iteration: one captured chunk per form and per parity of its first iteration;
+    //  a chunk that is halted half way leaves the next one to start on either)
+    const bool use_graph = chunk >= 4 && chunk % 2 == 0 && !getenv("GRAPHLEARN_AMD_NO_GRAPH");
+    struct Graphs {
+        hipGraphExec_t g[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [decide][parity of the first iteration]
+        ~Graphs() {
+            for (auto &row : g)
+                for (hipGraphExec_t q : row)
+                    if (q) (void)hipGraphExecDestroy(q);
         }
-    } graph_decide;
-    auto capture = [&](bool decide, hipGraphExec_t *out) -> int {
+    } graphs;
+    auto capture = [&](bool decide, int par0, hipGraphExec_t *out) -> int {
         hipGraph_t gr = nullptr;
         GL_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-        for (int k = 0; k < chunk; ++k) one_iteration(decide);
+        for (int k = 0; k < chunk; ++k) one_iteration(decide, (par0 + k) & 1);
         hipError_t e = hipStreamEndCapture(ctx->stream, &gr);
         if (e == hipSuccess) e = hipGraphInstantiate(out, gr, nullptr, nullptr, 0);
         if (gr) (void)hipGraphDestroy(gr);
         if (e != hipSuccess) return gl_set_error(ctx, GL_E_HIP, "batch graph capture failed: %s", hipGetErrorString(e));
         return GL_OK;
     };
-    if (use_graph) GL_TRY(capture(false, &graph.g));
     bool deciding = false;  // the form the call is in
     auto rearm = [&]() -> int {
         k_batch_rearm<<<dim3((unsigned)((B + 63) / 64)), 64, 0, ctx->stream>>>((const LogdegDev *)sc.devs, B, st_dev);
@@ -1759,13 +2108,17 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
 
     double rp = std::numeric_limits<double>::infinity(), rd = rp;
     bool have_exact = false, converged = false;
-    int64_t n_iter = 0;
-    const int64_t it0 = sessions[0]->it;
+    int64_t n_iter = cruised;
+    const int64_t it0 = sessions[0]->it - cruised;
     while (n_iter < maxit) {
-        if (use_graph)
-            GL_HIP(ctx, hipGraphLaunch(deciding ? graph_decide.g : graph.g, ctx->stream));
-        else
-            for (int k = 0; k < chunk; ++k) one_iteration(deciding);
+        const int par0 = (int)((it0 + n_iter) & 1);
+        if (use_graph) {
+            hipGraphExec_t &gq = graphs.g[deciding ? 1 : 0][par0];
+            if (!gq) GL_TRY(capture(deciding, par0, &gq));
+            GL_HIP(ctx, hipGraphLaunch(gq, ctx->stream));
+        } else {
+            for (int k = 0; k < chunk; ++k) one_iteration(deciding, (par0 + k) & 1);
+        }
         GL_HIP(ctx, hipGetLastError());
         GL_HIP(ctx, hipMemcpyAsync(st_host, st_dev, sizeof(BatchState), hipMemcpyDeviceToHost, ctx->stream));
         GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1784,7 +2137,6 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
         if (n_iter >= maxit) break;
         if (can_decide && !deciding) {  // from here on the device judges such iterates itself
             deciding = true;
-            if (use_graph) GL_TRY(capture(true, &graph_decide.g));
             st_host->decide_here = 1;
             GL_HIP(ctx, hipMemcpyAsync(&st_dev->decide_here, &st_host->decide_here, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         }

@@ -167,6 +167,11 @@ struct TileDev {
     unsigned tag0;
     unsigned rendezvous;  // value the arrival counter reaches when every workgroup of this launch has arrived
     int check_rendezvous; // wait for that at the start also below the rounds (test hook)
+    // BATCH (k_tile<..., BATCH = true>): the lattice is block-diagonal -- B graphs of n nodes, graph g = node blocks
+    // g nb1 .. g nb1 + nb1 - 1, tiles g ntiles1 .., workgroups g NWG1 ..; n, nm2 are those of ONE graph; nb, NWG the totals
+    int nb1, NWG1;
+    int64_t ntiles1;
+    double t2hi, t2lo;    // thresholds of the coupled rule's screen: (1.05 tol)^2 and tol^2 (1 + 1e-9)
 };
 
 __device__ __forceinline__ double tl_val(tl_u4 g) {
@@ -183,6 +188,12 @@ __device__ __forceinline__ double lane_bcast(double v, int l) {  // lane l's val
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+__device__ __forceinline__ double tl_wave_max(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
+    return v;
 }
 
 // false: give up (error word raised by somebody, or one second without progress)
@@ -542,9 +553,11 @@ __device__ __forceinline__ void tl_stream_pass(const TileDev &P, double2 (&wq)[R
 // barriers) into the accumulators of the waves that publish the records.  Everything else -- records, owners, rule --
 // is unchanged.  Streamed tiles are updated in place: a launch that fails after the rendezvous is an error as before,
 // one whose workgroups never met has still written nothing.
-template <int U, bool RAGGED, bool NORMS, int BIGV = 0>  // BIGV: 0, 1 = rounds, 2 = rounds with non-temporal streams
+// BATCH: a batch of graphs of one size as ONE block-diagonal lattice (TileDev), stopped by the screen of the coupled rule
+template <int U, bool RAGGED, bool NORMS, int BIGV = 0, bool BATCH = false>  // BIGV: 0, 1 = rounds, 2 = rounds with non-temporal streams
 __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     constexpr bool BIG = BIGV != 0, NT = BIGV == 2;
+    static_assert(!BATCH || (NORMS && !BIG), "batches: below the rounds, with the norms");
     constexpr bool MASKW = RAGGED && NORMS;  // (see tl_chunk_pass)
     constexpr int ZEV = RoundsSplit<NORMS>::ZEV, ZLN = RoundsSplit<NORMS>::ZLN, WRG = BIG ? RoundsSplit<NORMS>::WRG : WRG_NONE;
     static_assert(!BIG || U == SLOTS, "rounds work on whole tiles");
@@ -588,6 +601,9 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     constexpr int GD_SLICE = GD_COL + NBW, GD_ACTIVE = GD_SLICE + 2, GD_NRND = GD_ACTIVE + 1, GD_ROW2 = GD_NRND + 1;
     constexpr int GD_NX = GD_ROW2 + NBW, GD_XT = GD_NX + 1, GD_XS = GD_XT + 4;
     const int nblk = gd_int(0), own = gd_int(1), own_e0 = gd_int(2), own_e1 = gd_int(3);
+    // a node block's index inside its graph (what lies outside i < j < n is decided there)
+    const int nb1 = BATCH ? P.nb1 : (int)P.nb;
+    auto in_graph = [&](int b) { return BATCH ? b % nb1 : b; };
     const unsigned long long slice_mask = ((unsigned long long)(unsigned)gd_int(GD_SLICE + 1) << 32) | (unsigned)gd_int(GD_SLICE);
     const bool active = gd_int(GD_ACTIVE) != 0;
     unsigned *err = P.bar + 32;
@@ -645,7 +661,11 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     // element offsets of this lane's first pair in my chunk and in my fringe tile: formed where they are used (prologue and
     // write-back), from the lane number of that moment -- over the pass they would only hold registers
     auto chunk_off = [&](int ln) -> int64_t { return (int64_t)wdv.tile * GL_TILE_ELEMS + (int64_t)a0 * (2 * TB) + (ln >> 5) * TB + 2 * (ln & 31); };
-    auto fringe_off = [&](int ln) -> int64_t { return gl_tile_id(fB, fB, P.nb) * GL_TILE_ELEMS + (ln >> 5) * TB + 2 * (ln & 31); };
+    const int fBl = in_graph(fB >= 0 ? fB : 0);
+    auto fringe_off = [&](int ln) -> int64_t {
+        const int64_t t = BATCH ? (int64_t)((fB >= 0 ? fB : 0) / nb1) * P.ntiles1 + gl_tile_id(fBl, fBl, nb1) : gl_tile_id(fB, fB, P.nb);
+        return t * GL_TILE_ELEMS + (ln >> 5) * TB + 2 * (ln & 31);
+    };
     if (has) zb = (unsigned)(chunk_off(lane) * 8);
     // The bulk loads of the prologue, in the order the first pass wants them: the LDS-resident part of z (straight into
     // LDS: zg is stored pre-multiplied, so nothing has to pass through registers) -- waited for at once: the compiler
@@ -703,7 +723,8 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     auto tile_off = [&](int r) -> unsigned {  // byte offset of this lane's first pair of tile (I + r, J)
         return (unsigned)((gl_tile_id(wdv.I + r, wdv.J, P.nb) * GL_TILE_ELEMS + (lane_s >> 5) * TB + 2 * (lane_s & 31)) * 8);
     };
-    const bool jv0 = (int64_t)wdv.J * TB + c0 < P.n, jv1 = (int64_t)wdv.J * TB + c0 + 1 < P.n;
+    const int Jl = in_graph(wdv.J);
+    const bool jv0 = (int64_t)Jl * TB + c0 < P.n, jv1 = (int64_t)Jl * TB + c0 + 1 < P.n;
     // where this wave starts its streamed tiles
     const int g0 = GL_TILE_STAGGER ? (int)(((unsigned)(wg * TW + wave) * 5u) & (unsigned)(SLOTS / RS - 1)) : 0;
     auto ring_load = [&](double2 (&wq)[RS], double2 (&zq)[RS], unsigned base, int grp) {
@@ -718,7 +739,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         return (unsigned)(((int64_t)gd_int(GD_XT + k) * GL_TILE_ELEMS + (lane_s >> 5) * TB + 2 * (lane_s & 31)) * 8);
     };
     // ragged last block column: 0 / 1 factors of my two columns (only the variants with the norms keep them over the pass)
-    auto col_valid = [&](int e) { return (RAGGED && has) ? ((int64_t)wdv.J * TB + c0 + e < P.n ? 1.0 : 0.0) : 1.0; };
+    auto col_valid = [&](int e) { return (RAGGED && has) ? ((int64_t)Jl * TB + c0 + e < P.n ? 1.0 : 0.0) : 1.0; };
     const double m0 = MASKW ? col_valid(0) : 1.0, m1 = MASKW ? col_valid(1) : 1.0;
 
     // ---- start-up rendezvous, wait (wave 0; the other waves go on and issue their bulk loads meanwhile)
@@ -798,7 +819,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) b[q] = 0.0;
 #pragma unroll 1
-        for (int b0 = 0; b0 < (BIG ? (int)P.nb : 1); b0 += 64) {  // (nb <= 64 unless BIG)
+        for (int b0 = 0; b0 < ((BIG || BATCH) ? (int)P.nb : 1); b0 += 64) {  // (nb <= 64 unless BIG or a batch)
             const bool mine = b0 + lane < P.nb;
             tl_u4 r[4];
             for (;;) {
@@ -816,6 +837,47 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) b[q] += wave_sum(mine ? tl_val(r[q]) : 0.0);
+        }
+        return true;
+    };
+    // BATCH: the screen of the coupled rule (smooth_learning.py:158-159,166-167 on (E x B) and (n x B) matrices: spectral
+    // norms; lambda_max of a Gram matrix lies in [max diagonal, trace]):  s = {max_g ||dW_g||^2, sum_g ||W_g||^2,
+    // max_g ||dD_g||^2, sum_g ||D_g||^2} of local iteration j from the node blocks' norm records -- lane = block, whole graphs
+    // per sweep of the wave, every sum in a fixed order.
+    auto screen_of = [&](int j, double (&s)[4]) -> bool {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned spins = 0;
+        const unsigned tag = P.tag0 + (unsigned)j + 1u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] = 0.0;
+        const int per = (64 / nb1) * nb1, first = lane - lane % nb1;  // lanes in use per sweep; my graph's first lane
+#pragma unroll 1
+        for (int b0 = 0; b0 < (int)P.nb; b0 += per) {
+            const bool mine = lane < per && b0 + lane < P.nb;
+            tl_u4 r[4];
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    r[q] = tl_u4{0u, tag, 0u, tag};
+                    if (mine) r[q] = __builtin_amdgcn_raw_buffer_load_b128(r_bn, (((j & 3) * (int)P.nb + b0 + lane) * 4 + q) * 16, 0, 16);
+                    ok = ok && tl_ok(r[q], tag);
+                }
+                asm volatile("" ::: "memory");
+                if (__all(ok)) break;
+                if (!tl_spin(spins, t0, err)) return false;
+            }
+            const double v0 = mine ? tl_val(r[0]) : 0.0, v2 = mine ? tl_val(r[2]) : 0.0;
+            s[1] += wave_sum(mine ? tl_val(r[1]) : 0.0);
+            s[3] += wave_sum(mine ? tl_val(r[3]) : 0.0);
+            double a0 = 0.0, a2 = 0.0;
+#pragma unroll 1
+            for (int k = 0; k < nb1; ++k) {
+                a0 += __shfl(v0, first + k);
+                a2 += __shfl(v2, first + k);
+            }
+            s[0] = fmax(s[0], tl_wave_max(mine ? a0 : 0.0));
+            s[2] = fmax(s[2], tl_wave_max(mine ? a2 : 0.0));
         }
         return true;
     };
@@ -888,6 +950,28 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 double b[4] = {0, 0, 0, 0};
                 int stop = 0;
                 double rp = INFINITY, rd = INFINITY;
+                if constexpr (BATCH) {
+                    // The batch runs while the screen RULES OUT the coupled rule with 5 % to spare (the lower bound of one of
+                    // the two ratios above 1.05 tol) and ends at the first iteration where it does not: the exact spectral norms
+                    // are the host's business from there on.  Should the lower bounds of that very iteration already lie below
+                    // tol (a drop of 5 % in one iteration, or a start from a converged iterate) the rule may have held for
+                    // an iterate these registers no longer hold: reported (rp = 1), and the caller redoes the run its own way.
+                    good = good && screen_of(it - 1, b);
+                    if (good && P.it0 + it - 1 >= 1) {  // never at iteration 0 (:156-161)
+                        const bool degenerate = !(b[1] > 0) || !(b[3] > 0);
+                        const bool not_yet = !degenerate && (b[0] > P.t2hi * b[1] || b[2] > P.t2hi * b[3]);
+                        const bool surely_not = !degenerate && (b[0] > P.t2lo * b[1] || b[2] > P.t2lo * b[3]);
+                        stop = not_yet ? 0 : 1;
+                        rp = surely_not ? 0.0 : 1.0;
+                        rd = degenerate ? 0.0 : fmax(b[0] / b[1], b[2] / b[3]);
+                    }
+                    if (lane == 0) {
+                        s_rel[0] = rp;
+                        s_rel[1] = rd;
+                        s_flag[2] = stop;
+                        s_flag[3] = 3;
+                    }
+                } else {
                 // The first iterations of every call are judged exactly too: a call that starts from a converged or nearly
                 // converged iterate (edge_init, a resumed session) drops below tol at once, with no older record to warn of it
                 bool sticky = exact;
@@ -930,6 +1014,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     s_rel[1] = rd;
                     s_flag[2] = stop;
                     s_flag[3] = (sticky ? 1 : 0) | (now_exact ? 2 : 0);
+                }
                 }
             }
             if (!good) s_flag[1] = 1;
@@ -1080,7 +1165,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     tl_edge(c, fw[f].x, fgz[f].x, rv.x, rv.y, cv0.x, cv0.y, pp[0], t[0]);
                     tl_edge(c, fw[f].y, fgz[f].y, rv.x, rv.y, cv1.x, cv1.y, pp[1], t[1]);
                     if (NORMS) {  // (without the norms the entries outside the lattice carry a bounded value nobody reads)
-                        const int64_t i = (int64_t)fB * TB + 2 * a + half, j = (int64_t)fB * TB + c0;
+                        const int64_t i = (int64_t)fBl * TB + 2 * a + half, j = (int64_t)fBl * TB + c0;
                         t[0] = (i < j && j < P.n) ? t[0] : 0.0;  // (w is 0 there and stays 0)
                         t[1] = (i < j + 1 && j + 1 < P.n) ? t[1] : 0.0;
                     }
@@ -1122,7 +1207,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             if (NORMS) s_wcarry[wave] = nw;
         }
         // (the rule's early look, after the publish phase: its records are requested now)
-        const bool look_on = NORMS && rule_on && !exact && wg == P.rule_wg && wave == TW - 1 && it >= 1 && it + 1 < P.maxit;
+        const bool look_on = !BATCH && NORMS && rule_on && !exact && wg == P.rule_wg && wave == TW - 1 && it >= 1 && it + 1 < P.maxit;
         tl_u4 lk[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) lk[q] = tl_u4{0u, P.tag0 + (unsigned)it, 0u, P.tag0 + (unsigned)it};
@@ -1226,13 +1311,14 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 // wave 1 also fetches the block sums of gamma u that this iteration's input state was published with (a whole
                 // pass ago): sum_j gamma u_j over all nodes, in a fixed order
                 constexpr int NUS = BIG ? 3 : 1;  // node blocks per lane (nb <= 64, rounds <= 192)
+                const int gb0 = BATCH ? own - in_graph(own) : 0, gnb = BATCH ? nb1 : (int)P.nb;  // my graph's node blocks
                 tl_u4 gu[NUS];
                 auto load_gu = [&]() {
 #pragma unroll
                     for (int q = 0; q < NUS; ++q) {
                         gu[q] = tl_u4{0u, tag_in, 0u, tag_in};
-                        if (wave == 1 && q * 64 + lane < P.nb)
-                            gu[q] = __builtin_amdgcn_raw_buffer_load_b128(r_us, (int)(((tag_in & 1u) * (unsigned)P.nb + (unsigned)(q * 64 + lane)) * 16u), 0, 16);
+                        if (wave == 1 && q * 64 + lane < gnb)
+                            gu[q] = __builtin_amdgcn_raw_buffer_load_b128(r_us, (int)(((tag_in & 1u) * (unsigned)P.nb + (unsigned)(gb0 + q * 64 + lane)) * 16u), 0, 16);
                     }
                 };
                 load_gu();
@@ -1274,7 +1360,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     }
                     double t = 0.0;
 #pragma unroll
-                    for (int q = 0; q < NUS; ++q) t += (q * 64 + lane < P.nb) ? tl_val(gu[q]) : 0.0;
+                    for (int q = 0; q < NUS; ++q) t += (q * 64 + lane < gnb) ? tl_val(gu[q]) : 0.0;
                     t = wave_sum(t);
                     if (lane == 0) s_gu = t;
                 }
@@ -1295,7 +1381,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 sp = s_own[0][ln];
 #pragma unroll
                 for (int v = 1; v < TW; ++v) sp += s_own[v][ln];
-                const bool real = (int64_t)own * TB + ln < P.n;
+                const bool real = (int64_t)in_graph(own) * TB + ln < P.n;
                 const double d_cur = s_dual[0][ln], yb_cur = s_dual[1][ln], pb_cur = s_dual[2][ln], gsw_cur = s_dual[4][ln];
                 const double gsp = P.gamma * sp;
                 const double qb = pb_cur + gsp;           // :154
@@ -1333,8 +1419,9 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 // my slice of the workgroups' norm records (workgroups own, own + nb, ...), beside wave 0's update and off the
                 // owner's critical path (in front of the barrier above it cost 0.5-1 us per iteration: the node values of
                 // the whole chip waited for it)
-                const int nsrc = own + lane * (int)P.nb;
-                const bool nmine = nsrc < P.NWG && ((slice_mask >> lane) & 1ull);
+                // (a batch: the workgroups of MY graph, so that a block's partials belong to one graph)
+                const int nsrc = BATCH ? (own / nb1) * P.NWG1 + in_graph(own) + lane * nb1 : own + lane * (int)P.nb;
+                const bool nmine = (BATCH ? nsrc < (own / nb1 + 1) * P.NWG1 : nsrc < P.NWG) && ((slice_mask >> lane) & 1ull);
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 unsigned spins = 0;
                 tl_u4 na, nb2;
@@ -1402,14 +1489,14 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
 #pragma unroll
         for (int s = 0; s < U; ++s) {
             double2 v = (BIG && s >= WRG) ? s_z[wave][ZLN + (s >= WRG ? s - WRG : 0)][lane] : wreg[s];
-            if (RAGGED && !MASKW) v = double2{((int64_t)wdv.J * TB + 2 * (lw & 31) < P.n ? 1.0 : 0.0) * v.x, ((int64_t)wdv.J * TB + 2 * (lw & 31) + 1 < P.n ? 1.0 : 0.0) * v.y};
+            if (RAGGED && !MASKW) v = double2{((int64_t)Jl * TB + 2 * (lw & 31) < P.n ? 1.0 : 0.0) * v.x, ((int64_t)Jl * TB + 2 * (lw & 31) + 1 < P.n ? 1.0 : 0.0) * v.y};
             *reinterpret_cast<double2 *>(P.wout + tb0 + s * (2 * TB)) = v;
         }
     }
 #pragma unroll
     for (int f = 0; f < FRMAX; ++f)
         if (f < fcnt) {
-            const int64_t i = (int64_t)fB * TB + 2 * (fa0 + f) + (lw >> 5), j = (int64_t)fB * TB + 2 * (lw & 31);
+            const int64_t i = (int64_t)fBl * TB + 2 * (fa0 + f) + (lw >> 5), j = (int64_t)fBl * TB + 2 * (lw & 31);
             *reinterpret_cast<double2 *>(P.wout + fringe_off(lw) + (int64_t)(fa0 + f) * (2 * TB)) =
                 double2{(i < j && j < P.n) ? fw[f].x : 0.0, (i < j + 1 && j + 1 < P.n) ? fw[f].y : 0.0};
         }
@@ -1457,6 +1544,26 @@ __global__ __launch_bounds__(256) void k_make_zg(const double *__restrict__ z, d
     }
 }
 
+// the same for a batch: blockIdx.y = graph, distances from the sessions' own buffers, tiles of graph g at g ntiles1
+__global__ __launch_bounds__(256) void k_make_zg_batch(const LogdegDev *__restrict__ devs, double *__restrict__ zg, int64_t n, int64_t nb1,
+                                                       int64_t ntiles1, double g2) {
+    int I, J;
+    gl_tile_decode((int64_t)blockIdx.x, nb1, I, J);
+    const double *z = devs[blockIdx.y].z + (int64_t)blockIdx.x * GL_TILE_ELEMS;
+    double *o_ = zg + ((int64_t)blockIdx.y * ntiles1 + blockIdx.x) * GL_TILE_ELEMS;
+#pragma unroll
+    for (int k = 0; k < GL_TILE_ELEMS / (2 * 256); ++k) {
+        const int e = 2 * ((int)threadIdx.x + 256 * k);
+        const int r = e / TB, c = e % TB;
+        const int64_t i = (int64_t)I * TB + r, j = (int64_t)J * TB + c;
+        const double2 v = *reinterpret_cast<const double2 *>(z + e);
+        double2 o;
+        o.x = (i < j && j < n) ? g2 * v.x : ZG_OUTSIDE;
+        o.y = (i < j + 1 && j + 1 < n) ? g2 * v.y : ZG_OUTSIDE;
+        *reinterpret_cast<double2 *>(o_ + e) = o;
+    }
+}
+
 }  // namespace
 
 // =========================================================================== host side
@@ -1473,6 +1580,9 @@ struct gl_tile {
     int64_t zg_version = -1;    // ... and the version of the session's distances it was formed from
     unsigned next_tag = 1u;     // first tag of the next launch (a launch uses maxit + 2 consecutive ones, never 0)
     unsigned arrivals = 0;      // workgroups that have arrived at the start-up rendezvous over all launches so far
+    bool batch = false;         // a batch of graphs as one block-diagonal lattice (gl_tile_prepare_batch)
+    int nb1 = 0, NWG1 = 0;      // ... node blocks and workgroups of ONE graph
+    int64_t ntiles1 = 0;        // ... and its tiles
 };
 
 void gl_tile_free(gl_logdeg *s) {
@@ -1484,27 +1594,40 @@ void gl_tile_free(gl_logdeg *s) {
 }
 
 // slices, record entries, device arena: common to both decompositions
-static int tile_finish(gl_logdeg *s, std::vector<WaveDesc> &wd, std::vector<WgDesc> &gd, const int NWG, const int U, const bool big) {
+// (batch_nb1 > 0: a batch -- the lattice of batch_nb1 node blocks and batch_nwg1 workgroups replicated; the owner of a node
+//  block sums the norm records of the workgroups of ITS graph)
+static int tile_finish(gl_logdeg *s, std::vector<WaveDesc> &wd, std::vector<WgDesc> &gd, const int NWG, const int U, const bool big,
+                       const int batch_nb1 = 0, const int batch_nwg1 = 0) {
     gl_ctx *ctx = s->ctx;
     const LogdegDev &D = s->dev;
     const int nb = (int)D.nb;
     const int F = nb * (nb - 1) / 2;
+    const int nb1 = batch_nb1 > 0 ? batch_nb1 : nb, nwg1 = batch_nb1 > 0 ? batch_nwg1 : NWG;
     std::vector<std::vector<int>> touch((size_t)nb);  // block -> workgroups (ascending)
-    for (int g = 0; g < NWG; ++g)
+    std::vector<int> owner((size_t)nb, -1);           // block -> the workgroup that owns it
+    for (int g = 0; g < NWG; ++g) {
         for (int k = 0; k < gd[(size_t)g].nblk; ++k) touch[(size_t)gd[(size_t)g].blk[k]].push_back(g);
-    for (int B = 0; B < nb; ++B)
-        for (int r = 0; B + r * nb < NWG; ++r)
-            if (gd[(size_t)(B + r * nb)].active) (r < 32 ? gd[(size_t)B].slice_lo : gd[(size_t)B].slice_hi) |= 1u << (r & 31);
+        if (gd[(size_t)g].own >= 0) owner[(size_t)gd[(size_t)g].own] = g;
+    }
+    for (int B = 0; B < nb; ++B) {
+        if (owner[(size_t)B] < 0) return gl_set_error(ctx, GL_E_STATE, "internal: node block %d has no owner", B);
+        const int first = (B / nb1) * nwg1, bl = B % nb1;
+        for (int r = 0; bl + r * nb1 < nwg1; ++r) {
+            if (r >= 64) return gl_set_error(ctx, GL_E_STATE, "internal: more than 64 norm records per owner");
+            if (gd[(size_t)(first + bl + r * nb1)].active)
+                (r < 32 ? gd[(size_t)owner[(size_t)B]].slice_lo : gd[(size_t)owner[(size_t)B]].slice_hi) |= 1u << (r & 31);
+        }
+    }
     int n_entries = 0;
     for (int B = 0; B < nb; ++B) {
-        gd[(size_t)B].own_e0 = n_entries;
+        gd[(size_t)owner[(size_t)B]].own_e0 = n_entries;
         for (int g : touch[(size_t)B]) {
             WgDesc &G = gd[(size_t)g];
             for (int k = 0; k < G.nblk; ++k)
                 if (G.blk[k] == B) G.ent[k] = n_entries;
             ++n_entries;
         }
-        gd[(size_t)B].own_e1 = n_entries;
+        gd[(size_t)owner[(size_t)B]].own_e1 = n_entries;
         if (touch[(size_t)B].empty()) return gl_set_error(ctx, GL_E_STATE, "internal: node block %d has no producer", B);
     }
 
@@ -1565,6 +1688,10 @@ static int tile_finish(gl_logdeg *s, std::vector<WaveDesc> &wd, std::vector<WgDe
     if (!gd[(size_t)P.rule_wg].active) P.rule_wg = 0;  // (workgroup 0 owns block 0: always active)
     t->U = U;
     t->big = big;
+    t->batch = batch_nb1 > 0;
+    t->nb1 = nb1;
+    t->NWG1 = nwg1;
+    t->ntiles1 = batch_nb1 > 0 ? D.ntiles / (nb / nb1) : D.ntiles;
     if (big) {  // what streams per iteration: w and z of every tile no wave keeps in registers
         int64_t streamed = 0;
         for (const WaveDesc &w : wd) streamed += w.nr - (w.tile >= 0 ? 1 : 0);
@@ -1755,20 +1882,14 @@ static int tile_prepare_rounds(gl_logdeg *s, bool allow_split = true) {
     return tile_finish(s, wd, gd, NWG, SLOTS, true);
 }
 
-// Builds the static work decomposition.  GL_OK with s->tile == nullptr when the engine does not apply.
-int gl_tile_prepare(gl_logdeg *s) {
-    gl_ctx *ctx = s->ctx;
-    s->tile = nullptr;
-    bool forced = false;
-    if (const char *e = getenv("GRAPHLEARN_AMD_ENGINE")) {
-        if (!strcmp(e, "stream") || !strcmp(e, "resident1")) return GL_OK;
-        forced = !strcmp(e, "resident") || !strcmp(e, "tile");
-    }
-    const LogdegDev &D = s->dev;
-    const int ncu = ctx->prop.multiProcessorCount;
-    const int nb = (int)D.nb;
+// The static work decomposition of ONE lattice of nb node blocks on at most ncu workgroups (below the rounds).
+// NWG_out = 0: it does not apply.
+static int tile_plan_fit(const int nb, const int ncu, const bool forced, std::vector<WaveDesc> &wd_out, std::vector<WgDesc> &gd_out,
+                         int &NWG_out, int &U_out) {
+    NWG_out = 0;
+    U_out = SLOTS;
     const int F = nb * (nb - 1) / 2;  // bulk (off-diagonal) tiles
-    if (nb > 64 || F > TW * ncu) return tile_prepare_rounds(s);  // does not fit the register files
+    if (nb > 64 || F > TW * ncu) return GL_OK;  // does not fit the register files
     if (!forced && F < GL_TILE_MIN_BULK_TILES) return GL_OK;  // (n <= 128 belongs to the small engine)
     // chunk length: the finest split that still fits one chunk per wave of the chip (shorter edge phase)
     int U = F * 4 <= TW * ncu ? 8 : (F * 2 <= TW * ncu ? 16 : 32);
@@ -1880,7 +2001,78 @@ int gl_tile_prepare(gl_logdeg *s) {
         }
         G.active = (G.nblk > 0 || G.own >= 0) ? 1 : 0;
     }
+    wd_out.swap(wd);
+    gd_out.swap(gd);
+    NWG_out = NWG;
+    U_out = U;
+    return GL_OK;
+}
+
+
+// Builds the static work decomposition.  GL_OK with s->tile == nullptr when the engine does not apply.
+int gl_tile_prepare(gl_logdeg *s) {
+    gl_ctx *ctx = s->ctx;
+    s->tile = nullptr;
+    bool forced = false;
+    if (const char *e = getenv("GRAPHLEARN_AMD_ENGINE")) {
+        if (!strcmp(e, "stream") || !strcmp(e, "resident1")) return GL_OK;
+        forced = !strcmp(e, "resident") || !strcmp(e, "tile");
+    }
+    const LogdegDev &D = s->dev;
+    const int ncu = ctx->prop.multiProcessorCount;
+    const int nb = (int)D.nb;
+    if (nb > 64 || nb * (nb - 1) / 2 > TW * ncu) return tile_prepare_rounds(s);  // does not fit the register files
+    std::vector<WaveDesc> wd;
+    std::vector<WgDesc> gd;
+    int NWG = 0, U = SLOTS;
+    GL_TRY(tile_plan_fit(nb, ncu, forced, wd, gd, NWG, U));
+    if (NWG == 0) return GL_OK;
     return tile_finish(s, wd, gd, NWG, U, false);
+}
+
+// A batch of B graphs of one size (s: a session that stands for all of them -- dev.n of ONE graph, dev.nb / dev.ntiles and
+// every buffer B-fold, graph after graph): the decomposition of one graph on a B-th of the chip, replicated.  GL_OK with
+// s->tile == nullptr when it does not apply.
+int gl_tile_prepare_batch(gl_logdeg *s, int B) {
+    gl_ctx *ctx = s->ctx;
+    s->tile = nullptr;
+    if (const char *e = getenv("GRAPHLEARN_AMD_ENGINE"))
+        if (!strcmp(e, "stream") || !strcmp(e, "resident1")) return GL_OK;
+    const int ncu = ctx->prop.multiProcessorCount;
+    const int nb1 = (int)(s->dev.nb / B);
+    const int64_t ntiles1 = s->dev.ntiles / B;
+    if (B < 1 || nb1 * B != s->dev.nb || ncu / B < nb1) return GL_OK;
+    std::vector<WaveDesc> wd1;
+    std::vector<WgDesc> gd1;
+    int NWG1 = 0, U = SLOTS;
+    GL_TRY(tile_plan_fit(nb1, ncu / B, false, wd1, gd1, NWG1, U));
+    if (NWG1 == 0 || NWG1 > 64 * nb1) return GL_OK;
+    std::vector<WaveDesc> wd((size_t)B * NWG1 * TW);
+    std::vector<WgDesc> gd((size_t)B * NWG1);
+    for (int g = 0; g < B; ++g)
+        for (int q = 0; q < NWG1; ++q) {
+            WgDesc G = gd1[(size_t)q];
+            for (int k = 0; k < G.nblk; ++k) G.blk[k] += g * nb1;
+            if (G.own >= 0) G.own += g * nb1;
+            gd[(size_t)g * NWG1 + q] = G;
+            for (int v = 0; v < TW; ++v) {
+                WaveDesc w = wd1[(size_t)q * TW + v];
+                if (w.tile >= 0) w.tile += (int)(g * ntiles1), w.I += g * nb1, w.J += g * nb1;
+                if (w.fB >= 0) w.fB += g * nb1;
+                wd[((size_t)g * NWG1 + q) * TW + v] = w;
+            }
+        }
+    return tile_finish(s, wd, gd, B * NWG1, U, false, nb1, NWG1);
+}
+
+// 2 gamma z of every graph of the batch in the batch's own tiled buffer (devs: the sessions' device views, on the device)
+int gl_tile_batch_make_zg(gl_logdeg *s, const LogdegDev *devs_dev, int B) {
+    gl_tile *t = s->tile;
+    k_make_zg_batch<<<dim3((unsigned)t->ntiles1, (unsigned)B), dim3(256), 0, s->ctx->stream>>>(devs_dev, t->zg, s->dev.n, t->nb1, t->ntiles1,
+                                                                                          s->dev.g2);
+    GL_HIP(s->ctx, hipGetLastError());
+    t->zg_version = s->init_version;
+    return GL_OK;
 }
 
 bool gl_tile_writes_final_parity(const gl_logdeg *s) { return s->tile != nullptr && !s->tile->big; }
@@ -1894,6 +2086,7 @@ int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int fina
     gl_tile *t = s->tile;
     TileDev P = t->dev;
     const LogdegDev &D = s->dev;
+    if (t->batch && t->zg_version != s->init_version) return gl_set_error(ctx, GL_E_STATE, "internal: the batch's distances were not set");
     if (t->zg_version != s->init_version) {  // first launch since gl_logdeg_init: the distances or gamma may be new
         k_make_zg<<<dim3((unsigned)D.ntiles), dim3(256), 0, ctx->stream>>>(D.z, t->zg, D.n, D.nb, D.g2);
         GL_HIP(ctx, hipGetLastError());
@@ -1910,7 +2103,12 @@ int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int fina
     P.nm2 = (double)(D.n - 2);
     P.a4g = D.a4g;
     P.tol = tol;
-    if (tol > 0) norms = true;
+    P.nb1 = t->nb1;
+    P.NWG1 = t->NWG1;
+    P.ntiles1 = t->ntiles1;
+    P.t2hi = (1.05 * tol) * (1.05 * tol);
+    P.t2lo = tol * tol * (1 + 1e-9);
+    if (tol > 0 || t->batch) norms = true;
     P.it0 = s->it;
     P.maxit = (int)std::min<int64_t>(iters, 1 << 30);
     if (t->next_tag == 0u || t->next_tag > 0xE0000000u - (unsigned)P.maxit) {  // the tags would wrap into old ones
@@ -1937,7 +2135,16 @@ int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int fina
         else if (ragged) go(k_tile<UU, true, true, BB>);                                         \
         else go(k_tile<UU, false, true, BB>);                                                    \
     } while (0)
-    if (t->big && t->nt)
+#define GL_TILE_GO_BATCH(UU)                                                                     \
+    do {                                                                                         \
+        if (ragged) go(k_tile<UU, true, true, 0, true>);                                         \
+        else go(k_tile<UU, false, true, 0, true>);                                               \
+    } while (0)
+    if (t->batch) {
+        if (t->U == 32) GL_TILE_GO_BATCH(32);
+        else if (t->U == 16) GL_TILE_GO_BATCH(16);
+        else GL_TILE_GO_BATCH(8);
+    } else if (t->big && t->nt)
         GL_TILE_GO(32, 2);
     else if (t->big)
         GL_TILE_GO(32, 1);
@@ -1948,6 +2155,7 @@ int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int fina
     else
         GL_TILE_GO(8, 0);
 #undef GL_TILE_GO
+#undef GL_TILE_GO_BATCH
     GL_HIP(ctx, hipGetLastError());
     return GL_OK;
 }

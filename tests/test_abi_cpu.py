@@ -98,7 +98,7 @@ def test_tile_kernels_keep_their_pass_out_of_scratch():
     r = subprocess.run([os.path.join(ROOT, "tools", "build_tile.sh")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     rows = [l for l in r.stdout.splitlines() if "k_tile" in l]
-    assert len(rows) == 15, r.stdout          # 3 variants x (U = 8, 16, 32 and the two rounds forms)
+    assert len(rows) == 21, r.stdout          # 3 variants x (U = 8, 16, 32 and the two rounds forms) + the batch: 2 x (U = 8, 16, 32)
     for l in rows:
         f = l.split()
         name = f[0]
