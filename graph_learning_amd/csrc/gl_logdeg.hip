@@ -513,7 +513,7 @@ struct BatchState {
     int first;            // 1 until the call's first iteration is done (the rule is not evaluated for it, :156)
     int remaining;        // iterations this call may still run
     unsigned done_blocks; // workgroups of the current node pass that have finished ("last block" pattern)
-    int decide_here;      // 1: an iterate the screen cannot rule out is judged on the device (k_batch_dots .. k_batch_brackets
+    int decide_here;      // 1: an iterate the screen cannot rule out is judged on the device (k_batch_gram
                           // behind the node pass) instead of halting for the host
     int want_brackets;    // ... set by the screen for the kernels behind it, cleared by the last of them
     unsigned gram_blocks; // workgroups of the current k_batch_gram that have finished
@@ -774,14 +774,10 @@ __global__ __launch_bounds__(256) void k_pair_dots(const double *__restrict__ wa
 struct BatchPtrs {
     const double *w_new, *w_old, *d_new, *d_old;
 };
-// want != nullptr (inside a chunk of batched iterations): only when the screen of the node pass asked for the brackets, and
-// the operands' parity comes from the device (it_done[0] = iterations completed), ptrs holding both parities ([2][nprob]).
+// (the host's exact evaluation; inside a chunk of batched iterations k_batch_gram forms the same matrices on the matrix cores)
 __global__ __launch_bounds__(256) void k_batch_dots(const BatchPtrs *__restrict__ ptrs, const int2 *__restrict__ pairs,
-                                                    int64_t n_tiled, int64_t n_nodes, double *__restrict__ part,
-                                                    const int *want = nullptr, const long long *it_done = nullptr, int nprob = 0) {
+                                                    int64_t n_tiled, int64_t n_nodes, double *__restrict__ part) {
     __shared__ double sh[4][4];
-    if (want && want[0] == 0) return;
-    if (it_done) ptrs += (size_t)(it_done[0] & 1) * nprob;
     const int2 pr = pairs[blockIdx.x];  // pairs on grid x (up to B (B + 1) / 2 of them), blocks on y
     const BatchPtrs A = ptrs[pr.x], Bq = ptrs[pr.y];
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
@@ -812,10 +808,8 @@ __global__ __launch_bounds__(256) void k_batch_dots(const BatchPtrs *__restrict_
             ((sh[threadIdx.x][0] + sh[threadIdx.x][1]) + sh[threadIdx.x][2]) + sh[threadIdx.x][3];
 }
 // out[pair][q] = sum over the blocks of part[pair][block][q], fixed order
-__global__ void k_batch_dots_reduce(const double *__restrict__ part, int npairs, int blocks, double *__restrict__ out,
-                                    const int *want = nullptr) {
+__global__ void k_batch_dots_reduce(const double *__restrict__ part, int npairs, int blocks, double *__restrict__ out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (want && want[0] == 0) return;
     if (t >= npairs * 4) return;
     const int pr = t >> 2, q = t & 3;
     double acc = 0;
@@ -823,48 +817,12 @@ __global__ void k_batch_dots_reduce(const double *__restrict__ part, int npairs,
     out[t] = acc;
 }
 
-// The coupled rule judged on the device (inside a chunk of batched iterations, behind k_batch_dots and its reduce): the
-// four B x B Gram matrices go to LDS, wave q brackets lambda_max of matrix q by repeated squaring (gl_bracket.h; rigorous,
-// to ~1e-9 relative), and the rule of smooth_learning.py:166-167 is decided for every value the four spectral norms can
-// take: met -> every problem's done flag is raised (halt = 3: the host reports the exact values); surely not met -> the
-// batch goes on; a tie inside the brackets' width -> halt = 1, the host decides.  B <= 32.
-constexpr int BATCH_BRACKET_MAXB = 32;
-__global__ __launch_bounds__(256) void k_batch_brackets(const double *__restrict__ dots, const int2 *__restrict__ pairs, int npairs,
-                                                        const LogdegDev *__restrict__ devs, int nprob, double t2, BatchState *st) {
-    __shared__ double gA[4 * BATCH_BRACKET_MAXB * BATCH_BRACKET_MAXB];
-    __shared__ double br[8];
-    if (st->want_brackets == 0) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, B = nprob;
-    for (int k = tid; k < npairs; k += 256) {
-        const int2 pr = pairs[k];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) gA[(q * B + pr.x) * B + pr.y] = gA[(q * B + pr.y) * B + pr.x] = dots[(size_t)k * 4 + q];
-    }
-    __syncthreads();
-    {
-        double lo, hi;
-        if (B <= 16)
-            sm_lambda_bracket<4>(gA + wave * B * B, B, lane, lo, hi);
-        else
-            sm_lambda_bracket<16>(gA + wave * B * B, B, lane, lo, hi);
-        if (lane == 0) br[2 * wave] = lo, br[2 * wave + 1] = hi;
-    }
-    __syncthreads();
-    if (tid == 0) {  // {lo, hi} x {update, iterate, dual update, dual}
-        const double tp = t2 * (1 + 1e-9), tm = t2 * (1 - 1e-9);
-        const bool not_yet = br[0] > tp * br[3] || br[4] > tp * br[7];
-        const bool met = br[2] > 0 && br[6] > 0 && br[1] < tm * br[2] && br[5] < tm * br[6];
-        st->want_brackets = 0;
-        const int halt = met ? 3 : (not_yet ? 0 : 1);
-        if (halt) {
-            for (int a = 0; a < nprob; ++a) devs[a].ctr[0] = 1;
-            st->halt = halt;
-        }
-    }
-}
-
-// The same decision in ONE launch (inside a chunk of batched iterations): the four Gram matrices on the matrix cores, their
-// reduction and the brackets in the workgroup that finishes last.  G = sum over the entries e of a_e a_e' with a_e the B values
+constexpr int BATCH_BRACKET_MAXB = 32;  // (what k_batch_gram takes: two groups of 16 graphs)
+// The coupled rule judged on the device, in ONE launch inside a chunk of batched iterations: the four Gram matrices on the
+// matrix cores, their reduction and the brackets of their largest eigenvalues (gl_bracket.h; rigorous) in the workgroup that
+// finishes last.  The rule of smooth_learning.py:166-167 is decided for every value the four spectral norms can take: met ->
+// every problem's done flag is raised (halt = 3: the host reports the exact values); surely not met -> the batch goes on; a
+// tie inside the brackets' final width (1e-9) -> halt = 1, the host decides.  B <= 32.  G = sum over the entries e of a_e a_e' with a_e the B values
 // of entry e: v_mfma_f64_16x16x4_f64 takes four entries of 16 graphs at a time -- lane (i = l & 15, k = l >> 4) holds entry k of
 // graph i, which is its A operand (i, k) and its B operand (k, j = i) at once -- so a vector is read ONCE (k_batch_dots reads it
 // B + 1 times; at B = 20 its 210 pairs cost 45 us per iteration against 6 here).  NG groups of 16 graphs: B <= 16 NG.
@@ -889,6 +847,7 @@ __global__ __launch_bounds__(GRAM_WAVES * 64) void k_batch_gram(const BatchPtrs 
     __shared__ double br[8];
     __shared__ int s_last;
     if (st->want_brackets == 0) return;
+    const unsigned long long T0 = __builtin_amdgcn_s_memrealtime();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gi = lane & 15, kq = lane >> 4;
     const bool node_blk = blockIdx.x == gridDim.x - 1;
     const double *vn[NG], *vo[NG];
@@ -951,6 +910,7 @@ __global__ __launch_bounds__(GRAM_WAVES * 64) void k_batch_gram(const BatchPtrs 
 #pragma unroll
         for (int g = 0; g < NG; ++g) cn[g][0] = nn[g][0], cn[g][1] = nn[g][1], co[g][0] = no[g][0], co[g][1] = no[g][1];
     }
+    const unsigned long long T1 = __builtin_amdgcn_s_memrealtime();
     // waves -> workgroup: a fixed tree (wave w + h adds into wave w, h = 8, 4, 2, 1).  Element x of a block: lane x / 4,
     // register x % 4 -> row (lane >> 4) + 4 (x % 4), column lane & 15.
     for (int h = GRAM_WAVES / 2; h >= 1; h >>= 1) {
@@ -982,49 +942,63 @@ __global__ __launch_bounds__(GRAM_WAVES * 64) void k_batch_gram(const BatchPtrs 
     }
     __syncthreads();
     if (!s_last) return;
-    // ---- the last workgroup: the four B x B matrices {dW, W, dD, D} into LDS, brackets, decision (as k_batch_brackets).
+    const unsigned long long T2 = __builtin_amdgcn_s_memrealtime();
+    // ---- the last workgroup: the four B x B matrices {dW, W, dD, D} into LDS, brackets, decision.
     //      Thread = (matrix k, entry x), 2 NBLK x 256 of them in passes of 512.
+    typedef SmMfma<NG> MB;  // (the matrices padded to 16 NG rows of MB::LD doubles: gl_bracket.h)
+    static_assert(4 * MB::SIZE <= (GRAM_WAVES / 2) * SLOT, "the four padded matrices live in the reduction's LDS");
     double *gA = smem;
     const int B = nprob, ne = (int)gridDim.x - 1;
-    for (int kx = tid; kx < 2 * NBLK * 256; kx += GRAM_WAVES * 64) {
-        const int k = kx >> 8, x = kx & 255;
-        const int which = k / NBLK, b = k % NBLK;  // 0: update, 1: iterate
-        const int ln = x >> 2, r = x & 3;          // (the lane and register this entry came from)
+    for (int x = tid; x < 4 * MB::SIZE; x += GRAM_WAVES * 64) gA[x] = 0.0;
+    __syncthreads();
+    // (the workgroups' partials are read with sc1 loads -- written through by their owners before they were counted -- two
+    //  entries at a time; the loads of one thread are independent and stay in flight together)
+    typedef unsigned int bg_u4 __attribute__((ext_vector_type(4)));
+    const auto r_part = __builtin_amdgcn_make_buffer_rsrc((void *)part, 0, (int)((size_t)gridDim.x * 2 * NBLK * 256 * 8), 0x00020000);
+    auto two = [](bg_u4 g, double &a, double &b) {
+        a = __longlong_as_double((long long)(((unsigned long long)g.y << 32) | g.x));
+        b = __longlong_as_double((long long)(((unsigned long long)g.w << 32) | g.z));
+    };
+    for (int kp = tid; kp < 2 * NBLK * 128; kp += GRAM_WAVES * 64) {
+        const int k = kp >> 7, x = 2 * (kp & 127);  // entries x, x + 1 of matrix block k
+        const int which = k / NBLK, b = k % NBLK;   // 0: update, 1: iterate
+        const int ln = x >> 2, r = x & 3;           // (the lane and registers r, r + 1 these entries came from)
         const int row = (ln >> 4) + 4 * r + (b == 2 ? 16 : 0), col = (ln & 15) + (b >= 1 ? 16 : 0);
-        if (row >= B || col >= B) continue;
-        double ve = 0.0;
+        if (row >= B || col >= B) continue;          // (row + 4 >= B as well then)
+        double e0 = 0.0, e1 = 0.0;
 #pragma unroll 8
-        for (int blk = 0; blk < ne; ++blk)
-            ve += __hip_atomic_load(part + ((size_t)blk * 2 * NBLK + k) * 256 + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double vd = __hip_atomic_load(part + ((size_t)ne * 2 * NBLK + k) * 256 + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        gA[((which + 0) * B + row) * B + col] = ve;
-        gA[((which + 2) * B + row) * B + col] = vd;
-        if (b == 1) {  // (the off-diagonal block fills both triangles; the diagonal blocks are symmetric as computed)
-            gA[((which + 0) * B + col) * B + row] = ve;
-            gA[((which + 2) * B + col) * B + row] = vd;
+        for (int blk = 0; blk < ne; ++blk) {
+            double a, c;
+            two(__builtin_amdgcn_raw_buffer_load_b128(r_part, (int)((((size_t)blk * 2 * NBLK + k) * 256 + x) * 8), 0, 16), a, c);
+            e0 += a, e1 += c;
+        }
+        double d0, d1;
+        two(__builtin_amdgcn_raw_buffer_load_b128(r_part, (int)((((size_t)ne * 2 * NBLK + k) * 256 + x) * 8), 0, 16), d0, d1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rw = row + 4 * h;
+            if (rw >= B) break;
+            const double ve = h ? e1 : e0, vd = h ? d1 : d0;
+            gA[(which + 0) * MB::SIZE + rw * MB::LD + col] = ve;
+            gA[(which + 2) * MB::SIZE + rw * MB::LD + col] = vd;
+            if (b == 1) {  // (the off-diagonal block fills both triangles; the diagonal blocks are symmetric as computed)
+                gA[(which + 0) * MB::SIZE + col * MB::LD + rw] = ve;
+                gA[(which + 2) * MB::SIZE + col * MB::LD + rw] = vd;
+            }
         }
     }
     __syncthreads();
-    // brackets in stages of eight squarings (each halves the logarithmic width): an iterate clearly short of the rule -- most
-    // of them -- is decided after the first; the full 34 are only run out by a tie
+    const unsigned long long T3 = __builtin_amdgcn_s_memrealtime();
+    // brackets in stages (each squaring halves the logarithmic width; four, then six more at a time): an iterate clearly short
+    // of the rule -- most of them -- is decided after the first stage; the full 34 squarings are only run out by a tie
     __shared__ int s_dec;
     SmBracket S{};
-    if (wave < 4) {
-        if (B <= 16)
-            sm_bracket_begin<4>(gA + wave * B * B, B, lane, S);
-        else
-            sm_bracket_begin<16>(gA + wave * B * B, B, lane, S);
-    }
-    for (int round = 0; round < 5; ++round) {
+    if (wave < 4) MB::begin(gA + wave * MB::SIZE, lane, S);
+    for (int round = 0; round < 6; ++round) {
         if (wave < 4) {
             double lo, hi;
-            if (B <= 16) {
-                sm_bracket_advance<4>(gA + wave * B * B, B, lane, S, 8);
-                sm_bracket_bounds<4>(gA + wave * B * B, B, lane, S, lo, hi);
-            } else {
-                sm_bracket_advance<16>(gA + wave * B * B, B, lane, S, 8);
-                sm_bracket_bounds<16>(gA + wave * B * B, B, lane, S, lo, hi);
-            }
+            MB::advance(gA + wave * MB::SIZE, lane, S, round == 0 ? 4 : 6);
+            MB::bounds(gA + wave * MB::SIZE, lane, S, lo, hi);
             if (lane == 0) br[2 * wave] = lo, br[2 * wave + 1] = hi;
         }
         __syncthreads();
@@ -1038,6 +1012,8 @@ __global__ __launch_bounds__(GRAM_WAVES * 64) void k_batch_gram(const BatchPtrs 
         if (s_dec != 1) break;  // (1: undecided at this width)
     }
     if (tid == 0) {
+        const unsigned long long T4 = __builtin_amdgcn_s_memrealtime();
+        st->diag[0] += (double)(T1 - T0), st->diag[1] += (double)(T2 - T1), st->diag[2] += (double)(T3 - T2), st->diag[3] += (double)(T4 - T3);
         st->want_brackets = 0;
         st->gram_blocks = 0u;
         const int halt = s_dec;
@@ -2027,6 +2003,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                 GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 keep = slot[0] == 0.0;
             }
+            if (getenv("GRAPHLEARN_AMD_BATCH_TEST_OVERSHOOT")) keep = false;  // (test hook: as if the screen had overshot)
             if (getenv("GRAPHLEARN_AMD_BATCH_DEBUG"))
                 fprintf(stderr, "[batch cruise] n %lld B %d: ran %lld of %lld, stopped %d, not resident %d, kept %d\n", (long long)sessions[0]->n, B,
                         (long long)ran, (long long)(maxit - 1), (int)stopped, (int)not_resident, (int)keep);
@@ -2144,6 +2121,11 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
     }
     GL_TRY(rearm());  // the done flags belong to this call's screen
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (getenv("GRAPHLEARN_AMD_BATCH_DEBUG")) {
+        GL_HIP(ctx, hipMemcpy(st_host, st_dev, sizeof(BatchState), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[batch gram, last workgroup, 10 ns ticks summed] loop %.0f  tree+store+count %.0f  reduce %.0f  brackets %.0f\n", st_host->diag[0],
+                st_host->diag[1], st_host->diag[2], st_host->diag[3]);
+    }
     if (!have_exact && n_iter > 1) {  // the values the caller sees; the budget's last iteration is judged like any other (:166-167)
         GL_TRY(exact(rp, rd));
         if (rp < tol && rd < tol) converged = true;

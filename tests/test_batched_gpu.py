@@ -119,6 +119,49 @@ def test_batched_launch_path_chunks_and_budget(chunk, monkeypatch):
     np.testing.assert_allclose(out, ref, rtol=0, atol=1e-10)
 
 
+@pytest.mark.parametrize("n,b,hook", [(256, 8, None), (256, 20, None), (160, 30, None), (1000, 3, None), (256, 8, "overshoot"),
+                                      (256, 8, "not_resident"), (256, 8, "off"), (300, 20, "no_room")])
+def test_batched_cruise_on_the_tile_engine(n, b, hook, monkeypatch, capfd):
+    """Above n = 128 a batched call first cruises on the tile engine: the B graphs as ONE block-diagonal lattice in one
+    persistent launch (k_tile<..., BATCH>), stopped by the screen of the coupled rule (lambda_max of a Gram matrix lies in
+    [max diagonal, trace], smooth_learning.py:158-159,166-167) with 5 % to spare; the chunked launches with the exact
+    spectral norms (Gram matrices on f64 MFMA, k_batch_gram) finish the run.  Same stopping iteration and iterates as the
+    oracle's 2-D branch for: the headline case; 80 node blocks in total and two groups of 16 graphs (256, 20); thirty graphs
+    of three node blocks on eight CUs each; a large graph; a cruise whose result is
+    discarded (the screen overshot: redone from the sessions' own state); workgroups that are not co-resident; the cruise
+    switched off; a batch the chip has no room for (300 nodes x 20 graphs: one graph needs 14 workgroups, has 12 CUs)."""
+    monkeypatch.setenv("GRAPHLEARN_AMD_BATCH_DEBUG", "1")
+    if hook == "overshoot":
+        monkeypatch.setenv("GRAPHLEARN_AMD_BATCH_TEST_OVERSHOOT", "1")
+    if hook == "not_resident":
+        monkeypatch.setenv("GRAPHLEARN_AMD_RES_TEST_NOT_RESIDENT", "1")
+    if hook == "off":
+        monkeypatch.setenv("GRAPHLEARN_AMD_BATCH_NO_CRUISE", "1")
+    rng = default_rng(1000 * n + b)
+    z = rng.uniform(0.1, 3.0, size=(b, n * (n - 1) // 2))
+    maxit = 300 if n < 1000 else 120
+    ref, info = old.learn_log_degrees(z, 1.1, 0.9, maxit=maxit, tol=1e-4, edge_tol=-np.inf, return_info=True)
+    out, got = gsp_learn_graph_log_degrees(z, 1.1, 0.9, maxit=maxit, tol=1e-4, edge_tol=-np.inf, return_info=True)
+    err = capfd.readouterr().err
+    cruised = [l for l in err.splitlines() if l.startswith("[batch cruise]")]
+    if hook in ("off", "no_room"):
+        assert not cruised
+    else:
+        assert len(cruised) == 1 and f"n {n} B {b}:" in cruised[0]
+        kept = cruised[0].rstrip().endswith("kept 1")
+        assert kept == (hook is None), cruised[0]
+        if hook is None:
+            ran = int(cruised[0].split("ran ")[1].split()[0])
+            assert 0.5 * info["n_iter"] < ran < info["n_iter"], cruised[0]   # most of the run, never the iteration that stops it
+    assert got["n_iter"] == info["n_iter"] and got["converged"] == (info["n_iter"] < maxit)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-10)
+    assert got["rel_primal"] == pytest.approx(info["rel"][0], rel=1e-8)
+    assert got["rel_dual"] == pytest.approx(info["rel"][1], rel=1e-8)
+    # a second call on the cached stand-in session: bit-identical
+    out2 = gsp_learn_graph_log_degrees(z, 1.1, 0.9, maxit=maxit, tol=1e-4, edge_tol=-np.inf)
+    assert np.array_equal(out, out2)
+
+
 def test_batch_gram_entry_point():
     """gl_logdeg_batch_gram (diagnostic entry point): the four B x B Gram matrices of the last iteration."""
     import ctypes as C
