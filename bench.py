@@ -76,6 +76,7 @@ def other_configs(ctx):
                (gl_lgmrf_time_node_updates); every QP runs its 100 ADMM steps on this input.
     graphdict  BASELINE configs[4]: GraphDictLog K=8, n=1024, T=4096: ms per primal-dual step, fp64 (what the reference
                computes) and fp32 contractions (what the config names).
+    batched_n256    the 2-D branch (B = 8 graphs of n = 256): us per iteration of the bare loop and of a run to tol.
     logmodel_n8192  the headline loop on a lattice four times as large (SURVEY section 8 row d quotes the roofline for
                n >= 4096): time per iteration and its fraction of 24 E bytes / 8 TB/s."""
     import numpy as np
@@ -139,6 +140,23 @@ def other_configs(ctx):
                                "ms_per_cycle_projected": dtm * 1e3 / nodes * n, "dtype": "f64"}
     except Exception as exc:
         out["lgmrf_error"] = repr(exc)
+    try:  # the 2-D (batched) branch above n = 128: cruise on the tile engine, deciding stretch on batched launches
+        from graph_learning_amd import gsp_learn_graph_log_degrees
+        n, b = 256, 8
+        z = np.random.default_rng(n).uniform(0.2, 3.0, size=(b, n * (n - 1) // 2))
+        gsp_learn_graph_log_degrees(z, 1, 1, maxit=100, tol=0.0)      # code objects, the cruise's stand-in session
+        t0 = time.perf_counter(); gsp_learn_graph_log_degrees(z, 1, 1, maxit=0); t_setup = time.perf_counter() - t0
+        t0 = time.perf_counter(); gsp_learn_graph_log_degrees(z, 1, 1, maxit=2000, tol=0.0); t_bare = time.perf_counter() - t0 - t_setup
+        t0 = time.perf_counter()
+        _, info = gsp_learn_graph_log_degrees(z, 1, 1, maxit=20000, tol=1e-6, return_info=True)
+        t_tol = time.perf_counter() - t0 - t_setup
+        out["batched_n256"] = {"workload": "gsp_learn_graph_log_degrees on a (8, E) matrix, n=256 (WindowLogModel / M-step shape), "
+                                           "coupled spectral-norm rule (smooth_learning.py:158-159)", "dtype": "f64",
+                               "us_per_iteration_bare_loop": t_bare / 2000 * 1e6, "to_tol_1e-6": {"iterations": int(info["n_iter"]),
+                               "converged": bool(info["converged"]), "us_per_iteration": t_tol / max(int(info["n_iter"]), 1) * 1e6},
+                               "timing": "host wall clock around the call minus the same call with maxit=0 (uploads, set-up)"}
+    except Exception as exc:
+        out["batched_error"] = repr(exc)
     try:  # a lattice four times the headline's: what does not fit the register files streams (rounds)
         n = 8192
         e = n * (n - 1) // 2
