@@ -810,6 +810,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     double rel_p = INFINITY, rel_d = INFINITY;
     const bool rule_on = P.tol > 0;
     bool evaluated = false, exact = false;
+    double screen_prev = INFINITY;  // BATCH: the screen's figure of the previous iteration (wave TW - 1)
 
     // (wave TW - 1) one norm record per node block, lane = block
     auto norms_of = [&](int j, double (&b)[4]) -> bool {  // sums of the records of local iteration j
@@ -952,14 +953,20 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 double rp = INFINITY, rd = INFINITY;
                 if constexpr (BATCH) {
                     // The batch runs while the screen RULES OUT the coupled rule with 5 % to spare (the lower bound of one of
-                    // the two ratios above 1.05 tol) and ends at the first iteration where it does not: the exact spectral norms
+                    // the two ratios above 1.05 tol, now and extrapolated one iteration ahead) and ends at the first iteration where it does not: the exact spectral norms
                     // are the host's business from there on.  Should the lower bounds of that very iteration already lie below
                     // tol (a drop of 5 % in one iteration, or a start from a converged iterate) the rule may have held for
                     // an iterate these registers no longer hold: reported (rp = 1), and the caller redoes the run its own way.
                     good = good && screen_of(it - 1, b);
                     if (good && P.it0 + it - 1 >= 1) {  // never at iteration 0 (:156-161)
                         const bool degenerate = !(b[1] > 0) || !(b[3] > 0);
-                        const bool not_yet = !degenerate && (b[0] > P.t2hi * b[1] || b[2] > P.t2hi * b[3]);
+                        // how far the larger lower bound is above tol (squared): the cruise goes on while it has 5 % to spare
+                        // now AND, extrapolated by its last step's factor, after the next iteration (early in a run, and
+                        // on inputs that converge geometrically, one step is more than 5 %)
+                        const double rk = degenerate ? 0.0 : fmax(b[0] / b[1], b[2] / b[3]) / P.t2lo;
+                        const double next = (screen_prev > rk && screen_prev < INFINITY) ? rk * (rk / screen_prev) : rk;
+                        const bool not_yet = !degenerate && rk > 1.05 * 1.05 && next > 1.05 * 1.05;
+                        screen_prev = rk;
                         const bool surely_not = !degenerate && (b[0] > P.t2lo * b[1] || b[2] > P.t2lo * b[3]);
                         stop = not_yet ? 0 : 1;
                         rp = surely_not ? 0.0 : 1.0;
