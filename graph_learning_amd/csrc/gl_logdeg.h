@@ -63,6 +63,7 @@ struct gl_logdeg {
     int wpc = 8;                  // edge waves per CU
     gl_resident *res = nullptr;   // first resident engine (gl_resident.hip: grid barriers), null when not applicable
     gl_tile *tile = nullptr;      // tile engine (gl_tile.hip: tagged hand-offs), preferred when it applies
+    bool engines_ready = false;   // gl_resident_prepare / gl_tile_prepare have run (at the first own iterate call)
     bool res_unchecked = false;   // an asynchronous resident launch has not had its error word read yet
     int64_t res_pending = 0;      // ... and this many iterations were asked of the unchecked launches together
     double tol_dev = 0.0;         // the tolerance word the streaming kernels see (dstat[2]) ...

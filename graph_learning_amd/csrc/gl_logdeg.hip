@@ -1193,9 +1193,10 @@ GL_API int gl_logdeg_create(gl_ctx *ctx, int64_t n_nodes, gl_logdeg **out) {
     s->stage = s->stage_rec + 8;  // the 64-byte record header of the gather payload sits right in front (wire format)
     D.col_ptr = s->col_ptr;
     D.seg_dest = s->seg_dest;
+    // (the persistent engines are prepared at the session's first own iterate call -- ensure_engines --: the sessions of a
+    //  batch, which runs on the batch's own stand-in, never pay for their decomposition, allocation and upload)
     if ((rc = gl_h2d(ctx, s->col_ptr, ptr.data(), ptr.size() * sizeof(int))) != GL_OK ||
-        (rc = gl_h2d(ctx, s->seg_dest, dest.data(), dest.size() * sizeof(int))) != GL_OK ||
-        (rc = gl_resident_prepare(s)) != GL_OK || (rc = gl_tile_prepare(s)) != GL_OK) {
+        (rc = gl_h2d(ctx, s->seg_dest, dest.data(), dest.size() * sizeof(int))) != GL_OK) {
         gl_logdeg_destroy(s);
         return rc;
     }
@@ -1359,6 +1360,14 @@ GL_API int gl_logdeg_init(gl_logdeg *s, double alpha, double beta, double step_s
 
 // The resident engine (gl_resident.hip) takes over when it applies and the call is long enough
 // to amortise loading / storing the register-held iterate.  GRAPHLEARN_AMD_ENGINE=stream disables it.
+static int ensure_engines(gl_logdeg *s) {
+    if (s->engines_ready) return GL_OK;
+    s->engines_ready = true;  // (also after a failure: the streaming engine serves the session then)
+    GL_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    GL_TRY(gl_resident_prepare(s));
+    GL_TRY(gl_tile_prepare(s));
+    return GL_OK;
+}
 static bool use_small(const gl_logdeg *s, int64_t iters) { return iters >= 8 && gl_small_applicable(s); }
 // (a call of the tile engine costs ~30 us beyond its iterations -- loading w and half of z, storing w -- and 5-7 us per
 //  iteration, the streaming engine 10-40 us per iteration: from four iterations on the tile engine is never slower)
@@ -1421,6 +1430,7 @@ GL_API int gl_logdeg_iterate_async(gl_logdeg *s, int64_t n_iter) {
     if (n_iter < 0) return gl_set_error(ctx, GL_E_INVALID, "n_iter < 0");
     GL_HIP(ctx, hipSetDevice(ctx->device));
     GL_TRY(set_tol(s, 0.0));
+    GL_TRY(ensure_engines(s));
     if (use_small(s, n_iter)) {  // tol = 0 never stops: the iteration count is known now
         GL_TRY(gl_small_launch(s, n_iter, 0.0));
         GL_HIP(ctx, hipMemsetAsync(s->dev.ctr, 0, 2 * 8, ctx->stream));
@@ -1458,6 +1468,7 @@ GL_API int gl_logdeg_iterate(gl_logdeg *s, int64_t maxit, double tol, int64_t *n
     GL_TRY(resident_check(s));
     LogdegDev &D = s->dev;
     GL_TRY(set_tol(s, tol));
+    GL_TRY(ensure_engines(s));
     if (use_small(s, maxit)) {
         double *st = (double *)ctx->pinned;
         long long *ct = (long long *)(st + 8);
@@ -2145,6 +2156,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
 // session state is unchanged.
 GL_API int gl_logdeg_engine(gl_logdeg *s) {
     if (!s) return 0;
+    (void)ensure_engines(s);
     if (s->inited && gl_small_applicable(s)) return 2;
     return s->tile ? 3 : (s->res ? 1 : 0);
 }
