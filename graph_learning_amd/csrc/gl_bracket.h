@@ -96,7 +96,10 @@ struct SmMfma {
         tr = wave_sum(tr);
         S.tr = tr, S.L = 0.0, S.wgt = 0.5, S.k = 0, S.done = !(tr > 0.0);
         if (S.done) return;
-        for (int idx = lane; idx < SIZE; idx += 64) A[idx] = A[idx] / tr;
+        // (a reciprocal instead of SIZE / 64 divisions per lane: the scaling is off by an ulp, twelve orders below the
+        //  bracket's safety factors, and so is the one by 1 / t below)
+        const double rt = 1.0 / tr;
+        for (int idx = lane; idx < SIZE; idx += 64) A[idx] = A[idx] * rt;
     }
     static __device__ __forceinline__ void advance(double *A, int lane, SmBracket &S, int steps) {
         const int r = lane & 15, q4 = lane >> 4;
@@ -123,12 +126,13 @@ struct SmMfma {
                 for (int e = 0; e < 4; ++e)
                     if (q4 + 4 * e == r) dsum += acc[bi][bi][e];
             const double t = wave_sum(dsum);  // in (1/B, 1]
+            const double rt = 1.0 / t;
 #pragma unroll
             for (int bi = 0; bi < NB16; ++bi)
 #pragma unroll
                 for (int bj = 0; bj < NB16; ++bj)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) A[(16 * bi + q4 + 4 * e) * LD + 16 * bj + r] = acc[bi][bj][e] / t;
+                    for (int e = 0; e < 4; ++e) A[(16 * bi + q4 + 4 * e) * LD + 16 * bj + r] = acc[bi][bj][e] * rt;
             S.L += S.wgt * log(t);
             S.wgt *= 0.5;
             ++S.k;
