@@ -127,7 +127,17 @@ __global__ __launch_bounds__(256) void k_matvec(const double *__restrict__ A, co
     if (row >= n) return;
     const double *a = A + row * n;
     double acc = 0;
-    for (int64_t j = lane; j < n; j += 64) acc += a[j] * x[j];
+    if ((n & 1) == 0) {  // (rows start 16-byte aligned: two entries per load, two chains)
+        double acc2 = 0;
+        for (int64_t j = 2 * lane; j < n; j += 128) {
+            const double2 av = *reinterpret_cast<const double2 *>(a + j), xv = *reinterpret_cast<const double2 *>(x + j);
+            acc += av.x * xv.x;
+            acc2 += av.y * xv.y;
+        }
+        acc += acc2;
+    } else {
+        for (int64_t j = lane; j < n; j += 64) acc += a[j] * x[j];
+    }
     acc = wsum(acc);
     if (lane == 0) y[row] = acc;
 }
@@ -555,11 +565,11 @@ __global__ __launch_bounds__(NT) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u
         const double guu = D.G[u_fast * n + u_fast];
         for (int r = 0; r < min(nrows, RLDS); ++r) {
             const int64_t i = r0 + r;
-            const double gi = D.gcol[i];
+            const double gq = D.gcol[i] / guu;  // (one quotient per row: a division per entry cost this prologue 5 us per launch)
             const double *grow = D.G + i * n;
             for (int j = tid; j < (int)n; j += NT) {
                 double w = (i == j) ? 1.0 : 0.0;
-                if (i != u_fast && j != u_fast) w -= D.rho * (grow[j] - (gi * D.gcol[j]) / guu);
+                if (i != u_fast && j != u_fast) w -= D.rho * (grow[j] - gq * D.gcol[j]);
                 s_W[r * (int)n + j] = w;
             }
         }
@@ -573,7 +583,7 @@ __global__ __launch_bounds__(NT) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u
         for (int r = 0; r < RREG; ++r) {
             const int64_t i = r0 + RLDS + r;
             const bool row = RLDS + r < nrows;
-            const double gi = (row && u_fast >= 0) ? D.gcol[i] : 0.0;
+            const double gq = (row && u_fast >= 0) ? D.gcol[i] / guu : 0.0;
 #pragma unroll
             for (int c = 0; c < CPT; ++c) {
                 const int64_t j = tid + NT * (int64_t)c;
@@ -581,7 +591,7 @@ __global__ __launch_bounds__(NT) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u
                 if (row && j < n) {
                     if (u_fast >= 0) {
                         w = (i == j) ? 1.0 : 0.0;
-                        if (i != u_fast && j != u_fast) w -= D.rho * (D.G[i * n + j] - (gi * D.gcol[j]) / guu);
+                        if (i != u_fast && j != u_fast) w -= D.rho * (D.G[i * n + j] - gq * D.gcol[j]);
                     } else {
                         w = D.W[i * n + j];
                     }
