@@ -620,7 +620,7 @@ __global__ __launch_bounds__(NT) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u
         uo = D.uu[i];
         pi = D.p[i];
         on = D.act[i];
-        if (!(test_missing && blockIdx.x == 0)) publish(0, i, D.v[i], tag0);  // the input of step 0
+        if (!((test_missing & 1) && blockIdx.x == 0)) publish(0, i, D.v[i], tag0);  // the input of step 0
     }
     lg_u4 pr[4][3];  // wave 0: the partials {dx2, x2 | xm, dz2 | z2, zm} of workgroups lane, lane + 64, ...
     bool pending = false;
@@ -645,7 +645,11 @@ __global__ __launch_bounds__(NT) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u
                 }
                 asm volatile("" ::: "memory");  // the loads stay in the loop
                 if (__all(ok)) break;
-                __builtin_amdgcn_s_sleep(4);  // ~0.1 us: leave the fabric to the stores we wait for
+                // ~0.1 us: leave the fabric to the stores we wait for (development: GRAPHLEARN_AMD_LGMRF_POLL = 1 / 2 / 3)
+                const int pm = test_missing >> 1;
+                if (pm == 0) __builtin_amdgcn_s_sleep(4);
+                else if (pm == 1) __builtin_amdgcn_s_sleep(1);
+                else if (pm == 3) __builtin_amdgcn_s_sleep(12);
                 if ((spins & 63u) == 63u &&
                     (gl_ld_u32(err) != 0u || __builtin_amdgcn_s_memrealtime() - t_start > 100000000ull)) {
                     good = false;  // 1 s: a producer is not on the chip
@@ -1546,12 +1550,12 @@ int run_admm_res(gl_ctx *ctx, const LgDev &D, AdmmRes &A, int max_iter, int64_t 
         const unsigned tag0 = A.next_tag;
         A.next_tag += (unsigned)max_iter + 2u;
         // error word: bar[32], zero since the allocation (a failure ends the use of this form)
+        static const int poll_mode = getenv("GRAPHLEARN_AMD_LGMRF_POLL") ? atoi(getenv("GRAPHLEARN_AMD_LGMRF_POLL")) : 0;
+        const int flags = (test_not_resident ? 1 : 0) | (poll_mode << 1);
         if (A.wide)
-            k_lg_admm_tag<512, 8><<<dim3((unsigned)A.nwg), 512, A.lds, ctx->stream>>>(D, A.bar + 32, A.gran, tag0, A.R, max_iter, u_fast,
-                                                                                      test_not_resident ? 1 : 0);
+            k_lg_admm_tag<512, 8><<<dim3((unsigned)A.nwg), 512, A.lds, ctx->stream>>>(D, A.bar + 32, A.gran, tag0, A.R, max_iter, u_fast, flags);
         else
-            k_lg_admm_tag<256, 0><<<dim3((unsigned)A.nwg), 256, A.lds, ctx->stream>>>(D, A.bar + 32, A.gran, tag0, A.R, max_iter, u_fast,
-                                                                                      test_not_resident ? 1 : 0);
+            k_lg_admm_tag<256, 0><<<dim3((unsigned)A.nwg), 256, A.lds, ctx->stream>>>(D, A.bar + 32, A.gran, tag0, A.R, max_iter, u_fast, flags);
         GL_HIP(ctx, hipGetLastError());
         return GL_OK;
     }

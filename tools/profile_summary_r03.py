@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir = os.path.join(ROOT, "profiles")
 n = 4096
 algo = 12 * n * (n - 1)
-TIMED = "k_tile<32, true, false, 0>"     # the instantiation bench.py's timed call launches (U = 32, no norms)
+TIMED = "k_tile<32, true, false, 0, false>"     # the instantiation bench.py's timed call launches (U = 32, no norms)
 
 
 def one(d, suffix):

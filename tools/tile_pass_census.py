@@ -3,7 +3,7 @@
 usage: python tools/tile_pass_census.py [--kernel ILi32ELb1ELb0ELi0E] [--out profiles/r03_tile_census.json]
 
 Compiles graph_learning_amd/csrc/gl_tile.hip with the Makefile's flags plus -save-temps (tools/build_tile.sh), takes the
-kernel bench.py times (k_tile<32, true, false, 0>: U = 32, no norms), and counts the instructions of the basic blocks that
+kernel bench.py times (k_tile<32, true, false, 0, false>: U = 32, no norms), and counts the instructions of the basic blocks that
 make up the unrolled pass (the blocks holding the v_max_f64 of `p = max(0, .)`, 64 per pass) by class.  bench.py prices the
 pass's fp64 vector instructions against the fp64 VALU issue rate (MI355X: 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz
 = 39.3 T lane-operations/s, i.e. the 78.6 TFLOP/s spec with an FMA counted twice) -- the roof that binds this kernel.
@@ -62,7 +62,7 @@ for b in pass_blocks:
 nmax = sum(sum("v_max_f64" in l for l in b) for b in pass_blocks)
 assert nmax == 64, f"expected the 64 v_max_f64 of one pass (32 row pairs x 2 edges per lane), found {nmax}"
 src = open(os.path.join(ROOT, "graph_learning_amd", "csrc", "gl_tile.hip"), "rb").read()
-out = {"kernel": m.group(1), "kernel_demangled": "k_tile<32, true, false, 0> (U = 32, write-back mask only, no norms)",
+out = {"kernel": m.group(1), "kernel_demangled": "k_tile<32, true, false, 0, false> (U = 32, write-back mask only, no norms, single graph)",
        "source_sha16": hashlib.sha256(src).hexdigest()[:16], "row_pairs_per_pass": 32, "edges_per_lane_and_row_pair": 2,
        "per_pass": tot, "per_row_pair": {k: v / 32.0 for k, v in tot.items()},
        "fp64_valu_peak_lane_ops_per_s": 256 * 4 * 16 * 2.4e9,
