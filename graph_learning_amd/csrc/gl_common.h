@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "graphlearn_amd.h"
 
@@ -34,11 +35,23 @@ struct gl_ctx {
     // the batched solver's stand-in session for the tile engine (gl_logdeg.hip: BatchCruise), kept for the next call
     void *batch_cruise = nullptr;
     void (*batch_cruise_free)(void *) = nullptr;
+    // released device blocks of the sessions, kept for the next session of the same size (gl_ctx_alloc / gl_ctx_release):
+    // a batch of windows creates and destroys a session per graph, and hipFree alone cost 0.3 ms each
+    struct PoolBlock {
+        void *p;
+        size_t bytes;
+    };
+    std::vector<PoolBlock> pool;
+    size_t pool_bytes = 0;
 };
 
 // At least `bytes` of device scratch, valid until the next gl_ctx_scratch call on this context (the stream is in
 // order and the batched entry points return synchronised, so consecutive calls may reuse it).
 int gl_ctx_scratch(gl_ctx *ctx, size_t bytes, void **out);
+// Device blocks that outlive their session: a released block serves the next request of exactly its size.  Everything runs
+// on the context's one stream, so reuse is ordered behind the previous owner's work without a synchronisation.
+int gl_ctx_alloc(gl_ctx *ctx, size_t bytes, void **out);
+void gl_ctx_release(gl_ctx *ctx, void *p, size_t bytes);
 
 int gl_set_error(gl_ctx *ctx, int code, const char *fmt, ...);
 

@@ -80,6 +80,7 @@ GL_API int gl_ctx_destroy(gl_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->batch_cruise && ctx->batch_cruise_free) ctx->batch_cruise_free(ctx->batch_cruise);
+    for (const gl_ctx::PoolBlock &b : ctx->pool) (void)hipFree(b.p);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -87,6 +88,38 @@ GL_API int gl_ctx_destroy(gl_ctx *ctx) {
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return GL_OK;
+}
+
+int gl_ctx_alloc(gl_ctx *ctx, size_t bytes, void **out) {
+    for (size_t k = ctx->pool.size(); k-- > 0;)
+        if (ctx->pool[k].bytes == bytes) {
+            *out = ctx->pool[k].p;
+            ctx->pool_bytes -= bytes;
+            ctx->pool.erase(ctx->pool.begin() + (long)k);
+            return GL_OK;
+        }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess && !ctx->pool.empty()) {  // (the pool holds memory somebody needs in another size)
+        (void)hipStreamSynchronize(ctx->stream);
+        for (const gl_ctx::PoolBlock &b : ctx->pool) (void)hipFree(b.p);
+        ctx->pool.clear();
+        ctx->pool_bytes = 0;
+        e = hipMalloc(out, bytes);
+    }
+    if (e != hipSuccess) return gl_set_error(ctx, GL_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return GL_OK;
+}
+
+void gl_ctx_release(gl_ctx *ctx, void *p, size_t bytes) {
+    if (!p) return;
+    constexpr size_t cap = (size_t)8 << 30;  // (what the pool may hold; beyond it blocks are freed as before)
+    if (ctx->pool_bytes + bytes > cap || ctx->pool.size() >= 4096) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(p);
+        return;
+    }
+    ctx->pool.push_back(gl_ctx::PoolBlock{p, bytes});
+    ctx->pool_bytes += bytes;
 }
 
 GL_API const char *gl_last_error(gl_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }

@@ -41,6 +41,7 @@ struct gl_logdeg {
     int64_t n = 0, n_edges = 0;
     void *arena = nullptr;        // the one allocation every fixed-size buffer of the session is carved from
     void *sig_arena = nullptr;    // zsq, theta_terms and xdev (set_signals only), one allocation too
+    size_t arena_bytes = 0, sig_bytes = 0;  // (both blocks go back to the context's pool: gl_ctx_release)
     double *zsq = nullptr;        // n x n squared distances (set_signals only)
     double *stage = nullptr;      // device staging for condensed host transfers (E doubles)
     double *stage_rec = nullptr;  // = stage - 8 doubles: room for the 64-byte record header of the gather payload

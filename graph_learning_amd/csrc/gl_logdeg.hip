@@ -1177,11 +1177,11 @@ GL_API int gl_logdeg_create(gl_ctx *ctx, int64_t n_nodes, gl_logdeg **out) {
         {(void **)&D.colslab, (size_t)std::max(s->n_segments, 1) * 2 * GL_TB * 8}};
     size_t total = 0;
     for (const Part &q : parts) total += (q.bytes + 255) / 256 * 256;
-    hipError_t e = hipMalloc(&s->arena, total);
-    if (e != hipSuccess) {
+    if ((rc = gl_ctx_alloc(ctx, total, &s->arena)) != GL_OK) {  // (a block of this size released by an earlier session, or hipMalloc)
         delete s;
-        return gl_set_error(ctx, GL_E_NOMEM, "hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
+        return rc;
     }
+    s->arena_bytes = total;
     {
         char *at = (char *)s->arena;
         for (const Part &q : parts) {
@@ -1214,9 +1214,14 @@ GL_API int gl_logdeg_destroy(gl_logdeg *s) {
     drop_graph(s);
     gl_resident_free(s);
     gl_tile_free(s);
-    void *ptrs[] = {s->arena, s->sig_arena, s->square_out};
-    for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+    if (s->ctx) {  // (kept by the context for the next session of this size)
+        gl_ctx_release(s->ctx, s->arena, s->arena_bytes);
+        gl_ctx_release(s->ctx, s->sig_arena, s->sig_bytes);
+    } else {
+        if (s->arena) (void)hipFree(s->arena);
+        if (s->sig_arena) (void)hipFree(s->sig_arena);
+    }
+    if (s->square_out) (void)hipFree(s->square_out);
     delete s;
     return GL_OK;
 }
@@ -1252,15 +1257,13 @@ GL_API int gl_logdeg_set_signals(gl_logdeg *s, const double *x, int64_t d, int64
     GL_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t xe = d * s->n;
     if (s->xdev_elems < xe || !s->zsq) {  // signals, squared distances and the theta terms in one allocation
-        if (s->sig_arena) {
-            GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            (void)hipFree(s->sig_arena);
-        }
+        gl_ctx_release(ctx, s->sig_arena, s->sig_bytes);
         s->sig_arena = nullptr;
         s->xdev = s->zsq = s->theta_terms = s->gram_diag = nullptr;
         s->xdev_elems = 0;
         const size_t bz = ((size_t)s->n * s->n * 8 + 255) / 256 * 256, bt = ((size_t)3 * s->n * 8 + 255) / 256 * 256;
-        GL_HIP(ctx, hipMalloc(&s->sig_arena, bz + bt + (size_t)2 * xe * 8));  // x and its centred copy
+        s->sig_bytes = bz + bt + (size_t)2 * xe * 8;  // x and its centred copy
+        GL_TRY(gl_ctx_alloc(ctx, s->sig_bytes, &s->sig_arena));
         s->zsq = (double *)s->sig_arena;
         s->theta_terms = (double *)((char *)s->sig_arena + bz);
         s->gram_diag = s->theta_terms + 2 * s->n;
@@ -1270,9 +1273,10 @@ GL_API int gl_logdeg_set_signals(gl_logdeg *s, const double *x, int64_t d, int64
     GL_TRY(gl_h2d(ctx, s->xdev, x, (size_t)xe * 8));
     GL_TRY(gl_gram_distances(ctx, s->xdev, s->xdev + s->xdev_elems, d, s->n, s->zsq, s->gram_diag));
     double theta = 1.0;
-    // theta_out == NULL: the caller fetches theta later (gl_logdeg_theta); for n <= 128 it then never leaves the
-    // device before the distances are scaled, and a batch of windows goes through without a round trip each
-    const bool deferred = !theta_out && avg_degree > 0 && s->n <= 128;
+    // theta_out == NULL: the caller fetches theta later (gl_logdeg_theta); it then never leaves the device before the
+    // distances are scaled, and a batch of windows goes through without a round trip each (the finish of a large graph's
+    // theta by one thread costs tens of microseconds: only below 2048 nodes)
+    const bool deferred = !theta_out && avg_degree > 0 && s->n <= 2048;
     s->theta_pending = deferred;
     if (deferred) {
         double *theta_dev = s->dev.dstat + 4;
@@ -2068,7 +2072,10 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
     };
     // (the launches carry the parity of their iteration: one captured chunk per form and per parity of its first iteration;
     //  a chunk that is halted half way leaves the next one to start on either)
-    const bool use_graph = chunk >= 4 && chunk % 2 == 0 && !getenv("GRAPHLEARN_AMD_NO_GRAPH");
+    // (off by default: the launches of a chunk queue faster than they run -- 20 us of kernels per iteration against 8 us of
+    //  host time --, and capturing a chunk costs ~0.4 ms per form and parity: 21.6 against 23.6 us per iteration at n = 256,
+    //  B = 8 over 1299 iterations, 3.4 against 4.0 ms for a 212-iteration WindowLogModel fit.  GRAPHLEARN_AMD_BATCH_GRAPH=1)
+    const bool use_graph = chunk >= 4 && chunk % 2 == 0 && getenv("GRAPHLEARN_AMD_BATCH_GRAPH") && !getenv("GRAPHLEARN_AMD_NO_GRAPH");
     struct Graphs {
         hipGraphExec_t g[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [decide][parity of the first iteration]
         ~Graphs() {

@@ -107,21 +107,27 @@ double pairwise_sum(const double *a, int64_t n) {
     return pairwise_sum(a, h) + pairwise_sum(a + h, n - h);
 }
 
-// the host's finish of theta on the device, for rows <= 128 (there pairwise_sum is the plain ordered sum):
-// one thread, so that nothing has to come back before the distances are scaled
+// the host's finish of theta on the device -- the same pairwise sums in the same order, by one thread --, so that nothing
+// has to come back before the distances are scaled (a batch of windows: one host round trip per window otherwise)
+__device__ double pairwise_sum_dev(const double *a, int64_t n) {
+    if (n <= 128) {
+        double s = 0;
+        for (int64_t i = 0; i < n; ++i) s += a[i];
+        return s;
+    }
+    const int64_t h = (n / 2) & ~(int64_t)7;
+    return pairwise_sum_dev(a, h) + pairwise_sum_dev(a + h, n - h);
+}
 __global__ void k_theta_finish(const double *__restrict__ terms, int rows, double *__restrict__ theta_dev) {
-    double lo = 0, hi = 0;
-    for (int i = 0; i < rows; ++i) lo += terms[i];
-    for (int i = 0; i < rows; ++i) hi += terms[rows + i];
+    const double lo = pairwise_sum_dev(terms, rows), hi = pairwise_sum_dev(terms + rows, rows);
     theta_dev[0] = sqrt((lo / (double)rows) * (hi / (double)rows));
 }
 
 }  // namespace
 
-// theta of a square matrix left in device memory (n <= 128); no synchronisation
+// theta of a square matrix left in device memory; no synchronisation
 int gl_theta_from_square_dev(gl_ctx *ctx, const double *zsq_dev, int64_t n, int k, double *terms_dev, double *theta_dev) {
     if (k < 1 || k >= n) return gl_set_error(ctx, GL_E_INVALID, "avg_degree must be in [1, %lld], got %d", (long long)n - 1, k);
-    if (n > 128) return gl_set_error(ctx, GL_E_INVALID, "internal: device-side theta is for n <= 128");
     k_theta_rows<<<dim3((unsigned)n), dim3(256), 0, ctx->stream>>>(zsq_dev, n, k, terms_dev, n);
     k_theta_finish<<<1, 1, 0, ctx->stream>>>(terms_dev, (int)n, theta_dev);
     GL_HIP(ctx, hipGetLastError());
