@@ -171,7 +171,7 @@ struct TileDev {
     // g nb1 .. g nb1 + nb1 - 1, tiles g ntiles1 .., workgroups g NWG1 ..; n, nm2 are those of ONE graph; nb, NWG the totals
     int nb1, NWG1;
     int64_t ntiles1;
-    double t2hi, t2lo;    // thresholds of the coupled rule's screen: (1.05 tol)^2 and tol^2 (1 + 1e-9)
+    double t2lo;          // the coupled rule's screen: tol^2 (1 + 1e-9)
 };
 
 __device__ __forceinline__ double tl_val(tl_u4 g) {
@@ -2113,7 +2113,6 @@ int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int fina
     P.nb1 = t->nb1;
     P.NWG1 = t->NWG1;
     P.ntiles1 = t->ntiles1;
-    P.t2hi = (1.05 * tol) * (1.05 * tol);
     P.t2lo = tol * tol * (1 + 1e-9);
     if (tol > 0 || t->batch) norms = true;
     P.it0 = s->it;
