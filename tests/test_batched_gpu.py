@@ -162,6 +162,27 @@ def test_batched_cruise_on_the_tile_engine(n, b, hook, monkeypatch, capfd):
     assert np.array_equal(out, out2)
 
 
+def test_window_model_large_windows_theta_on_device_and_session_pool():
+    """Windows of n = 200 nodes: theta never leaves the device before the distances are scaled (the finish of get_theta --
+    NumPy's pairwise means, smooth_learning.py:204-211 -- by one device thread, any n), the sessions' device blocks come from and
+    go back to the context's pool (two fits in a row, then another size in between): thetas and weights against the oracle."""
+    from scipy.spatial.distance import pdist, squareform
+
+    rng = default_rng(11)
+    n, win, deg = 200, 64, 5
+    x = rng.standard_normal((3 * win, n)).cumsum(axis=1) * 0.1 + rng.standard_normal((3 * win, n)) * 0.05
+    d = np.stack([pdist(w.T) ** 2 for w in x.reshape(-1, win, n)])
+    th = np.array([old.theta_for_degree(squareform(dd), deg) for dd in d])
+    ref, info = old.learn_log_degrees(d * th[:, None], 1, 1, maxit=300, tol=1e-4, edge_tol=-np.inf, return_info=True)
+    for rep in range(2):
+        m = WindowLogModel(window_size=win, avg_degree=deg, maxit=300, tol=1e-4, edge_tol=-np.inf).fit(x)
+        np.testing.assert_allclose(m.theta_[:, 0], th, rtol=1e-12)
+        assert m.n_iter_ == info["n_iter"]
+        np.testing.assert_allclose(m.weights_, ref, rtol=0, atol=1e-9)
+        if rep == 0:  # another session size between the two fits
+            gsp_learn_graph_log_degrees(rng.uniform(0.1, 3.0, size=(2, 30 * 29 // 2)), 1, 1, maxit=20, tol=0.0)
+
+
 def test_batch_gram_entry_point():
     """gl_logdeg_batch_gram (diagnostic entry point): the four B x B Gram matrices of the last iteration."""
     import ctypes as C
