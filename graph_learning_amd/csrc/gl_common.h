@@ -28,6 +28,11 @@ struct gl_ctx {
     void *pinned_dev = nullptr;  // the same memory as the device sees it (mapped)
     size_t pinned_bytes = 0;  // status area only (the staging area follows it)
     bool stage_busy = false;  // an asynchronous staged upload may still be reading the staging area
+    // the staging area is a ring of GL_STAGE_SLOTS slots, each fenced by an event of its own: consecutive uploads (a batch of
+    // windows: one block of signals per graph) do not wait for the stream to drain between them
+    hipEvent_t stage_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool stage_pending[4] = {false, false, false, false};
+    int stage_next = 0;
     bool small_attrs_set = false;  // dynamic-LDS limit of the small-engine kernels raised on this device
     // device scratch for the batched entry points (grown on demand, kept: no hipMalloc / hipFree per call)
     void *scratch = nullptr;
@@ -61,8 +66,10 @@ int gl_set_error(gl_ctx *ctx, int code, const char *fmt, ...);
 // gl_h2d is asynchronous (the staging area is fenced by a stream sync before its next use), gl_d2h
 // returns with the data in place.
 constexpr size_t GL_STATUS_BYTES = 1 << 16;  // pinned[0 .. 64 KiB): status words of the kernels
-constexpr size_t GL_STAGE_BYTES = 1 << 20;   // pinned[64 KiB ..): staging
+constexpr size_t GL_STAGE_BYTES = 1 << 20;   // pinned[64 KiB ..): staging, GL_STAGE_SLOTS slots of this size
+constexpr int GL_STAGE_SLOTS = 4;
 int gl_h2d(gl_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+void gl_stage_idle(gl_ctx *ctx);  // after a synchronisation of the stream: no staged upload is in flight
 int gl_d2h(gl_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 
 #define GL_HIP(ctx, call)                                                                   \

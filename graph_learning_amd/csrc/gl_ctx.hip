@@ -68,8 +68,10 @@ GL_API int gl_ctx_create(int device, gl_ctx **out) {
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess)
         return fail(GL_E_HIP);
     ctx->pinned_bytes = GL_STATUS_BYTES;
-    if (hipHostMalloc(&ctx->pinned, GL_STATUS_BYTES + GL_STAGE_BYTES, hipHostMallocMapped) != hipSuccess)
+    if (hipHostMalloc(&ctx->pinned, GL_STATUS_BYTES + GL_STAGE_SLOTS * GL_STAGE_BYTES, hipHostMallocMapped) != hipSuccess)
         return fail(GL_E_NOMEM);
+    for (int k = 0; k < GL_STAGE_SLOTS; ++k)
+        if (hipEventCreateWithFlags(&ctx->stage_ev[k], hipEventDisableTiming) != hipSuccess) return fail(GL_E_HIP);
     if (hipHostGetDevicePointer(&ctx->pinned_dev, ctx->pinned, 0) != hipSuccess) return fail(GL_E_HIP);
     *out = ctx;
     return GL_OK;
@@ -83,6 +85,8 @@ GL_API int gl_ctx_destroy(gl_ctx *ctx) {
     for (const gl_ctx::PoolBlock &b : ctx->pool) (void)hipFree(b.p);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    for (int k = 0; k < GL_STAGE_SLOTS; ++k)
+        if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -192,16 +196,29 @@ static int stage_copy(gl_ctx *ctx, const void *src, void *dst, size_t bytes) {
     return GL_OK;
 }
 
+// after a synchronisation of the stream: no staged upload is in flight
+void gl_stage_idle(gl_ctx *ctx) {
+    ctx->stage_busy = false;
+    for (int k = 0; k < GL_STAGE_SLOTS; ++k) ctx->stage_pending[k] = false;
+}
+
 int gl_h2d(gl_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
     if (bytes == 0) return GL_OK;
     if (bytes > GL_STAGE_BYTES || (bytes & 7)) {
         GL_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
         return GL_OK;
     }
-    if (ctx->stage_busy) GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    char *stage = (char *)ctx->pinned + GL_STATUS_BYTES;
-    memcpy(stage, src_host, bytes);
-    GL_TRY(stage_copy(ctx, (char *)ctx->pinned_dev + GL_STATUS_BYTES, dst_dev, bytes));
+    const int slot = ctx->stage_next;
+    ctx->stage_next = (slot + 1) % GL_STAGE_SLOTS;
+    if (ctx->stage_pending[slot]) {  // (the copy that last read this slot: four uploads ago)
+        GL_HIP(ctx, hipEventSynchronize(ctx->stage_ev[slot]));
+        ctx->stage_pending[slot] = false;
+    }
+    const size_t off = GL_STATUS_BYTES + (size_t)slot * GL_STAGE_BYTES;
+    memcpy((char *)ctx->pinned + off, src_host, bytes);
+    GL_TRY(stage_copy(ctx, (char *)ctx->pinned_dev + off, dst_dev, bytes));
+    GL_HIP(ctx, hipEventRecord(ctx->stage_ev[slot], ctx->stream));
+    ctx->stage_pending[slot] = true;
     ctx->stage_busy = true;
     return GL_OK;
 }
@@ -211,13 +228,13 @@ int gl_d2h(gl_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
     if (bytes > GL_STAGE_BYTES || (bytes & 7)) {
         GL_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
         GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->stage_busy = false;
+        gl_stage_idle(ctx);
         return GL_OK;
     }
-    char *stage = (char *)ctx->pinned + GL_STATUS_BYTES;
+    char *stage = (char *)ctx->pinned + GL_STATUS_BYTES;  // (slot 0: behind whatever upload still reads it, same stream)
     GL_TRY(stage_copy(ctx, src_dev, (char *)ctx->pinned_dev + GL_STATUS_BYTES, bytes));
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // also fences any earlier staged upload (same stream)
-    ctx->stage_busy = false;
+    gl_stage_idle(ctx);
     memcpy(dst_host, stage, bytes);
     return GL_OK;
 }

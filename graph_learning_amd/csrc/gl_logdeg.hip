@@ -1981,7 +1981,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
     // iteration: 45-57 us per iteration at n = 256, against ~10 us for the two launches.)
     if (ctx->stage_busy) {
         GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->stage_busy = false;
+        gl_stage_idle(ctx);
     }
     // The cruise (above): everything but the call's last iteration at most -- the values reported at the end need the last
     // two iterates side by side, which only the launches below keep.
