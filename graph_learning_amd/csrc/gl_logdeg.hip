@@ -67,6 +67,28 @@ struct RowReduce<4> {
 // INIT = true computes only the degree sums of the current iterate (dvar = S w, :144).
 // ABL: development-only ablation mask (tools/edge_ablate.hip); the product uses ABL = 0.
 //   1 no node-vector gathers, 2 no row sums, 4 no column sums, 8 no w store, 16 no norms, 32 no z load
+// development (tools/build_variant.sh): non-temporal hints on the streams of the edge pass -- 1: z, 2: w loads, 4: w stores
+#ifndef GL_EDGE_NT
+#define GL_EDGE_NT 0
+#endif
+template <bool NT>
+__device__ __forceinline__ double2 edge_ld(const double *p) {
+    if (NT) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p));
+        return double2{v.x, v.y};
+    }
+    return *reinterpret_cast<const double2 *>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void edge_st(double *p, double2 v) {
+    if (NT) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store((v2d){v.x, v.y}, reinterpret_cast<v2d *>(p));
+    } else {
+        *reinterpret_cast<double2 *>(p) = v;
+    }
+}
 struct EdgeStep {
     int64_t t;   // tile
     int a;       // first row pair of the step inside the tile
@@ -118,8 +140,8 @@ __device__ __forceinline__ void edge_body(const LogdegDev &P, const double *__re
         zv[k] = double2{0.0, 0.0};
         if (k < cur.cnt) {
             const int64_t off = cur.t * GL_TILE_ELEMS + (int64_t)(cur.a + k) * (2 * TB) + lofs;
-            wv[k] = *reinterpret_cast<const double2 *>(wsrc + off);
-            if (!INIT && !(ABL & 32)) zv[k] = *reinterpret_cast<const double2 *>(P.z + off);
+            wv[k] = edge_ld<(GL_EDGE_NT & 2) != 0>(wsrc + off);
+            if (!INIT && !(ABL & 32)) zv[k] = edge_ld<(GL_EDGE_NT & 1) != 0>(P.z + off);
         }
     }
 
@@ -206,13 +228,13 @@ __device__ __forceinline__ void edge_body(const LogdegDev &P, const double *__re
                 }
                 rowp[k] = pp[0] + pp[1];
                 roww[k] = wn[0] + wn[1];
-                if (!INIT && !(ABL & 8)) *reinterpret_cast<double2 *>(wq + k * (2 * TB)) = double2{wn[0], wn[1]};
+                if (!INIT && !(ABL & 8)) edge_st<(GL_EDGE_NT & 4) != 0>(wq + k * (2 * TB), double2{wn[0], wn[1]});
                 if (ABL & 8) nqy += wn[0] + wn[1];
             }
             // prefetch: this slot's registers are free again
             if (k < ns.cnt) {
-                wv[k] = *reinterpret_cast<const double2 *>(wp + k * (2 * TB));
-                if (!INIT && !(ABL & 32)) zv[k] = *reinterpret_cast<const double2 *>(zp + k * (2 * TB));
+                wv[k] = edge_ld<(GL_EDGE_NT & 2) != 0>(wp + k * (2 * TB));
+                if (!INIT && !(ABL & 32)) zv[k] = edge_ld<(GL_EDGE_NT & 1) != 0>(zp + k * (2 * TB));
             }
         }
     };
