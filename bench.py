@@ -77,6 +77,7 @@ def other_configs(ctx):
     graphdict  BASELINE configs[4]: GraphDictLog K=8, n=1024, T=4096: ms per primal-dual step, fp64 (what the reference
                computes) and fp32 contractions (what the config names).
     batched_n256    the 2-D branch (B = 8 graphs of n = 256): us per iteration of the bare loop and of a run to tol.
+    window_n256     WindowLogModel.fit end to end, 10 windows of one smooth process on 256 nodes.
     logmodel_n8192  the headline loop on a lattice four times as large (SURVEY section 8 row d quotes the roofline for
                n >= 4096): time per iteration and its fraction of 24 E bytes / 8 TB/s."""
     import numpy as np
@@ -155,6 +156,22 @@ def other_configs(ctx):
                                "us_per_iteration_bare_loop": t_bare / 2000 * 1e6, "to_tol_1e-6": {"iterations": int(info["n_iter"]),
                                "converged": bool(info["converged"]), "us_per_iteration": t_tol / max(int(info["n_iter"]), 1) * 1e6},
                                "timing": "host wall clock around the call minus the same call with maxit=0 (uploads, set-up)"}
+        # WindowLogModel end to end on windows of ONE smooth process (the case whose coupled rule stays undecided by the cheap
+        # bounds longest): 10 windows of 256 samples, 256 nodes; distances, theta and the solver on the device
+        from graph_learning_amd.temporal import WindowLogModel
+        rs = np.random.default_rng(5)
+        adj = np.triu((rs.random((n, n)) < 6.0 / n) * rs.uniform(0.3, 2.0, (n, n)), 1)
+        adj = adj + adj.T
+        chol = np.linalg.cholesky(np.linalg.inv(np.diag(adj.sum(1)) - adj + np.eye(n)))
+        xw = (chol @ rs.standard_normal((n, 10 * 256))).T
+        WindowLogModel(window_size=256, avg_degree=6, maxit=50, tol=1e-4).fit(xw)
+        t0 = time.perf_counter()
+        wm = WindowLogModel(window_size=256, avg_degree=6, maxit=20000, tol=1e-4).fit(xw)
+        t_fit = time.perf_counter() - t0
+        out["window_n256"] = {"workload": "WindowLogModel.fit, 10 windows of 256 samples of one smooth process on 256 nodes (temporal/smooth.py:12-61), "
+                                          "host signals in, (10, E) weights out", "dtype": "f64", "iterations": int(wm.n_iter_),
+                              "converged": bool(wm.converged_), "ms_end_to_end": t_fit * 1e3,
+                              "us_per_iteration_all_in": t_fit / max(int(wm.n_iter_), 1) * 1e6}
     except Exception as exc:
         out["batched_error"] = repr(exc)
     try:  # a lattice four times the headline's: what does not fit the register files streams (rounds)
