@@ -90,6 +90,7 @@ constexpr int GL_TILE_MIN_CALL = 4;  // shortest call (iterations) the tile engi
 int gl_tile_prepare(gl_logdeg *s);
 int gl_tile_prepare_batch(gl_logdeg *s, int B);  // s stands for B graphs of dev.n nodes (gl_logdeg.hip: the batch's cruise)
 int gl_tile_batch_make_zg(gl_logdeg *s, const LogdegDev *devs_dev, int B);
+void gl_tile_batch_set_ring(gl_logdeg *s, double *ring, int64_t ring_stride, double *dring, int64_t dring_stride);
 void gl_tile_free(gl_logdeg *s);
 int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int final_parity);
 bool gl_tile_writes_final_parity(const gl_logdeg *s);

@@ -1046,6 +1046,174 @@ __global__ __launch_bounds__(GRAM_WAVES * 64) void k_batch_gram(const BatchPtrs 
     }
 }
 
+// The same judgement for a whole CHUNK of iterations at once (the deciding chunks of a cruise, below): the tile engine has
+// written the iterate of every iteration of its launch to a ring of tiled batches (slot j: after j iterations) and the dual
+// variable beside it; blockIdx.y = j judges iteration j of the chunk (update = slot j + 1 - slot j, iterate = slot j) exactly
+// as k_batch_gram does -- Gram blocks on MFMA, fixed reduction tree, staged brackets in the last workgroup of its row -- and
+// leaves decision[j] = 0 (surely not met), 3 (met) or 1 (a tie inside 1e-9: the host decides).
+struct RingJudge {
+    unsigned done[64];
+    int decision[64];
+};
+template <int NG>
+__global__ __launch_bounds__(GRAM_WAVES * 64) void k_batch_gram_ring(const double *__restrict__ ring, const double *__restrict__ dring, int nprob,
+                                                                     int64_t ring_stride, int64_t tiled1, int64_t dring_stride, int64_t n_pad1,
+                                                                     double *__restrict__ part_all, double t2, RingJudge *rj) {
+    constexpr int NBLK = NG == 1 ? 1 : 3;
+    constexpr int SLOT = 2 * NBLK * 256;
+    __shared__ double smem[(GRAM_WAVES / 2) * SLOT];
+    __shared__ double br[8];
+    __shared__ int s_last, s_dec;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gi = lane & 15, kq = lane >> 4, j = blockIdx.y;
+    const bool node_blk = blockIdx.x == gridDim.x - 1;
+    double *part = part_all + (size_t)j * gridDim.x * 2 * NBLK * 256;
+    const double *vn[NG], *vo[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int a = 16 * g + gi;
+        vn[g] = vo[g] = nullptr;
+        if (a < nprob) {
+            vo[g] = node_blk ? dring + (int64_t)j * dring_stride + a * n_pad1 : ring + (int64_t)j * ring_stride + a * tiled1;
+            vn[g] = vo[g] + (node_blk ? dring_stride : ring_stride);
+        }
+    }
+    const int64_t units = (node_blk ? n_pad1 : tiled1) / 16;
+    const int nw = node_blk ? GRAM_WAVES : ((int)gridDim.x - 1) * GRAM_WAVES, w0 = node_blk ? wave : (int)blockIdx.x * GRAM_WAVES + wave;
+    bg_d4 acc[2 * NBLK];
+#pragma unroll
+    for (int b = 0; b < 2 * NBLK; ++b) acc[b] = bg_d4{0.0, 0.0, 0.0, 0.0};
+    double2 cn[NG][2], co[NG][2];
+    auto fetch = [&](int64_t u, double2 (&fn)[NG][2], double2 (&fo)[NG][2]) {
+        const int64_t e = 16 * u + 4 * kq;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            fn[g][0] = fn[g][1] = fo[g][0] = fo[g][1] = double2{0.0, 0.0};
+            if (vn[g] && u < units) {
+                fn[g][0] = *reinterpret_cast<const double2 *>(vn[g] + e), fn[g][1] = *reinterpret_cast<const double2 *>(vn[g] + e + 2);
+                fo[g][0] = *reinterpret_cast<const double2 *>(vo[g] + e), fo[g][1] = *reinterpret_cast<const double2 *>(vo[g] + e + 2);
+            }
+        }
+    };
+    fetch(w0, cn, co);
+    for (int64_t u = w0; u < units; u += nw) {
+        double2 nn[NG][2], no[NG][2];
+        fetch(u + nw, nn, no);
+        double dn[NG][4], od[NG][4];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            od[g][0] = co[g][0].x, od[g][1] = co[g][0].y, od[g][2] = co[g][1].x, od[g][3] = co[g][1].y;
+            dn[g][0] = cn[g][0].x - co[g][0].x, dn[g][1] = cn[g][0].y - co[g][0].y;
+            dn[g][2] = cn[g][1].x - co[g][1].x, dn[g][3] = cn[g][1].y - co[g][1].y;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc[0] = bg_mfma(dn[0][t], dn[0][t], acc[0]);
+            acc[NBLK] = bg_mfma(od[0][t], od[0][t], acc[NBLK]);
+            if (NG == 2) {
+                acc[1] = bg_mfma(dn[0][t], dn[NG - 1][t], acc[1]);
+                acc[NBLK - 1] = bg_mfma(dn[NG - 1][t], dn[NG - 1][t], acc[NBLK - 1]);
+                acc[NBLK + 1] = bg_mfma(od[0][t], od[NG - 1][t], acc[NBLK + 1]);
+                acc[2 * NBLK - 1] = bg_mfma(od[NG - 1][t], od[NG - 1][t], acc[2 * NBLK - 1]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) cn[g][0] = nn[g][0], cn[g][1] = nn[g][1], co[g][0] = no[g][0], co[g][1] = no[g][1];
+    }
+    for (int h = GRAM_WAVES / 2; h >= 1; h >>= 1) {
+        if (wave >= h && wave < 2 * h)
+#pragma unroll
+            for (int b = 0; b < 2 * NBLK; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) smem[(wave - h) * SLOT + b * 256 + lane * 4 + r] = acc[b][r];
+        __syncthreads();
+        if (wave < h)
+#pragma unroll
+            for (int b = 0; b < 2 * NBLK; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[b][r] += smem[wave * SLOT + b * 256 + lane * 4 + r];
+        __syncthreads();
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int b = 0; b < 2 * NBLK; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                __hip_atomic_store(part + ((size_t)blockIdx.x * 2 * NBLK + b) * 256 + lane * 4 + r, acc[b][r], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            const unsigned arrived = __hip_atomic_fetch_add(&rj->done[j], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            s_last = arrived == gridDim.x ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    typedef SmMfma<NG> MB;
+    static_assert(4 * MB::SIZE <= (GRAM_WAVES / 2) * SLOT, "the four padded matrices live in the reduction's LDS");
+    double *gA = smem;
+    const int B = nprob, ne = (int)gridDim.x - 1;
+    for (int x = tid; x < 4 * MB::SIZE; x += GRAM_WAVES * 64) gA[x] = 0.0;
+    __syncthreads();
+    typedef unsigned int bg_u4 __attribute__((ext_vector_type(4)));
+    const auto r_part = __builtin_amdgcn_make_buffer_rsrc((void *)part, 0, (int)((size_t)gridDim.x * 2 * NBLK * 256 * 8), 0x00020000);
+    auto two = [](bg_u4 g, double &a, double &b) {
+        a = __longlong_as_double((long long)(((unsigned long long)g.y << 32) | g.x));
+        b = __longlong_as_double((long long)(((unsigned long long)g.w << 32) | g.z));
+    };
+    for (int kp = tid; kp < 2 * NBLK * 128; kp += GRAM_WAVES * 64) {
+        const int k = kp >> 7, x = 2 * (kp & 127);
+        const int which = k / NBLK, b = k % NBLK;
+        const int ln = x >> 2, r = x & 3;
+        const int row = (ln >> 4) + 4 * r + (b == 2 ? 16 : 0), col = (ln & 15) + (b >= 1 ? 16 : 0);
+        if (row >= B || col >= B) continue;
+        double e0 = 0.0, e1 = 0.0;
+#pragma unroll 8
+        for (int blk = 0; blk < ne; ++blk) {
+            double a, c;
+            two(__builtin_amdgcn_raw_buffer_load_b128(r_part, (int)((((size_t)blk * 2 * NBLK + k) * 256 + x) * 8), 0, 16), a, c);
+            e0 += a, e1 += c;
+        }
+        double d0, d1;
+        two(__builtin_amdgcn_raw_buffer_load_b128(r_part, (int)((((size_t)ne * 2 * NBLK + k) * 256 + x) * 8), 0, 16), d0, d1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rw = row + 4 * h;
+            if (rw >= B) break;
+            const double ve = h ? e1 : e0, vd = h ? d1 : d0;
+            gA[(which + 0) * MB::SIZE + rw * MB::LD + col] = ve;
+            gA[(which + 2) * MB::SIZE + rw * MB::LD + col] = vd;
+            if (b == 1) {
+                gA[(which + 0) * MB::SIZE + col * MB::LD + rw] = ve;
+                gA[(which + 2) * MB::SIZE + col * MB::LD + rw] = vd;
+            }
+        }
+    }
+    __syncthreads();
+    SmBracket S{};
+    if (wave < 4) MB::begin(gA + wave * MB::SIZE, lane, S);
+    for (int round = 0; round < 6; ++round) {
+        if (wave < 4) {
+            double lo, hi;
+            MB::advance(gA + wave * MB::SIZE, lane, S, round == 0 ? 4 : 6);
+            MB::bounds(gA + wave * MB::SIZE, lane, S, lo, hi);
+            if (lane == 0) br[2 * wave] = lo, br[2 * wave + 1] = hi;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const double tp = t2 * (1 + 1e-9), tm = t2 * (1 - 1e-9);
+            const bool not_yet = br[0] > tp * br[3] || br[4] > tp * br[7];
+            const bool met = br[2] > 0 && br[6] > 0 && br[1] < tm * br[2] && br[5] < tm * br[6];
+            s_dec = met ? 3 : (not_yet ? 0 : 1);
+        }
+        __syncthreads();
+        if (s_dec != 1) break;
+    }
+    if (tid == 0) {
+        rj->decision[j] = s_dec;
+        rj->done[j] = 0u;
+    }
+}
+
 int check(gl_logdeg *s) { return (s && s->ctx) ? GL_OK : GL_E_INVALID; }
 
 // Where the column partials go.  The partition of the flat row-pair list over the
@@ -1763,24 +1931,36 @@ struct BatchCruise {
     int B = 0;
     int64_t n = 0;
     void *arena = nullptr;
+    // the deciding chunks (below): the ring of iterates, the dual variable beside it, a checkpoint of the rest of the dual
+    // state, the Gram partials and the per-iteration decisions -- one allocation, made when a call first gets there
+    void *ring_arena = nullptr;
+    int ring_k = 0;  // iterations per chunk
+    double *ring = nullptr, *dring = nullptr, *ckpt = nullptr, *gpart = nullptr;
+    RingJudge *judge = nullptr;
 };
 static void batch_cruise_free(void *p) {
     BatchCruise *bc = (BatchCruise *)p;
     if (!bc) return;
     gl_tile_free(&bc->cs);
     if (bc->arena) (void)hipFree(bc->arena);
+    if (bc->ring_arena) (void)hipFree(bc->ring_arena);
     delete bc;
 }
 namespace {
 // dir 0: sessions -> stand-in (iterate of parity par, dual state); dir 1: back, and the sessions' counters stand at `itf`
+// wold (dir 1 only): the iterate before the last one, graph after graph -- it goes to the sessions' other ping-pong buffer
 __global__ __launch_bounds__(256) void k_batch_copy_state(const LogdegDev *__restrict__ devs, LogdegDev C, int64_t tiled1, int64_t npad1,
-                                                          int64_t nb1, int par, int dir, long long itf) {
+                                                          int64_t nb1, int par, int dir, long long itf, const double *__restrict__ wold = nullptr) {
     const LogdegDev S = devs[blockIdx.y];
     const int64_t g = blockIdx.y, stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double *cw = C.w[par] + g * tiled1, *sw = S.w[par];
     for (int64_t e = t0; e < tiled1; e += stride) {
         if (dir == 0) cw[e] = sw[e];
         else sw[e] = cw[e];
+    }
+    if (dir == 1 && wold) {
+        double *so = S.w[par ^ 1];
+        for (int64_t e = t0; e < tiled1; e += stride) so[e] = wold[g * tiled1 + e];
     }
     for (int64_t i = t0; i < npad1; i += stride) {
         const int64_t k = g * npad1 + i;
@@ -2008,6 +2188,8 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
     // The cruise (above): everything but the call's last iteration at most -- the values reported at the end need the last
     // two iterates side by side, which only the launches below keep.
     int64_t cruised = 0;
+    bool ring_finished = false;  // the deciding chunks (below) have brought the call to its end
+    double ring_rp = std::numeric_limits<double>::infinity(), ring_rd = ring_rp;
     {
         bool same = sessions[0]->it == 0 && maxit >= 64 && !getenv("GRAPHLEARN_AMD_BATCH_NO_CRUISE");
         for (int a = 1; a < B && same; ++a) {
@@ -2048,11 +2230,128 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                 batch_cruise_free(bc);
                 ctx->batch_cruise = nullptr;
             } else if (keep) {
-                k_batch_copy_state<<<cgrid, 256, 0, ctx->stream>>>((const LogdegDev *)sc.devs, C, tiled1, D0.n_pad, D0.nb, (int)(ran & 1), 1,
-                                                                   (long long)ran);
-                GL_HIP(ctx, hipGetLastError());
                 cruised = ran;
-                for (int a = 0; a < B; ++a) sessions[a]->it = ran;
+                // ---- The deciding chunks.  From here on the exact rule is needed, iteration by iteration -- and the tile engine
+                // can still run them: K iterations per launch, every iterate written to a ring (gl_tile.hip: TileDev::ring), then
+                // ONE launch judges all K at once (k_batch_gram_ring).  The first iteration whose rule is met (or tied) ends
+                // the chunk: the state after it is rebuilt from the chunk's start -- the engine is deterministic -- by a launch
+                // of exactly that many iterations.  ~10 us per iteration where the three launches per iteration below take 32-45.
+                const int nbk = B <= 16 ? 1 : 3;
+                const int64_t gram_units = tiled1 / 16;
+                const unsigned ge = (unsigned)std::max<int64_t>(1, std::min<int64_t>(128, gram_units / (4 * GRAM_WAVES)));
+                bool ring_ok = B <= BATCH_BRACKET_MAXB && !getenv("GRAPHLEARN_AMD_BATCH_NO_RING");
+                if (ring_ok && !bc->ring_arena) {
+                    int K = getenv("GRAPHLEARN_AMD_BATCH_RING_K") ? std::max(2, std::min(64, atoi(getenv("GRAPHLEARN_AMD_BATCH_RING_K")))) : 32;
+                    const size_t slot = (size_t)B * tiled1 * 8, dslot = (size_t)C.n_pad * 8;
+                    while (K > 4 && (K + 1) * slot > ((size_t)3 << 30)) K /= 2;
+                    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+                    const size_t b_ring = up((K + 1) * slot), b_dring = up((K + 1) * dslot), b_ck = up(3 * dslot);
+                    const size_t b_part = up((size_t)K * (ge + 1) * 2 * nbk * 256 * 8), b_j = up(sizeof(RingJudge));
+                    if (hipMalloc(&bc->ring_arena, b_ring + b_dring + b_ck + b_part + b_j) == hipSuccess) {
+                        char *at = (char *)bc->ring_arena;
+                        bc->ring = (double *)at, at += b_ring;
+                        bc->dring = (double *)at, at += b_dring;
+                        bc->ckpt = (double *)at, at += b_ck;
+                        bc->gpart = (double *)at, at += b_part;
+                        bc->judge = (RingJudge *)at;
+                        bc->ring_k = K;
+                        GL_HIP(ctx, hipMemsetAsync(bc->judge, 0, sizeof(RingJudge), ctx->stream));
+                    } else {
+                        (void)hipGetLastError();
+                        bc->ring_arena = nullptr;
+                        ring_ok = false;
+                    }
+                }
+                int64_t n_done = ran;
+                bool back_to_launches = !ring_ok;
+                const double *w_old = nullptr;  // the iterate before the current one (a ring slot), once a chunk has run
+                const size_t wbytes = (size_t)B * tiled1 * 8, dbytes = (size_t)C.n_pad * 8;
+                const double t2r = tol * tol;
+                int chunks = 0, replays = 0;
+                while (ring_ok && !back_to_launches && n_done < maxit) {
+                    const int Kc = (int)std::min<int64_t>(bc->ring_k, maxit - n_done);
+                    const int64_t it_ck = cs.it;
+                    GL_HIP(ctx, hipMemcpyAsync(bc->ring, C.w[it_ck & 1], wbytes, hipMemcpyDeviceToDevice, ctx->stream));
+                    GL_HIP(ctx, hipMemcpyAsync(bc->dring, C.dvar, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
+                    GL_HIP(ctx, hipMemcpyAsync(bc->ckpt, C.ybar, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
+                    GL_HIP(ctx, hipMemcpyAsync(bc->ckpt + C.n_pad, C.pbar, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
+                    GL_HIP(ctx, hipMemcpyAsync(bc->ckpt + 2 * C.n_pad, C.dprev, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
+                    gl_tile_batch_set_ring(&cs, bc->ring, (int64_t)B * tiled1, bc->dring, C.n_pad);
+                    GL_TRY(gl_tile_launch(&cs, Kc, 0.0, true, -1));
+                    gl_tile_batch_set_ring(&cs, nullptr, 0, nullptr, 0);
+                    int64_t got = 0;
+                    bool st2 = false, nr2 = false;
+                    GL_TRY(gl_resident_finish(&cs, &got, &st2, &nr2));
+                    auto restore = [&]() -> int {  // the chunk's start
+                        cs.it = it_ck;
+                        GL_HIP(ctx, hipMemcpyAsync(C.w[it_ck & 1], bc->ring, wbytes, hipMemcpyDeviceToDevice, ctx->stream));
+                        GL_HIP(ctx, hipMemcpyAsync(C.dvar, bc->dring, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
+                        GL_HIP(ctx, hipMemcpyAsync(C.ybar, bc->ckpt, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
+                        GL_HIP(ctx, hipMemcpyAsync(C.pbar, bc->ckpt + C.n_pad, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
+                        GL_HIP(ctx, hipMemcpyAsync(C.dprev, bc->ckpt + 2 * C.n_pad, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
+                        return GL_OK;
+                    };
+                    if (nr2 || got != Kc) {  // (the workgroups did not meet: nothing was written; the launches below go on from here)
+                        GL_TRY(restore());
+                        back_to_launches = true;
+                        break;
+                    }
+                    ++chunks;
+                    const dim3 gg(ge + 1, (unsigned)Kc);
+                    if (B <= 16)
+                        k_batch_gram_ring<1><<<gg, GRAM_WAVES * 64, 0, ctx->stream>>>(bc->ring, bc->dring, B, (int64_t)B * tiled1, tiled1, C.n_pad, D0.n_pad,
+                                                                                      bc->gpart, t2r, bc->judge);
+                    else
+                        k_batch_gram_ring<2><<<gg, GRAM_WAVES * 64, 0, ctx->stream>>>(bc->ring, bc->dring, B, (int64_t)B * tiled1, tiled1, C.n_pad, D0.n_pad,
+                                                                                      bc->gpart, t2r, bc->judge);
+                    GL_HIP(ctx, hipGetLastError());
+                    RingJudge *jh = (RingJudge *)((char *)ctx->pinned + GL_STATUS_BYTES);
+                    GL_HIP(ctx, hipMemcpyAsync(jh, bc->judge, sizeof(RingJudge), hipMemcpyDeviceToHost, ctx->stream));
+                    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    int hit = -1;
+                    for (int j = 0; j < Kc && hit < 0; ++j)
+                        if (jh->decision[j] != 0) hit = j;
+                    if (hit < 0) {  // the whole chunk was short of the rule
+                        n_done += Kc;
+                        w_old = bc->ring + (size_t)(Kc - 1) * B * tiled1;
+                        continue;
+                    }
+                    if (hit + 1 < Kc) {  // the state after iteration `hit`: from the chunk's start, hit + 1 iterations
+                        GL_TRY(restore());
+                        GL_TRY(gl_tile_launch(&cs, hit + 1, 0.0, true, -1));
+                        GL_TRY(gl_resident_finish(&cs, &got, &st2, &nr2));
+                        ++replays;
+                        if (nr2 || got != hit + 1) {
+                            GL_TRY(restore());
+                            back_to_launches = true;
+                            break;
+                        }
+                    }
+                    n_done += hit + 1;
+                    w_old = bc->ring + (size_t)hit * B * tiled1;
+                    // the sessions get this state (both iterates), the host forms the exact ratios: met -> done; a tie that was
+                    // not met after all -> the chunks go on from here
+                    k_batch_copy_state<<<cgrid, 256, 0, ctx->stream>>>((const LogdegDev *)sc.devs, C, tiled1, D0.n_pad, D0.nb, (int)(n_done & 1), 1,
+                                                                       (long long)n_done, w_old);
+                    GL_HIP(ctx, hipGetLastError());
+                    for (int a = 0; a < B; ++a) sessions[a]->it = n_done;
+                    GL_TRY(exact(ring_rp, ring_rd));
+                    if (jh->decision[hit] == 3 || (ring_rp < tol && ring_rd < tol)) {
+                        ring_finished = true;
+                        break;
+                    }
+                }
+                if (getenv("GRAPHLEARN_AMD_BATCH_DEBUG") && ring_ok)
+                    fprintf(stderr, "[batch ring] %d chunks of %d iterations, %d replays, at iteration %lld, finished %d, back to the launches %d\n", chunks,
+                            bc->ring_k, replays, (long long)n_done, (int)ring_finished, (int)back_to_launches);
+                if (!ring_finished) {  // the budget ran out, or the ring is not available: the sessions take over where the engine stands
+                    k_batch_copy_state<<<cgrid, 256, 0, ctx->stream>>>((const LogdegDev *)sc.devs, C, tiled1, D0.n_pad, D0.nb, (int)(n_done & 1), 1,
+                                                                       (long long)n_done, w_old);
+                    GL_HIP(ctx, hipGetLastError());
+                    for (int a = 0; a < B; ++a) sessions[a]->it = n_done;
+                    if (ring_ok && !back_to_launches) ring_finished = true;  // (n_done == maxit)
+                }
+                cruised = n_done;
             }
         }
     }
@@ -2127,7 +2426,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
     bool have_exact = false, converged = false;
     int64_t n_iter = cruised;
     const int64_t it0 = sessions[0]->it - cruised;
-    while (n_iter < maxit) {
+    while (n_iter < maxit && !ring_finished) {
         const int par0 = (int)((it0 + n_iter) & 1);
         if (use_graph) {
             hipGraphExec_t &gq = graphs.g[deciding ? 1 : 0][par0];

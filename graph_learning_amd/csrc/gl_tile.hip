@@ -172,6 +172,11 @@ struct TileDev {
     int nb1, NWG1;
     int64_t ntiles1;
     double t2lo;          // the coupled rule's screen: tol^2 (1 + 1e-9)
+    // ... and, where the exact coupled rule is judged afterwards (gl_logdeg.hip: the deciding chunks): every iteration's new
+    // iterate is also written out, iteration it of the call to slot it + 1 of a ring of whole tiled batches (slot 0: the
+    // call's start, by the host) and its dual variable to the same slot of dring; null: not
+    double *ring, *dring;
+    int64_t ring_stride, dring_stride;  // doubles per slot
 };
 
 __device__ __forceinline__ double tl_val(tl_u4 g) {
@@ -1202,6 +1207,25 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     if (f < fcnt) vp[2 * (fa0 + f) + half] += rsp[f];
             }
         }
+        if constexpr (BATCH) {
+            if (P.ring) {  // (fire and forget: drained with everything else at the bottom of the iteration, a hand-off later)
+                int ld = lane;
+                asm volatile("" : "+v"(ld));  // (the offsets are formed here and now: kept over the pass they cost it registers)
+                double *slot = P.ring + (int64_t)(it + 1) * P.ring_stride;
+                if (has) {
+                    const int64_t tb0 = chunk_off(ld);
+#pragma unroll
+                    for (int s = 0; s < U; ++s) *reinterpret_cast<double2 *>(slot + tb0 + s * (2 * TB)) = wreg[s];
+                }
+#pragma unroll
+                for (int f = 0; f < FRMAX; ++f)
+                    if (f < fcnt) {
+                        const int64_t i = (int64_t)fBl * TB + 2 * (fa0 + f) + (ld >> 5), j = (int64_t)fBl * TB + 2 * (ld & 31);
+                        *reinterpret_cast<double2 *>(slot + fringe_off(ld) + (int64_t)(fa0 + f) * (2 * TB)) =
+                            double2{(i < j && j < P.n) ? fw[f].x : 0.0, (i < j + 1 && j + 1 < P.n) ? fw[f].y : 0.0};
+                    }
+            }
+        }
         if (NORMS) {
             nqy = wave_sum(nqy);
             nw = wave_sum(nw);
@@ -1404,6 +1428,9 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 const double d_new = real ? dnew : 0.0, pb_new = real ? pbn : 0.0;
                 s_dual[3][ln] = d_cur;
                 s_dual[0][ln] = d_new;
+                if constexpr (BATCH) {
+                    if (P.dring) P.dring[(int64_t)(it + 1) * P.dring_stride + (int64_t)own * TB + ln] = d_new;
+                }
                 s_dual[1][ln] = real ? ybn : 0.0;
                 s_dual[2][ln] = pb_new;
                 s_dual[4][ln] = real ? gsw : 0.0;
@@ -1588,6 +1615,8 @@ struct gl_tile {
     unsigned next_tag = 1u;     // first tag of the next launch (a launch uses maxit + 2 consecutive ones, never 0)
     unsigned arrivals = 0;      // workgroups that have arrived at the start-up rendezvous over all launches so far
     bool batch = false;         // a batch of graphs as one block-diagonal lattice (gl_tile_prepare_batch)
+    double *ring = nullptr, *dring = nullptr;  // ... whose next launch writes every iterate out (gl_tile_batch_set_ring)
+    int64_t ring_stride = 0, dring_stride = 0;
     int nb1 = 0, NWG1 = 0;      // ... node blocks and workgroups of ONE graph
     int64_t ntiles1 = 0;        // ... and its tiles
 };
@@ -2072,6 +2101,14 @@ int gl_tile_prepare_batch(gl_logdeg *s, int B) {
     return tile_finish(s, wd, gd, B * NWG1, U, false, nb1, NWG1);
 }
 
+// the launches from now on write every iterate to `ring` (slots of ring_stride doubles) and its dual variable to `dring`
+// (null: stop doing so)
+void gl_tile_batch_set_ring(gl_logdeg *s, double *ring, int64_t ring_stride, double *dring, int64_t dring_stride) {
+    gl_tile *t = s->tile;
+    t->ring = ring, t->dring = dring;
+    t->ring_stride = ring_stride, t->dring_stride = dring_stride;
+}
+
 // 2 gamma z of every graph of the batch in the batch's own tiled buffer (devs: the sessions' device views, on the device)
 int gl_tile_batch_make_zg(gl_logdeg *s, const LogdegDev *devs_dev, int B) {
     gl_tile *t = s->tile;
@@ -2114,6 +2151,10 @@ int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int fina
     P.NWG1 = t->NWG1;
     P.ntiles1 = t->ntiles1;
     P.t2lo = tol * tol * (1 + 1e-9);
+    P.ring = t->batch ? t->ring : nullptr;
+    P.dring = t->batch ? t->dring : nullptr;
+    P.ring_stride = t->ring_stride;
+    P.dring_stride = t->dring_stride;
     if (tol > 0 || t->batch) norms = true;
     P.it0 = s->it;
     P.maxit = (int)std::min<int64_t>(iters, 1 << 30);

@@ -162,6 +162,34 @@ def test_batched_cruise_on_the_tile_engine(n, b, hook, monkeypatch, capfd):
     assert np.array_equal(out, out2)
 
 
+@pytest.mark.parametrize("ring_k", ["2", "7", "32", "off"])
+@pytest.mark.parametrize("n,b,tol,maxit", [(256, 8, 1e-4, 2000), (200, 20, 3e-4, 2000), (256, 6, 1e-4, 150), (320, 3, 0.0, 90)])
+def test_batched_deciding_chunks_on_the_ring(n, b, tol, maxit, ring_k, monkeypatch, capfd):
+    """Behind the cruise the exact rule is judged in chunks: the tile engine runs K iterations per launch and writes every
+    iterate to a ring, one launch (k_batch_gram_ring) judges all K exactly (Gram matrices on MFMA, rigorous brackets), and the
+    first iteration that meets the rule ends the chunk -- its state is rebuilt from the chunk's start.  Whatever K (2: a replay
+    nearly every time; 7: chunks that do not divide the run; 32: the default; off: the batched launches instead): the oracle's
+    stopping iteration, iterates and ratios -- also when the budget ends the run inside a chunk, and with tol = 0."""
+    monkeypatch.setenv("GRAPHLEARN_AMD_BATCH_DEBUG", "1")
+    if ring_k == "off":
+        monkeypatch.setenv("GRAPHLEARN_AMD_BATCH_NO_RING", "1")
+    else:
+        monkeypatch.setenv("GRAPHLEARN_AMD_BATCH_RING_K", ring_k)
+    rng = default_rng(77 * n + b)
+    z = rng.uniform(0.1, 3.0, size=(1, n * (n - 1) // 2)) * rng.uniform(0.85, 1.15, size=(b, n * (n - 1) // 2))   # alike: long deciding stretch
+    ref, info = old.learn_log_degrees(z, 1.0, 1.0, maxit=maxit, tol=tol, edge_tol=-np.inf, return_info=True)
+    out, got = gsp_learn_graph_log_degrees(z, 1.0, 1.0, maxit=maxit, tol=tol, edge_tol=-np.inf, return_info=True)
+    err = capfd.readouterr().err
+    rings = [l for l in err.splitlines() if l.startswith("[batch ring]")]
+    assert (len(rings) == 1) == (ring_k != "off"), err[-400:]
+    assert got["n_iter"] == info["n_iter"] and got["converged"] == (info["n_iter"] < maxit)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-10)
+    assert got["rel_primal"] == pytest.approx(info["rel"][0], rel=1e-8)
+    assert got["rel_dual"] == pytest.approx(info["rel"][1], rel=1e-8)
+    if ring_k != "off":
+        assert "back to the launches 0" in rings[0] and f"at iteration {info['n_iter']}," in rings[0], rings[0]
+
+
 def test_window_model_large_windows_theta_on_device_and_session_pool():
     """Windows of n = 200 nodes: theta never leaves the device before the distances are scaled (the finish of get_theta --
     NumPy's pairwise means, smooth_learning.py:204-211 -- by one device thread, any n), the sessions' device blocks come from and
