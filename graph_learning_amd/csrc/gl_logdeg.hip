@@ -2241,7 +2241,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                 const unsigned ge = (unsigned)std::max<int64_t>(1, std::min<int64_t>(128, gram_units / (4 * GRAM_WAVES)));
                 bool ring_ok = B <= BATCH_BRACKET_MAXB && !getenv("GRAPHLEARN_AMD_BATCH_NO_RING");
                 if (ring_ok && !bc->ring_arena) {
-                    int K = getenv("GRAPHLEARN_AMD_BATCH_RING_K") ? std::max(2, std::min(64, atoi(getenv("GRAPHLEARN_AMD_BATCH_RING_K")))) : 32;
+                    int K = getenv("GRAPHLEARN_AMD_BATCH_RING_K") ? std::max(2, std::min(64, atoi(getenv("GRAPHLEARN_AMD_BATCH_RING_K")))) : 64;
                     const size_t slot = (size_t)B * tiled1 * 8, dslot = (size_t)C.n_pad * 8;
                     while (K > 4 && (K + 1) * slot > ((size_t)3 << 30)) K /= 2;
                     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -2268,8 +2268,12 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                 const size_t wbytes = (size_t)B * tiled1 * 8, dbytes = (size_t)C.n_pad * 8;
                 const double t2r = tol * tol;
                 int chunks = 0, replays = 0;
+                // (chunks of 16, 32, then K = 64 iterations: a short deciding stretch wastes little behind its stopping
+                //  iteration, a long one spreads a chunk's fixed cost -- ~150 us -- over many)
+                int kcur = getenv("GRAPHLEARN_AMD_BATCH_RING_K") ? bc->ring_k : std::min(16, bc->ring_k);
                 while (ring_ok && !back_to_launches && n_done < maxit) {
-                    const int Kc = (int)std::min<int64_t>(bc->ring_k, maxit - n_done);
+                    const int Kc = (int)std::min<int64_t>(kcur, maxit - n_done);
+                    kcur = std::min(bc->ring_k, 2 * kcur);
                     const int64_t it_ck = cs.it;
                     GL_HIP(ctx, hipMemcpyAsync(bc->ring, C.w[it_ck & 1], wbytes, hipMemcpyDeviceToDevice, ctx->stream));
                     GL_HIP(ctx, hipMemcpyAsync(bc->dring, C.dvar, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -2342,7 +2346,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                     }
                 }
                 if (getenv("GRAPHLEARN_AMD_BATCH_DEBUG") && ring_ok)
-                    fprintf(stderr, "[batch ring] %d chunks of %d iterations, %d replays, at iteration %lld, finished %d, back to the launches %d\n", chunks,
+                    fprintf(stderr, "[batch ring] %d chunks of up to %d iterations, %d replays, at iteration %lld, finished %d, back to the launches %d\n", chunks,
                             bc->ring_k, replays, (long long)n_done, (int)ring_finished, (int)back_to_launches);
                 if (!ring_finished) {  // the budget ran out, or the ring is not available: the sessions take over where the engine stands
                     k_batch_copy_state<<<cgrid, 256, 0, ctx->stream>>>((const LogdegDev *)sc.devs, C, tiled1, D0.n_pad, D0.nb, (int)(n_done & 1), 1,
