@@ -2295,7 +2295,8 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                         GL_HIP(ctx, hipMemcpyAsync(C.dprev, bc->ckpt + 2 * C.n_pad, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
                         return GL_OK;
                     };
-                    if (nr2 || got != Kc) {  // (the workgroups did not meet: nothing was written; the launches below go on from here)
+                    // (the workgroups did not meet: nothing was written; the launches below go on from here.  Test hook: as if)
+                    if (nr2 || got != Kc || (chunks == 1 && getenv("GRAPHLEARN_AMD_BATCH_TEST_RING_FAIL"))) {
                         GL_TRY(restore());
                         back_to_launches = true;
                         break;

@@ -190,6 +190,24 @@ def test_batched_deciding_chunks_on_the_ring(n, b, tol, maxit, ring_k, monkeypat
         assert "back to the launches 0" in rings[0] and f"at iteration {info['n_iter']}," in rings[0], rings[0]
 
 
+def test_batched_deciding_chunk_that_fails_hands_over_to_the_launches(monkeypatch, capfd):
+    """A deciding chunk whose launch cannot run (test hook: the second one is treated as not co-resident) puts the chunk's start
+    state back and hands the batch -- both iterates -- to the batched launches, which finish the run: same result."""
+    monkeypatch.setenv("GRAPHLEARN_AMD_BATCH_DEBUG", "1")
+    monkeypatch.setenv("GRAPHLEARN_AMD_BATCH_TEST_RING_FAIL", "1")
+    monkeypatch.setenv("GRAPHLEARN_AMD_BATCH_RING_K", "8")
+    n, b = 256, 6
+    rng = default_rng(3)
+    z = rng.uniform(0.1, 3.0, size=(1, n * (n - 1) // 2)) * rng.uniform(0.85, 1.15, size=(b, n * (n - 1) // 2))
+    ref, info = old.learn_log_degrees(z, 1.0, 1.0, maxit=2000, tol=1e-4, edge_tol=-np.inf, return_info=True)
+    out, got = gsp_learn_graph_log_degrees(z, 1.0, 1.0, maxit=2000, tol=1e-4, edge_tol=-np.inf, return_info=True)
+    err = capfd.readouterr().err
+    assert "back to the launches 1" in err and "[batch ring] 1 chunks" in err, err[-300:]
+    assert got["n_iter"] == info["n_iter"] and got["converged"]
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-10)
+    assert got["rel_primal"] == pytest.approx(info["rel"][0], rel=1e-8)
+
+
 def test_window_model_large_windows_theta_on_device_and_session_pool():
     """Windows of n = 200 nodes: theta never leaves the device before the distances are scaled (the finish of get_theta --
     NumPy's pairwise means, smooth_learning.py:204-211 -- by one device thread, any n), the sessions' device blocks come from and
