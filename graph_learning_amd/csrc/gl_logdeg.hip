@@ -2238,6 +2238,9 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                 // of exactly that many iterations.  ~10 us per iteration where the three launches per iteration below take 32-45.
                 const int nbk = B <= 16 ? 1 : 3;
                 const int64_t gram_units = tiled1 / 16;
+                // (measured without effect: a workgroup count per judged iteration that is a multiple of 8, so that the two readers
+                //  of a slot's stretch share an XCD's L2.  At B = 20 the judging launch takes 6 us per iteration -- one workgroup
+                //  per CU at its register count, 16 dependent load-multiply turns each --, at B = 8 1.7)
                 const unsigned ge = (unsigned)std::max<int64_t>(1, std::min<int64_t>(128, gram_units / (4 * GRAM_WAVES)));
                 bool ring_ok = B <= BATCH_BRACKET_MAXB && !getenv("GRAPHLEARN_AMD_BATCH_NO_RING");
                 if (ring_ok && !bc->ring_arena) {
