@@ -1056,7 +1056,7 @@ struct RingJudge {
     int decision[64];
 };
 template <int NG>
-__global__ __launch_bounds__(GRAM_WAVES * 64) void k_batch_gram_ring(const double *__restrict__ ring, const double *__restrict__ dring, int nprob,
+__global__ __launch_bounds__(GRAM_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4))) void k_batch_gram_ring(const double *__restrict__ ring, const double *__restrict__ dring, int nprob,
                                                                      int64_t ring_stride, int64_t tiled1, int64_t dring_stride, int64_t n_pad1,
                                                                      double *__restrict__ part_all, double t2, RingJudge *rj) {
     constexpr int NBLK = NG == 1 ? 1 : 3;
@@ -2239,8 +2239,8 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                 const int nbk = B <= 16 ? 1 : 3;
                 const int64_t gram_units = tiled1 / 16;
                 // (measured without effect: a workgroup count per judged iteration that is a multiple of 8, so that the two readers
-                //  of a slot's stretch share an XCD's L2.  At B = 20 the judging launch takes 6 us per iteration -- one workgroup
-                //  per CU at its register count, 16 dependent load-multiply turns each --, at B = 8 1.7)
+                //  of a slot's stretch share an XCD's L2.  At B = 20 the judging launch takes ~5 us per iteration -- two workgroups
+                //  per CU at 128 registers, 16 dependent load-multiply turns each --, at B = 8 1.7)
                 const unsigned ge = (unsigned)std::max<int64_t>(1, std::min<int64_t>(128, gram_units / (4 * GRAM_WAVES)));
                 bool ring_ok = B <= BATCH_BRACKET_MAXB && !getenv("GRAPHLEARN_AMD_BATCH_NO_RING");
                 if (ring_ok && !bc->ring_arena) {
