@@ -22,6 +22,7 @@
 #include "gl_logdeg.h"
 
 #include <algorithm>
+#include <chrono>
 #include <limits>
 #include <type_traits>
 #include <vector>
@@ -2197,7 +2198,10 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
             same = Da.gamma == D0.gamma && Da.c == D0.c && Da.a4g == D0.a4g;
         }
         BatchCruise *bc = nullptr;
+        const auto t_get0 = std::chrono::steady_clock::now();
         if (same) GL_TRY(batch_cruise_get(ctx, sessions, B, &bc));
+        if (getenv("GRAPHLEARN_AMD_BATCH_DEBUG"))
+            fprintf(stderr, "[batch cruise] stand-in session: %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_get0).count());
         if (bc) {
             gl_logdeg &cs = bc->cs;
             LogdegDev &C = cs.dev;
@@ -2243,6 +2247,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                 //  per CU at 128 registers, 16 dependent load-multiply turns each --, at B = 8 1.7)
                 const unsigned ge = (unsigned)std::max<int64_t>(1, std::min<int64_t>(128, gram_units / (4 * GRAM_WAVES)));
                 bool ring_ok = B <= BATCH_BRACKET_MAXB && !getenv("GRAPHLEARN_AMD_BATCH_NO_RING");
+                const auto t_ring0 = std::chrono::steady_clock::now();
                 if (ring_ok && !bc->ring_arena) {
                     int K = getenv("GRAPHLEARN_AMD_BATCH_RING_K") ? std::max(2, std::min(64, atoi(getenv("GRAPHLEARN_AMD_BATCH_RING_K")))) : 64;
                     const size_t slot = (size_t)B * tiled1 * 8, dslot = (size_t)C.n_pad * 8;
@@ -2265,6 +2270,8 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                         ring_ok = false;
                     }
                 }
+                if (getenv("GRAPHLEARN_AMD_BATCH_DEBUG"))
+                    fprintf(stderr, "[batch ring] arena: %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ring0).count());
                 int64_t n_done = ran;
                 bool back_to_launches = !ring_ok;
                 const double *w_old = nullptr;  // the iterate before the current one (a ring slot), once a chunk has run
