@@ -2201,7 +2201,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
         const auto t_get0 = std::chrono::steady_clock::now();
         if (same) GL_TRY(batch_cruise_get(ctx, sessions, B, &bc));
         if (getenv("GRAPHLEARN_AMD_BATCH_DEBUG"))
-            fprintf(stderr, "[batch cruise] stand-in session: %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_get0).count());
+            fprintf(stderr, "[batch setup] stand-in session: %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_get0).count());
         if (bc) {
             gl_logdeg &cs = bc->cs;
             LogdegDev &C = cs.dev;
@@ -2271,7 +2271,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                     }
                 }
                 if (getenv("GRAPHLEARN_AMD_BATCH_DEBUG"))
-                    fprintf(stderr, "[batch ring] arena: %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ring0).count());
+                    fprintf(stderr, "[batch setup] ring arena: %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ring0).count());
                 int64_t n_done = ran;
                 bool back_to_launches = !ring_ok;
                 const double *w_old = nullptr;  // the iterate before the current one (a ring slot), once a chunk has run
