@@ -36,8 +36,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PROFILE_JSON = "r03_rocprof_summary.json"   # falls back to nothing when absent
-CENSUS_JSON = "r03_tile_census.json"        # instruction census of the timed kernel's pass (tools/tile_pass_census.py)
+PROFILE_JSON = "r04_rocprof_summary.json"   # falls back to nothing when absent
+CENSUS_JSON = "r04_tile_census.json"        # instruction census of the timed kernel's pass (tools/tile_pass_census.py)
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md), the roofline the streaming edge pass is bound by
 FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X fp64 vector spec = 256 CUs x 4 SIMDs x 16 lanes/clk x 2 flop x 2.4 GHz: the tile engine's roof
 
@@ -342,11 +342,14 @@ def main():
                "definition": "SURVEY 8d: 24 E algorithmic bytes per iteration (read w, read z, write w) / launch time"}
         if engine == "resident" and engine_kernel == "k_tile":
             # The tile engine keeps w in registers and half of z in LDS: those 24 E bytes do not move, so the HBM figure
-            # above exceeds 1 and bounds nothing.  What binds the kernel is the issue rate of the fp64 vector pipe: the
-            # pass is a chain of fp64 VALU instructions (census of the shipped kernel: profiles/r03_tile_census.json,
-            # tools/tile_pass_census.py), two waves per SIMD.  Peak: 256 CUs x 4 SIMDs x 16 fp64 lanes per clock x 2.4 GHz
-            # = 39.3 T lane-operations/s = the 78.6 TFLOP/s vector spec with every instruction priced as an FMA (2 flop).
-            census, census_ok = None, None
+            # above exceeds 1 and bounds nothing.  What binds the kernel is the fp64 vector pipe: the pass is a chain of fp64
+            # VALU instructions (census of the shipped kernel's pass: profiles/r04_tile_census.json, made by
+            # tools/tile_pass_census.py from the assembly of the shipped flags), two waves per SIMD.
+            #   achieved / frac   REAL flops (a fused multiply-add = 2, add / mul / max = 1) / the 78.6 TFLOP/s fp64 vector spec
+            #   valu_issue_frac   fp64 vector instructions issued / the pipe's issue slots (one wave-instruction per 4 cycles
+            #                     per SIMD whatever it computes: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s)
+            # A census that was not made from THIS gl_tile.hip (sha of the source) prices another kernel: the figures are null then.
+            census, census_ok = None, False
             try:
                 import hashlib
                 with open(os.path.join(ROOT, "profiles", CENSUS_JSON)) as f:
@@ -356,21 +359,26 @@ def main():
             except Exception:
                 census = None
             streamed_bytes = 2 * n * (n - 1)      # half of z per iteration (4 E); records ~3 MB on top
-            roof = {"bound": "valu_f64", "unit": "TFLOP/s", "peak": FP64_VALU_PEAK_TFLOPS, "achieved": None, "frac": None}
-            if census is not None:
+            roof = {"bound": "valu_f64", "unit": "TFLOP/s", "peak": FP64_VALU_PEAK_TFLOPS, "achieved": None, "frac": None,
+                    "valu_issue_frac": None}
+            if census is not None and census_ok:
                 nb = (n + 63) // 64
-                row_pairs = nb * (nb + 1) // 2 * 32                     # every tile of the lattice, diagonal ones included
-                f64_per_rp = census["per_row_pair"]["valu_f64"]
-                lane_ops = f64_per_rp * row_pairs * 64 * its_per_launch  # fp64 VALU lane-operations of the launch
-                roof["achieved"] = 2.0 * lane_ops / (launch_us * 1e-6) / 1e12
+                # row pairs the launch really runs per iteration: 32 per bulk tile + the 32 of every diagonal tile (dealt out
+                # as fringe groups; whole rows are computed, the entries outside i < j are masked) = 64 512 + 2 048 at n = 4096
+                row_pairs = nb * (nb + 1) // 2 * 32
+                per_rp = census["per_row_pair"]
+                lanes = row_pairs * 64
+                flops = per_rp["flop_f64"] * lanes * its_per_launch
+                roof["achieved"] = flops / (launch_us * 1e-6) / 1e12
                 roof["frac"] = roof["achieved"] / FP64_VALU_PEAK_TFLOPS
-                roof["flop_convention"] = ("every fp64 vector instruction priced as an FMA (2 flop per lane): the pipe issues "
-                                          "one wave-instruction per 4 cycles whatever it computes, so this is the share of "
-                                          "the fp64 issue slots the launch used; the pass mixes 6 FMAs with 12.1 adds / max")
-                roof["census"] = {"source": f"profiles/{CENSUS_JSON}", "matches_this_build": census_ok,
-                                  "per_row_pair": census["per_row_pair"], "row_pairs_per_iteration": row_pairs}
-                steady_lane = f64_per_rp * row_pairs * 64 / (steady_us * 1e-6)
-                roof["steady_state_frac"] = 2.0 * steady_lane / 1e12 / FP64_VALU_PEAK_TFLOPS
+                roof["valu_issue_frac"] = per_rp["valu_f64"] * lanes * its_per_launch / (launch_us * 1e-6) / (FP64_VALU_PEAK_TFLOPS * 0.5e12)
+                roof["flop_convention"] = ("achieved = real fp64 flops of the pass (fused multiply-add 2, add / max 1) x row pairs "
+                                          "executed (diagonal tiles' masked halves included); valu_issue_frac = share of the fp64 "
+                                          "pipe's issue slots (every instruction takes one slot)")
+                roof["steady_state_frac"] = per_rp["flop_f64"] * lanes / (steady_us * 1e-6) / 1e12 / FP64_VALU_PEAK_TFLOPS
+                roof["steady_state_valu_issue_frac"] = per_rp["valu_f64"] * lanes / (steady_us * 1e-6) / (FP64_VALU_PEAK_TFLOPS * 0.5e12)
+            roof["census"] = {"source": f"profiles/{CENSUS_JSON}", "matches_this_build": census_ok,
+                              "per_row_pair": census["per_row_pair"] if census is not None else None}
             roof.update({"traffic": traffic, "traffic_source": traffic_src, "kernel": kernel,
                          "iterations_per_launch": its_per_launch, "avg_launch_us": launch_us,
                          "streamed_bytes_per_iteration": streamed_bytes,

@@ -44,6 +44,7 @@ SIGNATURES = {
     "gl_last_error": (C.c_char_p, [C.c_void_p]),
     "gl_ctx_device_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "gl_ctx_sync": (C.c_int, [C.c_void_p]),
+    "gl_ctx_trim": (C.c_int, [C.c_void_p]),
     "gl_ctx_timer_start": (C.c_int, [C.c_void_p]),
     "gl_ctx_timer_stop": (C.c_int, [C.c_void_p, _c_double_p]),
     "gl_logdeg_create": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
@@ -99,6 +100,8 @@ SIGNATURES = {
     "gl_graphdict_time_gradients": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p]),
     "gl_comm_unique_id": (C.c_int, [C.c_void_p]),
     "gl_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gl_comm_set_timeout": (C.c_int, [C.c_void_p, C.c_double]),
+    "gl_comm_abort": (C.c_int, [C.c_void_p]),
     "gl_comm_destroy": (C.c_int, [C.c_void_p]),
     "gl_comm_barrier": (C.c_int, [C.c_void_p]),
     "gl_comm_allreduce_max": (C.c_int, [C.c_void_p, _c_double_p]),
@@ -194,6 +197,11 @@ class Context:
 
     def sync(self):
         self.check(self._lib.gl_ctx_sync(self._h), "sync")
+
+    def trim(self):
+        """Give back the device memory the context retains between calls (session pool, the batched solver's
+        stand-in session and ring, scratch)."""
+        self.check(self._lib.gl_ctx_trim(self._h), "trim")
 
     def timer_start(self):
         self.check(self._lib.gl_ctx_timer_start(self._h), "timer_start")

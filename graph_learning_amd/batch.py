@@ -27,12 +27,18 @@ import numpy as np
 from . import _lib
 
 
-def _host_record(session, edge_tol, problem_id, n_iter, theta, converged):
+def _host_record(session, edge_tol, problem_id, n_iter, theta, converged, failed=False):
     """One gather record (wire.py: 64-byte header + condensed weights) built on the host."""
     from . import wire
 
     return wire.pack(session.weights_condensed(edge_tol), problem_id=problem_id, n_iter=n_iter, theta=theta,
-                     edge_tol=edge_tol, converged=converged)
+                     edge_tol=edge_tol, converged=converged, failed=failed)
+
+
+class BatchError(RuntimeError):
+    """A rank of the batch failed.  Every collective is entered by all ranks or by none (a failing rank sends a
+    record flagged `failed`, or aborts the communicator when it cannot even do that), and every wait is bounded, so
+    the other ranks see this error instead of waiting for the launcher to kill them."""
 
 
 class SingleComm:
@@ -52,8 +58,11 @@ class SingleComm:
     def allgather_condensed(self, session, edge_tol=1e-3) -> np.ndarray:
         return session.weights_condensed(edge_tol)[None]
 
-    def allgather_records(self, session, edge_tol, problem_id, n_iter, theta, converged=False) -> np.ndarray:
-        return _host_record(session, edge_tol, problem_id, n_iter, theta, converged)[None]
+    def allgather_records(self, session, edge_tol, problem_id, n_iter, theta, converged=False, failed=False) -> np.ndarray:
+        return _host_record(session, edge_tol, problem_id, n_iter, theta, converged, failed)[None]
+
+    def abort(self):
+        pass
 
     def close(self):
         pass
@@ -63,7 +72,7 @@ class RcclComm:
     """RCCL communicator bound to a ``_lib.Context`` (one rank per GPU)."""
 
     def __init__(self, ctx: _lib.Context, rank: int, world: int, rendezvous_key: str | None = None,
-                 timeout_s: float = 120.0):
+                 timeout_s: float = 120.0, comm_timeout_s: float = 300.0):
         self.ctx, self.rank, self.world = ctx, int(rank), int(world)
         self._lib = ctx._lib
         uid = (C.c_char * 128)()
@@ -94,6 +103,8 @@ class RcclComm:
         h = C.c_void_p()
         ctx.check(self._lib.gl_comm_create(ctx.handle, self.rank, self.world, uid, C.byref(h)), "comm_create")
         self._h = h
+        # every wait for a collective is bounded (gl_comm.hip): a rank that never arrives ends the others with an error
+        ctx.check(self._lib.gl_comm_set_timeout(h, float(os.environ.get("GRAPHLEARN_AMD_COMM_TIMEOUT_S", comm_timeout_s))), "comm_set_timeout")
         self.barrier()
         if self.rank == 0:
             try:
@@ -130,14 +141,20 @@ class RcclComm:
                        "comm_allgather_f64")
         return out
 
-    def allgather_records(self, session, edge_tol, problem_id, n_iter, theta, converged=False) -> np.ndarray:
+    def allgather_records(self, session, edge_tol, problem_id, n_iter, theta, converged=False, failed=False) -> np.ndarray:
         """(world, 8 + E): every rank's self-describing record (wire.py) -- header and weights travel
         together through ONE RCCL all-gather, straight from device memory."""
         out = np.empty((self.world, 8 + session.n_edges))
+        flags = (1 if converged else 0) | (2 if failed else 0)
         self.ctx.check(self._lib.gl_comm_allgather_records(self._h, session._h, float(edge_tol), int(problem_id),
-                                                           int(n_iter), float(theta), int(bool(converged)),
+                                                           int(n_iter), float(theta), flags,
                                                            _lib.ptr(out)), "comm_allgather_records")
         return out
+
+    def abort(self):
+        """This rank cannot go on: nobody must wait for it (ncclCommAbort; later calls fail at once)."""
+        if getattr(self, "_h", None):
+            self._lib.gl_comm_abort(self._h)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -154,12 +171,17 @@ class RcclComm:
 class GlooComm:
     """torch.distributed (gloo) communicator over host buffers -- CPU tests / fallback."""
 
-    def __init__(self, rank: int, world: int, init_method: str | None = None):
+    def __init__(self, rank: int, world: int, init_method: str | None = None, timeout_s: float | None = None):
+        import datetime
+
         import torch.distributed as dist
 
         self._dist = dist
         self.rank, self.world = int(rank), int(world)
         self._own = not dist.is_initialized()
+        # the bound of every collective: a rank that never enters one ends the others with an error after this long
+        timeout_s = float(os.environ.get("GRAPHLEARN_AMD_COMM_TIMEOUT_S", 300.0 if timeout_s is None else timeout_s))
+        self.timeout_s = timeout_s
         if self._own:
             if init_method is None:
                 if "TORCHELASTIC_RUN_ID" in os.environ:  # under torch.distributed.run: use the agent's store
@@ -168,7 +190,8 @@ class GlooComm:
                     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
                     port = os.environ.get("MASTER_PORT", "29500")
                     init_method = f"tcp://{addr}:{port}"
-            dist.init_process_group("gloo", init_method=init_method, rank=self.rank, world_size=self.world)
+            dist.init_process_group("gloo", init_method=init_method, rank=self.rank, world_size=self.world,
+                                    timeout=datetime.timedelta(seconds=timeout_s))
 
     def barrier(self):
         self._dist.barrier()
@@ -191,8 +214,11 @@ class GlooComm:
     def allgather_condensed(self, session, edge_tol=1e-3) -> np.ndarray:
         return self.allgather_arrays(session.weights_condensed(edge_tol))
 
-    def allgather_records(self, session, edge_tol, problem_id, n_iter, theta, converged=False) -> np.ndarray:
-        return self.allgather_arrays(_host_record(session, edge_tol, problem_id, n_iter, theta, converged))
+    def allgather_records(self, session, edge_tol, problem_id, n_iter, theta, converged=False, failed=False) -> np.ndarray:
+        return self.allgather_arrays(_host_record(session, edge_tol, problem_id, n_iter, theta, converged, failed))
+
+    def abort(self):
+        """Nothing to tear down on the host side: the peers' collectives end at the process group's timeout."""
 
     def close(self):
         if self._own and self._dist.is_initialized():
@@ -200,21 +226,22 @@ class GlooComm:
 
 
 def make_comm(rank: int, world: int, local_rank: int = 0, ctx: _lib.Context | None = None, backend: str | None = None,
-              allow_fallback: bool = True):
+              allow_fallback: bool = True, timeout_s: float = 300.0):
     """RCCL by default; ``GRAPHLEARN_AMD_COMM=gloo`` (or backend="gloo") selects the host-staged
     torch.distributed/gloo communicator.  If RCCL cannot be brought up at all (library missing,
     communicator init error on every rank) the gloo communicator is used instead and says so
     (``comm.kind == "gloo-fallback"``) -- a slower gather, never a silent change of the solver; with
-    ``allow_fallback=False`` (bench.py) the RCCL error is raised instead."""
+    ``allow_fallback=False`` (bench.py) the RCCL error is raised instead.  ``timeout_s`` bounds every wait for a
+    collective (a rank that never arrives ends the others with an error, not with the launcher's kill)."""
     if world <= 1:
         return SingleComm()
     backend = backend or os.environ.get("GRAPHLEARN_AMD_COMM", "rccl")
     if backend == "gloo":
-        c = GlooComm(rank, world)
+        c = GlooComm(rank, world, timeout_s=timeout_s)
         c.kind = "gloo"
         return c
     try:
-        c = RcclComm(ctx or _lib.Context(local_rank), rank, world)
+        c = RcclComm(ctx or _lib.Context(local_rank), rank, world, comm_timeout_s=timeout_s)
         c.kind = "rccl"
         return c
     except (_lib.GraphLearnError, TimeoutError, OSError) as exc:
@@ -222,7 +249,7 @@ def make_comm(rank: int, world: int, local_rank: int = 0, ctx: _lib.Context | No
             raise
         print(f"[graph_learning_amd] rank {rank}: RCCL communicator unavailable ({exc}); falling back to gloo",
               flush=True)
-        c = GlooComm(rank, world)
+        c = GlooComm(rank, world, timeout_s=timeout_s)
         c.kind = "gloo-fallback"
         return c
 
@@ -298,26 +325,50 @@ class LogModelBatch:
         with session as s:
             for r in range(rounds):
                 idx = r * comm.world + comm.rank
-                if idx < n_items:
-                    theta = s.set_signals(xs[idx], self.avg_degree)
-                    s.init(1, 1, self.step_size, None)
-                    n_it, conv, _ = s.iterate(self.maxit, self.tol)
-                    pid = idx
-                else:  # idle rank in the last round: contribute the zero iterate under problem id -1
-                    theta, n_it, conv, pid = 1.0, 0, False, -1
-                    s.set_distances(np.zeros(n_edges))
-                    s.init(1, 1, self.step_size, None)
-                gathered = comm.allgather_records(s, self.edge_tol, pid, n_it, theta, conv)
+                theta, n_it, conv, pid, err = 1.0, 0, False, -1, None
+                try:
+                    if idx < n_items:
+                        pid = idx
+                        theta = s.set_signals(xs[idx], self.avg_degree)
+                        s.init(1, 1, self.step_size, None)
+                        n_it, conv, _ = s.iterate(self.maxit, self.tol)
+                    else:  # idle rank in the last round: contribute the zero iterate under problem id -1
+                        s.set_distances(np.zeros(n_edges))
+                        s.init(1, 1, self.step_size, None)
+                except Exception as exc:  # noqa: BLE001 -- whatever it is, the other ranks must not wait for this one
+                    err = exc
+                # Every rank enters the gather, also one whose problem failed: it sends the zero iterate flagged `failed`,
+                # so the others get their answer now instead of a timeout.  A rank that cannot even do that aborts the
+                # communicator (its peers' wait is bounded and ends with an error).
+                try:
+                    if err is not None:
+                        theta, n_it, conv = 1.0, 0, False
+                        s.set_distances(np.zeros(n_edges))
+                        s.init(1, 1, self.step_size, None)
+                    gathered = comm.allgather_records(s, self.edge_tol, pid, n_it, theta, conv, failed=err is not None)
+                except Exception as exc2:  # noqa: BLE001
+                    if hasattr(comm, "abort"):
+                        comm.abort()
+                    raise BatchError(f"rank {comm.rank}: could not take part in the gather of round {r}: {exc2!r}"
+                                     + (f" (after {err!r})" if err is not None else "")) from (err or exc2)
+                bad = []
                 for src in range(comm.world):
                     j = r * comm.world + src
+                    rec = wire.unpack(gathered[src])
+                    if rec["failed"]:
+                        bad.append((src, rec["problem_id"]))
+                        continue
                     if j >= n_items:
                         continue
-                    rec = wire.unpack(gathered[src])
                     if rec["problem_id"] != j or rec["n_nodes"] != n_nodes:
                         raise RuntimeError(f"gathered record of rank {src} is for problem {rec['problem_id']} "
                                            f"({rec['n_nodes']} nodes), expected problem {j} ({n_nodes} nodes)")
                     self.weights_[j] = rec["weights"]
                     self.theta_[j], self.n_iter_[j], self.converged_[j] = rec["theta"], rec["n_iter"], rec["converged"]
+                if bad:  # the same exception on every rank, at the same point: nobody goes on into the next round alone
+                    what = ", ".join(f"rank {src} (problem {p})" for src, p in bad)
+                    raise BatchError(f"round {r}: {what} failed to solve its problem"
+                                     + (f": {err!r}" if err is not None else "")) from err
         return self
 
     def records(self):

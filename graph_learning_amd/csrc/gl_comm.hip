@@ -5,7 +5,18 @@
 //
 // The reference has no communication layer at all; this is the
 // one collective step BASELINE config 4 adds: gather the learned adjacencies.
+//
+// No call here can hang a node.  A collective only completes when EVERY rank enters it, so
+//   * a rank that hits a local error on its way into one (an allocation, a copy, the solver's staging) ABORTS the
+//     communicator (ncclCommAbort) before it returns the error: it will never enter, and says so;
+//   * every wait for a collective is bounded by the wall clock (gl_comm_set_timeout, default 300 s, or
+//     GRAPHLEARN_AMD_COMM_TIMEOUT_S): a rank whose peer never arrives aborts the communicator too and returns
+//     GL_E_COMM instead of waiting for the launcher's kill;
+//   * an aborted communicator fails every later call at once (GL_E_COMM); the process is expected to exit non-zero.
 #include <dlfcn.h>
+#include <time.h>
+
+#include <chrono>
 
 #include "gl_logdeg.h"
 
@@ -26,6 +37,8 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                      // (optional)
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;  // (optional)
     ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -48,6 +61,8 @@ RcclApi *rccl() {
             api.AllGather = (decltype(api.AllGather))dlsym(api.handle, "ncclAllGather");
             api.AllReduce = (decltype(api.AllReduce))dlsym(api.handle, "ncclAllReduce");
             api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
+            api.CommAbort = (decltype(api.CommAbort))dlsym(api.handle, "ncclCommAbort");
+            api.CommGetAsyncError = (decltype(api.CommGetAsyncError))dlsym(api.handle, "ncclCommGetAsyncError");
             if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.AllReduce) {
                 dlclose(api.handle);
                 api.handle = nullptr;
@@ -66,6 +81,8 @@ struct gl_comm {
     double *scratch = nullptr;  // a few device words for barrier / scalar reductions
     double *gather = nullptr;   // device receive buffer of the last gather
     size_t gather_bytes = 0;
+    double timeout_s = 300.0;   // wall-clock bound of every wait for a collective
+    bool dead = false;          // aborted: a local error in front of a collective, or a peer that never arrived
 };
 
 #define GL_NCCL(ctx, call)                                                                        \
@@ -75,6 +92,81 @@ struct gl_comm {
             return gl_set_error((ctx), GL_E_COMM, "%s failed: %s", #call,                         \
                                 rccl()->GetErrorString ? rccl()->GetErrorString(r_) : "rccl error"); \
     } while (0)
+
+namespace {
+
+// This rank will not take part in the collectives to come (or gave up waiting for one): tear the communicator down so that
+// nothing of it stays queued on the stream, and remember.  Returns `code` (the error that led here; ctx->err is the caller's).
+int comm_fail(gl_comm *c, int code) {
+    if (!c->dead) {
+        c->dead = true;
+        RcclApi *api = rccl();
+        if (c->comm && api) {
+            if (api->CommAbort) api->CommAbort(c->comm);  // (also ends a collective kernel that waits for a peer)
+            else api->CommDestroy(c->comm);
+            c->comm = nullptr;
+        }
+    }
+    return code;
+}
+
+int comm_alive(gl_comm *c) {
+    if (!c->dead) return GL_OK;
+    return gl_set_error(c->ctx, GL_E_COMM, "rank %d: the communicator was aborted (an earlier error on this rank, or a peer that never arrived)", c->rank);
+}
+
+// Waits for everything queued on the context's stream -- a collective among it -- for at most timeout_s.
+int comm_wait(gl_comm *c, const char *what) {
+    gl_ctx *ctx = c->ctx;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t e = hipStreamQuery(ctx->stream);
+        if (e == hipSuccess) {
+            gl_stage_idle(ctx);  // (the stream has drained: no staged upload is in flight any more)
+            return GL_OK;
+        }
+        if (e != hipErrorNotReady) {
+            (void)hipGetLastError();
+            gl_set_error(ctx, GL_E_HIP, "%s: %s", what, hipGetErrorString(e));
+            return comm_fail(c, GL_E_HIP);
+        }
+        if ((spins & 255u) == 255u) {
+            RcclApi *api = rccl();
+            ncclResult_t ar = ncclSuccess;
+            if (api->CommGetAsyncError && c->comm && api->CommGetAsyncError(c->comm, &ar) == ncclSuccess && ar != ncclSuccess) {
+                gl_set_error(ctx, GL_E_COMM, "%s: %s", what, api->GetErrorString ? api->GetErrorString(ar) : "rccl asynchronous error");
+                return comm_fail(c, GL_E_COMM);
+            }
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (el > c->timeout_s) {
+                gl_set_error(ctx, GL_E_COMM, "%s: rank %d of %d waited %.0f s for the other ranks (one of them is missing); communicator aborted",
+                             what, c->rank, c->nranks, el);
+                return comm_fail(c, GL_E_COMM);
+            }
+        }
+        if (spins > 2000u) {  // (the first ~2000 polls back to back: a barrier among live ranks takes microseconds)
+            const timespec ts{0, 50000};
+            nanosleep(&ts, nullptr);
+        }
+    }
+}
+
+// the receive buffer of the gathers
+int comm_gather_buffer(gl_comm *c, size_t bytes) {
+    gl_ctx *ctx = c->ctx;
+    if (c->gather_bytes >= bytes) return GL_OK;
+    if (c->gather) {
+        GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(c->gather);
+    }
+    c->gather = nullptr;
+    c->gather_bytes = 0;
+    GL_MALLOC(ctx, (void **)&c->gather, bytes, "comm");
+    c->gather_bytes = bytes;
+    return GL_OK;
+}
+
+}  // namespace
 
 GL_API int gl_comm_unique_id(void *out128) {
     if (!out128) return GL_E_INVALID;
@@ -98,6 +190,7 @@ GL_API int gl_comm_create(gl_ctx *ctx, int rank, int nranks, const void *unique_
     c->ctx = ctx;
     c->rank = rank;
     c->nranks = nranks;
+    if (const char *e = getenv("GRAPHLEARN_AMD_COMM_TIMEOUT_S")) c->timeout_s = std::max(0.01, atof(e));
     ncclUniqueId id;
     memcpy(id.internal, unique_id128, sizeof id.internal);
     ncclResult_t r = api->CommInitRank(&c->comm, nranks, id, rank);
@@ -106,12 +199,27 @@ GL_API int gl_comm_create(gl_ctx *ctx, int rank, int nranks, const void *unique_
         return gl_set_error(ctx, GL_E_COMM, "ncclCommInitRank failed: %s",
                             api->GetErrorString ? api->GetErrorString(r) : "rccl error");
     }
-    if (hipMalloc((void **)&c->scratch, 64) != hipSuccess) {
-        api->CommDestroy(c->comm);
+    if (gl_ctx_malloc(ctx, (void **)&c->scratch, 64, "comm_create") != hipSuccess) {
+        if (api->CommAbort) api->CommAbort(c->comm);  // (the peers' first collective then fails instead of waiting for this rank)
+        else api->CommDestroy(c->comm);
         delete c;
         return gl_set_error(ctx, GL_E_NOMEM, "hipMalloc failed");
     }
     *out = c;
+    return GL_OK;
+}
+
+GL_API int gl_comm_set_timeout(gl_comm *c, double seconds) {
+    if (!c || !(seconds > 0)) return GL_E_INVALID;
+    c->timeout_s = seconds;
+    return GL_OK;
+}
+
+// This rank cannot go on (its caller failed in front of a collective): nobody must wait for it.
+GL_API int gl_comm_abort(gl_comm *c) {
+    if (!c) return GL_E_INVALID;
+    (void)hipSetDevice(c->ctx->device);
+    (void)comm_fail(c, GL_OK);
     return GL_OK;
 }
 
@@ -132,22 +240,30 @@ GL_API int gl_comm_destroy(gl_comm *c) {
 GL_API int gl_comm_barrier(gl_comm *c) {
     if (!c) return GL_E_INVALID;
     gl_ctx *ctx = c->ctx;
-    GL_HIP(ctx, hipSetDevice(ctx->device));
-    GL_HIP(ctx, hipMemsetAsync(c->scratch, 0, 8, ctx->stream));
-    GL_NCCL(ctx, rccl()->AllReduce(c->scratch, c->scratch + 1, 1, ncclInt32, ncclSum, c->comm, ctx->stream));
-    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return GL_OK;
+    GL_TRY(comm_alive(c));
+    const int rc = [&]() -> int {
+        GL_HIP(ctx, hipSetDevice(ctx->device));
+        GL_HIP(ctx, hipMemsetAsync(c->scratch, 0, 8, ctx->stream));
+        GL_NCCL(ctx, rccl()->AllReduce(c->scratch, c->scratch + 1, 1, ncclInt32, ncclSum, c->comm, ctx->stream));
+        return GL_OK;
+    }();
+    if (rc != GL_OK) return comm_fail(c, rc);
+    return comm_wait(c, "gl_comm_barrier");
 }
 
 GL_API int gl_comm_allreduce_max(gl_comm *c, double *value) {
     if (!c || !value) return GL_E_INVALID;
     gl_ctx *ctx = c->ctx;
-    GL_HIP(ctx, hipSetDevice(ctx->device));
-    GL_HIP(ctx, hipMemcpyAsync(c->scratch + 2, value, 8, hipMemcpyHostToDevice, ctx->stream));
-    GL_NCCL(ctx, rccl()->AllReduce(c->scratch + 2, c->scratch + 3, 1, ncclFloat64, ncclMax, c->comm, ctx->stream));
-    GL_HIP(ctx, hipMemcpyAsync(value, c->scratch + 3, 8, hipMemcpyDeviceToHost, ctx->stream));
-    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return GL_OK;
+    GL_TRY(comm_alive(c));
+    const int rc = [&]() -> int {
+        GL_HIP(ctx, hipSetDevice(ctx->device));
+        GL_HIP(ctx, hipMemcpyAsync(c->scratch + 2, value, 8, hipMemcpyHostToDevice, ctx->stream));
+        GL_NCCL(ctx, rccl()->AllReduce(c->scratch + 2, c->scratch + 3, 1, ncclFloat64, ncclMax, c->comm, ctx->stream));
+        GL_HIP(ctx, hipMemcpyAsync(value, c->scratch + 3, 8, hipMemcpyDeviceToHost, ctx->stream));
+        return GL_OK;
+    }();
+    if (rc != GL_OK) return comm_fail(c, rc);
+    return comm_wait(c, "gl_comm_allreduce_max");
 }
 
 // Gather of the learned adjacencies (BASELINE config 4): every rank contributes its
@@ -158,21 +274,19 @@ GL_API int gl_comm_allgather_weights(gl_comm *c, gl_logdeg *s, double edge_tol, 
     if (!c || !s) return GL_E_INVALID;
     gl_ctx *ctx = c->ctx;
     if (s->ctx != ctx) return gl_set_error(ctx, GL_E_INVALID, "session and communicator live on different contexts");
-    GL_HIP(ctx, hipSetDevice(ctx->device));
-    // the session's staging buffer receives the condensed, thresholded weights (device only)
-    GL_TRY(gl_logdeg_get_weights_condensed(s, edge_tol, nullptr));
+    GL_TRY(comm_alive(c));
     const size_t bytes = (size_t)c->nranks * s->n_edges * 8;
-    if (c->gather_bytes < bytes) {
-        if (c->gather) (void)hipFree(c->gather);
-        c->gather = nullptr;
-        c->gather_bytes = 0;
-        GL_HIP(ctx, hipMalloc((void **)&c->gather, bytes));
-        c->gather_bytes = bytes;
-    }
-    GL_NCCL(ctx, rccl()->AllGather(s->stage, c->gather, (size_t)s->n_edges, ncclFloat64, c->comm, ctx->stream));
-    if (host_out) GL_HIP(ctx, hipMemcpyAsync(host_out, c->gather, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return GL_OK;
+    const int rc = [&]() -> int {
+        GL_HIP(ctx, hipSetDevice(ctx->device));
+        // the session's staging buffer receives the condensed, thresholded weights (device only)
+        GL_TRY(gl_logdeg_get_weights_condensed(s, edge_tol, nullptr));
+        GL_TRY(comm_gather_buffer(c, bytes));
+        GL_NCCL(ctx, rccl()->AllGather(s->stage, c->gather, (size_t)s->n_edges, ncclFloat64, c->comm, ctx->stream));
+        if (host_out) GL_HIP(ctx, hipMemcpyAsync(host_out, c->gather, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return GL_OK;
+    }();
+    if (rc != GL_OK) return comm_fail(c, rc);  // (whatever failed on the way in: this rank does not enter, and says so)
+    return comm_wait(c, "gl_comm_allgather_weights");
 }
 
 // All-gather of a small fp64 vector given in host memory (count doubles per rank -> nranks x count on
@@ -180,34 +294,33 @@ GL_API int gl_comm_allgather_weights(gl_comm *c, gl_logdeg *s, double edge_tol, 
 GL_API int gl_comm_allgather_f64(gl_comm *c, const double *host_in, int64_t count, double *host_out) {
     if (!c || !host_in || !host_out || count < 1) return GL_E_INVALID;
     gl_ctx *ctx = c->ctx;
-    GL_HIP(ctx, hipSetDevice(ctx->device));
+    GL_TRY(comm_alive(c));
     const size_t bytes = (size_t)(c->nranks + 1) * (size_t)count * 8;  // [send | recv]
-    if (c->gather_bytes < bytes) {
-        if (c->gather) (void)hipFree(c->gather);
-        c->gather = nullptr;
-        c->gather_bytes = 0;
-        GL_HIP(ctx, hipMalloc((void **)&c->gather, bytes));
-        c->gather_bytes = bytes;
-    }
-    GL_HIP(ctx, hipMemcpyAsync(c->gather, host_in, (size_t)count * 8, hipMemcpyHostToDevice, ctx->stream));
-    GL_NCCL(ctx, rccl()->AllGather(c->gather, c->gather + count, (size_t)count, ncclFloat64, c->comm, ctx->stream));
-    GL_HIP(ctx, hipMemcpyAsync(host_out, c->gather + count, (size_t)c->nranks * (size_t)count * 8, hipMemcpyDeviceToHost,
-                               ctx->stream));
-    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return GL_OK;
+    const int rc = [&]() -> int {
+        GL_HIP(ctx, hipSetDevice(ctx->device));
+        GL_TRY(comm_gather_buffer(c, bytes));
+        GL_HIP(ctx, hipMemcpyAsync(c->gather, host_in, (size_t)count * 8, hipMemcpyHostToDevice, ctx->stream));
+        GL_NCCL(ctx, rccl()->AllGather(c->gather, c->gather + count, (size_t)count, ncclFloat64, c->comm, ctx->stream));
+        GL_HIP(ctx, hipMemcpyAsync(host_out, c->gather + count, (size_t)c->nranks * (size_t)count * 8, hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        return GL_OK;
+    }();
+    if (rc != GL_OK) return comm_fail(c, rc);
+    return comm_wait(c, "gl_comm_allgather_f64");
 }
 
 // The gather payload of SURVEY.md section 8 row f-4: every rank contributes ONE self-describing record --
 // the 64-byte header of graph_learning_amd/wire.py (magic "GLAM", version 1, n_nodes, n_edges, problem id,
 // iterations run, theta, edge_tol, flags) followed by its condensed, thresholded weights -- so the header
 // travels THROUGH the collective with the data it describes.  host_out is nranks x (8 + E) doubles.
+// flags: bit 0 = the solver converged, bit 1 = this rank FAILED to solve its problem (its weights are whatever the
+// session holds -- zeros after a fresh init -- and every rank learns of the failure from the record itself).
 GL_API int gl_comm_allgather_records(gl_comm *c, gl_logdeg *s, double edge_tol, int64_t problem_id, int64_t n_iter,
-                                     double theta, int converged, double *host_out) {
+                                     double theta, int flags, double *host_out) {
     if (!c || !s) return GL_E_INVALID;
     gl_ctx *ctx = c->ctx;
     if (s->ctx != ctx) return gl_set_error(ctx, GL_E_INVALID, "session and communicator live on different contexts");
-    GL_HIP(ctx, hipSetDevice(ctx->device));
-    GL_TRY(gl_logdeg_get_weights_condensed(s, edge_tol, nullptr));  // condensed weights -> s->stage (device only)
+    GL_TRY(comm_alive(c));
     struct Header {  // little-endian, 64 bytes: the layout of wire.HEADER ("<4sIqqqqddQ")
         char magic[4];
         uint32_t version;
@@ -224,19 +337,18 @@ GL_API int gl_comm_allgather_records(gl_comm *c, gl_logdeg *s, double edge_tol, 
     h.n_iter = n_iter;
     h.theta = theta;
     h.edge_tol = edge_tol;
-    h.flags = converged ? 1u : 0u;
-    GL_TRY(gl_h2d(ctx, s->stage_rec, &h, sizeof h));
+    h.flags = (uint64_t)(unsigned)flags & 3u;
     const size_t rec = (size_t)s->n_edges + 8;
     const size_t bytes = (size_t)c->nranks * rec * 8;
-    if (c->gather_bytes < bytes) {
-        if (c->gather) (void)hipFree(c->gather);
-        c->gather = nullptr;
-        c->gather_bytes = 0;
-        GL_HIP(ctx, hipMalloc((void **)&c->gather, bytes));
-        c->gather_bytes = bytes;
-    }
-    GL_NCCL(ctx, rccl()->AllGather(s->stage_rec, c->gather, rec, ncclFloat64, c->comm, ctx->stream));
-    if (host_out) GL_HIP(ctx, hipMemcpyAsync(host_out, c->gather, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return GL_OK;
+    const int rc = [&]() -> int {
+        GL_HIP(ctx, hipSetDevice(ctx->device));
+        GL_TRY(gl_logdeg_get_weights_condensed(s, edge_tol, nullptr));  // condensed weights -> s->stage (device only)
+        GL_TRY(gl_h2d(ctx, s->stage_rec, &h, sizeof h));
+        GL_TRY(comm_gather_buffer(c, bytes));
+        GL_NCCL(ctx, rccl()->AllGather(s->stage_rec, c->gather, rec, ncclFloat64, c->comm, ctx->stream));
+        if (host_out) GL_HIP(ctx, hipMemcpyAsync(host_out, c->gather, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return GL_OK;
+    }();
+    if (rc != GL_OK) return comm_fail(c, rc);
+    return comm_wait(c, "gl_comm_allgather_records");
 }

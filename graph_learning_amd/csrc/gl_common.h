@@ -40,6 +40,7 @@ struct gl_ctx {
     // the batched solver's stand-in session for the tile engine (gl_logdeg.hip: BatchCruise), kept for the next call
     void *batch_cruise = nullptr;
     void (*batch_cruise_free)(void *) = nullptr;
+    bool batch_cruise_busy = false;  // gl_logdeg_batch_iterate is working on it: gl_ctx_trim_retained leaves it alone
     // released device blocks of the sessions, kept for the next session of the same size (gl_ctx_alloc / gl_ctx_release):
     // a batch of windows creates and destroys a session per graph, and hipFree alone cost 0.3 ms each
     struct PoolBlock {
@@ -57,6 +58,22 @@ int gl_ctx_scratch(gl_ctx *ctx, size_t bytes, void **out);
 // on the context's one stream, so reuse is ordered behind the previous owner's work without a synchronisation.
 int gl_ctx_alloc(gl_ctx *ctx, size_t bytes, void **out);
 void gl_ctx_release(gl_ctx *ctx, void *p, size_t bytes);
+// hipMalloc for everything else the library allocates.  When the device has no room, what the context itself retains -- the
+// released session blocks, the batched solver's stand-in session with its ring (unless a call is using it) -- is given back
+// first and the allocation tried once more; the runtime's last-error word is cleared either way, so a caller that falls back
+// to another path does not trip over it at its next hipGetLastError().  `tag` names the site for the test hook
+// GRAPHLEARN_AMD_TEST_ALLOC_FAIL=<tag>: allocations of that site fail as if the device were full.
+hipError_t gl_ctx_malloc(gl_ctx *ctx, void **out, size_t bytes, const char *tag);
+size_t gl_ctx_trim_retained(gl_ctx *ctx);  // returns the bytes given back (0: there was nothing)
+#define GL_MALLOC(ctx, pp, bytes, tag)                                                                          \
+    do {                                                                                                        \
+        const size_t b_ = (bytes);                                                                              \
+        hipError_t e_ = gl_ctx_malloc((ctx), (void **)(pp), b_, (tag));                                         \
+        if (e_ != hipSuccess)                                                                                   \
+            return gl_set_error((ctx), e_ == hipErrorOutOfMemory ? GL_E_NOMEM : GL_E_HIP,                       \
+                                "hipMalloc(%zu) [%s] failed: %s (%s:%d)", b_, (tag), hipGetErrorString(e_),     \
+                                __FILE__, __LINE__);                                                            \
+    } while (0)
 
 int gl_set_error(gl_ctx *ctx, int code, const char *fmt, ...);
 

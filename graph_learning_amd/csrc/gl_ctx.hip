@@ -94,6 +94,52 @@ GL_API int gl_ctx_destroy(gl_ctx *ctx) {
     return GL_OK;
 }
 
+size_t gl_ctx_trim_retained(gl_ctx *ctx) {
+    const bool cruise = ctx->batch_cruise && ctx->batch_cruise_free && !ctx->batch_cruise_busy;
+    if (ctx->pool.empty() && !cruise) return 0;
+    (void)hipStreamSynchronize(ctx->stream);  // (a released block may still be read by work queued before its release)
+    size_t freed = ctx->pool_bytes;
+    for (const gl_ctx::PoolBlock &b : ctx->pool) (void)hipFree(b.p);
+    ctx->pool.clear();
+    ctx->pool_bytes = 0;
+    if (cruise) {
+        ctx->batch_cruise_free(ctx->batch_cruise);
+        ctx->batch_cruise = nullptr;
+        freed += 1;  // (its size is the owner's business: "something")
+    }
+    return freed;
+}
+
+hipError_t gl_ctx_malloc(gl_ctx *ctx, void **out, size_t bytes, const char *tag) {
+    *out = nullptr;
+    if (const char *hook = getenv("GRAPHLEARN_AMD_TEST_ALLOC_FAIL"))
+        if (tag && !strcmp(hook, tag)) return hipErrorOutOfMemory;
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipSuccess) return e;
+    (void)hipGetLastError();
+    *out = nullptr;
+    if (gl_ctx_trim_retained(ctx) == 0) return e;
+    e = hipMalloc(out, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+    }
+    return e;
+}
+
+GL_API int gl_ctx_trim(gl_ctx *ctx) {
+    if (!ctx) return GL_E_INVALID;
+    GL_HIP(ctx, hipSetDevice(ctx->device));
+    (void)gl_ctx_trim_retained(ctx);
+    if (ctx->scratch) {  // (between calls nobody holds the scratch)
+        GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->scratch);
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+    }
+    return GL_OK;
+}
+
 int gl_ctx_alloc(gl_ctx *ctx, size_t bytes, void **out) {
     for (size_t k = ctx->pool.size(); k-- > 0;)
         if (ctx->pool[k].bytes == bytes) {
@@ -102,21 +148,14 @@ int gl_ctx_alloc(gl_ctx *ctx, size_t bytes, void **out) {
             ctx->pool.erase(ctx->pool.begin() + (long)k);
             return GL_OK;
         }
-    hipError_t e = hipMalloc(out, bytes);
-    if (e != hipSuccess && !ctx->pool.empty()) {  // (the pool holds memory somebody needs in another size)
-        (void)hipStreamSynchronize(ctx->stream);
-        for (const gl_ctx::PoolBlock &b : ctx->pool) (void)hipFree(b.p);
-        ctx->pool.clear();
-        ctx->pool_bytes = 0;
-        e = hipMalloc(out, bytes);
-    }
-    if (e != hipSuccess) return gl_set_error(ctx, GL_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    GL_MALLOC(ctx, out, bytes, "session");  // (gives the pool back first when the device is full)
     return GL_OK;
 }
 
 void gl_ctx_release(gl_ctx *ctx, void *p, size_t bytes) {
     if (!p) return;
-    constexpr size_t cap = (size_t)8 << 30;  // (what the pool may hold; beyond it blocks are freed as before)
+    // what the pool may hold: a sixteenth of the device's memory, 8 GiB at most (beyond it blocks are freed as before)
+    const size_t cap = std::min<size_t>((size_t)8 << 30, ctx->prop.totalGlobalMem / 16);
     if (ctx->pool_bytes + bytes > cap || ctx->pool.size() >= 4096) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipFree(p);
@@ -151,7 +190,7 @@ int gl_ctx_scratch(gl_ctx *ctx, size_t bytes, void **out) {
         ctx->scratch = nullptr;
         ctx->scratch_bytes = 0;
         const size_t want = (bytes + ((size_t)1 << 20) - 1) >> 20 << 20;
-        GL_HIP(ctx, hipMalloc(&ctx->scratch, want));
+        GL_MALLOC(ctx, &ctx->scratch, want, "scratch");
         ctx->scratch_bytes = want;
     }
     *out = ctx->scratch;

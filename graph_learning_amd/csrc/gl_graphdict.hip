@@ -674,7 +674,7 @@ int gd_check(gl_graphdict *s) {
 template <typename T>
 int gd_alloc(gl_graphdict *s, T **p, size_t count) {
     gl_ctx *ctx = s->ctx;
-    GL_HIP(ctx, hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T)));
+    GL_MALLOC(ctx, (void **)p, std::max<size_t>(count, 1) * sizeof(T), "graphdict");
     s->allocs.push_back(*p);
     GL_HIP(ctx, hipMemsetAsync(*p, 0, std::max<size_t>(count, 1) * sizeof(T), ctx->stream));
     return GL_OK;
@@ -877,7 +877,7 @@ GL_API int gl_graphdict_create(gl_ctx *ctx, int64_t n_nodes, int64_t n_samples, 
     size_t total = 0;
     for (const Part &q : parts) total += (std::max<size_t>(q.bytes, 8) + 255) / 256 * 256;
     void *arena = nullptr;
-    if (hipMalloc(&arena, total) != hipSuccess) {
+    if (gl_ctx_malloc(ctx, &arena, total, "graphdict") != hipSuccess) {
         delete s;
         return gl_set_error(ctx, GL_E_NOMEM, "hipMalloc(%zu) failed", total);
     }
@@ -1048,7 +1048,7 @@ GL_API int gl_graphdict_fit(gl_graphdict *s, int64_t max_iter, double tol, int r
     for (int64_t q = 0; q < 2 * max_iter; ++q) history_out[q] = -1.0;
     if (P.hist_cap < max_iter) {  // history of the run on the device; the captured steps hold its address
         double *h = nullptr;
-        GL_HIP(ctx, hipMalloc((void **)&h, (size_t)std::max<int64_t>(max_iter, 1) * 2 * sizeof(double)));
+        GL_MALLOC(ctx, (void **)&h, (size_t)std::max<int64_t>(max_iter, 1) * 2 * sizeof(double), "graphdict");
         if (P.hist) {
             auto itp = std::find(s->allocs.begin(), s->allocs.end(), (void *)P.hist);
             if (itp != s->allocs.end()) s->allocs.erase(itp);

@@ -420,7 +420,7 @@ int gs_run(gl_graphdict *s, int mode, int64_t max_iter, double tol, int plateau,
     const int64_t hist_steps = mode == 0 ? max_iter : 0;
     if (!s->small_hist || s->small_hist_steps < hist_steps) {  // [8 result words][2 per step]
         double *h = nullptr;
-        GL_HIP(ctx, hipMalloc((void **)&h, (size_t)(8 + 2 * hist_steps) * sizeof(double)));
+        GL_MALLOC(ctx, (void **)&h, (size_t)(8 + 2 * hist_steps) * sizeof(double), "graphdict");
         if (s->small_hist) {
             auto itp = std::find(s->allocs.begin(), s->allocs.end(), (void *)s->small_hist);
             if (itp != s->allocs.end()) s->allocs.erase(itp);

@@ -2115,9 +2115,9 @@ GL_API int gl_relative_error(gl_ctx *ctx, const double *y_true, const double *y_
     if (!y_true || !y_pred || !out || count < 1) return gl_set_error(ctx, GL_E_INVALID, "bad argument");
     GL_HIP(ctx, hipSetDevice(ctx->device));
     Buf a, b, part;
-    GL_HIP(ctx, hipMalloc(&a.p, (size_t)count * 8));
-    GL_HIP(ctx, hipMalloc(&b.p, (size_t)count * 8));
-    GL_HIP(ctx, hipMalloc(&part.p, 3 * 256 * 8));
+    GL_MALLOC(ctx, &a.p, (size_t)count * 8, "lgmrf");
+    GL_MALLOC(ctx, &b.p, (size_t)count * 8, "lgmrf");
+    GL_MALLOC(ctx, &part.p, 3 * 256 * 8, "lgmrf");
     GL_TRY(gl_h2d(ctx, a.p, y_true, (size_t)count * 8));
     GL_TRY(gl_h2d(ctx, b.p, y_pred, (size_t)count * 8));
     return relative_error_dev(ctx, (double *)a.p, (double *)b.p, count, (double *)part.p, out);
@@ -2139,7 +2139,7 @@ GL_API int gl_nonneg_qp_solve(gl_ctx *ctx, const double *mat, const double *vec,
         auto up = [](size_t b) { return (b + 255) / 256 * 256; };
         const size_t bW = up((size_t)m * m * 8), bPart = up((size_t)4 * m * 6 * 8), bBar = up(GL_BAR_WORDS * 4),
                      bGran = up((size_t)2 * m * 16), bVec = up((size_t)16 * m * 8), bScal = up(16 * 8);
-        GL_HIP(ctx, hipMalloc(&arena.p, bW + bPart + bBar + bGran + bVec + bScal));
+        GL_MALLOC(ctx, &arena.p, bW + bPart + bBar + bGran + bVec + bScal, "lgmrf");
         char *at = (char *)arena.p;
         W.p = at, at += bW;
         part.p = at, at += bPart;
@@ -2229,32 +2229,32 @@ static int lgmrf_fit_impl(gl_ctx *ctx, const double *x, int64_t n, double norm_p
 
     const size_t nn = (size_t)n * n * 8;
     Buf bx, bK, bTh, bC, bG, bW, bPrev, bMask, bVec, bScal, bPart;
-    GL_HIP(ctx, hipMalloc(&bx.p, nn));
-    GL_HIP(ctx, hipMalloc(&bK.p, nn));
-    GL_HIP(ctx, hipMalloc(&bTh.p, nn));
-    GL_HIP(ctx, hipMalloc(&bC.p, nn));
-    GL_HIP(ctx, hipMalloc(&bPrev.p, nn));
-    if (fast) GL_HIP(ctx, hipMalloc(&bG.p, nn));
-    GL_HIP(ctx, hipMalloc(&bW.p, nn));
+    GL_MALLOC(ctx, &bx.p, nn, "lgmrf");
+    GL_MALLOC(ctx, &bK.p, nn, "lgmrf");
+    GL_MALLOC(ctx, &bTh.p, nn, "lgmrf");
+    GL_MALLOC(ctx, &bC.p, nn, "lgmrf");
+    GL_MALLOC(ctx, &bPrev.p, nn, "lgmrf");
+    if (fast) GL_MALLOC(ctx, &bG.p, nn, "lgmrf");
+    GL_MALLOC(ctx, &bW.p, nn, "lgmrf");
     if (adj_mask && !full_mask) {
-        GL_HIP(ctx, hipMalloc(&bMask.p, nn));
+        GL_MALLOC(ctx, &bMask.p, nn, "lgmrf");
         GL_TRY(gl_h2d(ctx, bMask.p, adj_mask, nn));
     }
-    GL_HIP(ctx, hipMalloc(&bVec.p, (size_t)16 * n * 8));
-    GL_HIP(ctx, hipMalloc(&bScal.p, 16 * 8));
-    GL_HIP(ctx, hipMalloc(&bPart.p, 3 * 256 * 8));
+    GL_MALLOC(ctx, &bVec.p, (size_t)16 * n * 8, "lgmrf");
+    GL_MALLOC(ctx, &bScal.p, 16 * 8, "lgmrf");
+    GL_MALLOC(ctx, &bPart.p, 3 * 256 * 8, "lgmrf");
     Buf bAdmm, bBar;
     Buf bGran, bCprev;
-    GL_HIP(ctx, hipMalloc(&bAdmm.p, (size_t)4 * n * 6 * 8));  // one entry per workgroup and ring slot, any ADMM form
-    GL_HIP(ctx, hipMalloc(&bBar.p, GL_BAR_WORDS * 4));
+    GL_MALLOC(ctx, &bAdmm.p, (size_t)4 * n * 6 * 8, "lgmrf");  // one entry per workgroup and ring slot, any ADMM form
+    GL_MALLOC(ctx, &bBar.p, GL_BAR_WORDS * 4, "lgmrf");
     GL_HIP(ctx, hipMemsetAsync(bBar.p, 0, GL_BAR_WORDS * 4, ctx->stream));
-    GL_HIP(ctx, hipMalloc(&bGran.p, (size_t)2 * n * 16));
+    GL_MALLOC(ctx, &bGran.p, (size_t)2 * n * 16, "lgmrf");
     GL_HIP(ctx, hipMemsetAsync(bGran.p, 0, (size_t)2 * n * 16, ctx->stream));
     AdmmRes ares;
     GL_TRY(admm_res_plan(ctx, n, ares));
     ares.bar = (unsigned *)bBar.p;
     ares.gran = (lg_u4 *)bGran.p;
-    if (ares.on || !fast) GL_HIP(ctx, hipMalloc(&bCprev.p, (size_t)n * n * 8));
+    if (ares.on || !fast) GL_MALLOC(ctx, &bCprev.p, (size_t)n * n * 8, "lgmrf");
     GL_HIP(ctx, hipMemsetAsync(bVec.p, 0, (size_t)16 * n * 8, ctx->stream));
     GL_HIP(ctx, hipMemsetAsync(bScal.p, 0, 16 * 8, ctx->stream));
 
@@ -2311,8 +2311,8 @@ static int lgmrf_fit_impl(gl_ctx *ctx, const double *x, int64_t n, double norm_p
                 if (i != u && (!adj_mask || full_mask || adj_mask[i * n + u] == 1.0)) nz_idx.push_back((int)i);
             nz_ptr[(size_t)u + 1] = (int64_t)nz_idx.size();
         }
-        GL_HIP(ctx, hipMalloc(&bIdx.p, std::max<size_t>(nz_idx.size(), 1) * sizeof(int)));
-        GL_HIP(ctx, hipMalloc(&bCvec.p, (size_t)10 * n * 8));
+        GL_MALLOC(ctx, &bIdx.p, std::max<size_t>(nz_idx.size(), 1) * sizeof(int), "lgmrf");
+        GL_MALLOC(ctx, &bCvec.p, (size_t)10 * n * 8, "lgmrf");
         GL_HIP(ctx, hipMemcpyAsync(bIdx.p, nz_idx.data(), nz_idx.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         GL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // nz_idx is a local
         double *Vc = (double *)bCvec.p;
@@ -2340,7 +2340,7 @@ static int lgmrf_fit_impl(gl_ctx *ctx, const double *x, int64_t n, double norm_p
             const int np = n <= 16 ? 16 : (n <= 32 ? 32 : 64);
             const bool general = !fast;
             if (general && !D.mask) {  // forced general path with a full mask: the kernel reads the mask
-                GL_HIP(ctx, hipMalloc(&bMask.p, nn));
+                GL_MALLOC(ctx, &bMask.p, nn, "lgmrf");
                 std::vector<double> ones((size_t)n * n, 1.0);
                 GL_TRY(gl_h2d(ctx, bMask.p, ones.data(), nn));
                 GL_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -84,7 +84,7 @@ int gl_theta_from_rows(gl_ctx *ctx, const double *zsq_dev, int64_t rows, int64_t
 int gl_resident_prepare(gl_logdeg *s);
 void gl_resident_free(gl_logdeg *s);
 int gl_resident_launch(gl_logdeg *s, int64_t iters, double tol);
-int gl_resident_finish(gl_logdeg *s, int64_t *iters_done, bool *stopped, bool *not_resident);
+int gl_resident_finish(gl_logdeg *s, int64_t *iters_done, bool *stopped, bool *not_resident, bool *gated_out = nullptr);
 // gl_tile.hip
 constexpr int GL_TILE_MIN_CALL = 4;  // shortest call (iterations) the tile engine takes; shorter ones stream
 int gl_tile_prepare(gl_logdeg *s);
@@ -92,7 +92,7 @@ int gl_tile_prepare_batch(gl_logdeg *s, int B);  // s stands for B graphs of dev
 int gl_tile_batch_make_zg(gl_logdeg *s, const LogdegDev *devs_dev, int B);
 void gl_tile_batch_set_ring(gl_logdeg *s, double *ring, int64_t ring_stride, double *dring, int64_t dring_stride);
 void gl_tile_free(gl_logdeg *s);
-int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int final_parity);
+int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int final_parity, double gate = 0.0);
 bool gl_tile_writes_final_parity(const gl_logdeg *s);
 void gl_tile_dump_stamps(gl_logdeg *s);
 // gl_small.hip

@@ -1570,8 +1570,8 @@ static bool use_resident(const gl_logdeg *s, int64_t iters) {
     return s->tile != nullptr ? iters >= GL_TILE_MIN_CALL : (s->res != nullptr && iters >= 16);
 }
 // the persistent launch of the session's resident-family engine: the tile engine where it applies
-static int persistent_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int final_parity = -1) {
-    return s->tile ? gl_tile_launch(s, iters, tol, norms, final_parity) : gl_resident_launch(s, iters, tol);
+static int persistent_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int final_parity = -1, double gate = 0.0) {
+    return s->tile ? gl_tile_launch(s, iters, tol, norms, final_parity, gate) : gl_resident_launch(s, iters, tol);
 }
 static void persistent_free(gl_logdeg *s) {
     gl_resident_free(s);
@@ -1683,15 +1683,58 @@ GL_API int gl_logdeg_iterate(gl_logdeg *s, int64_t maxit, double tol, int64_t *n
     }
     if (use_resident(s, maxit)) {
         double *st = (double *)ctx->pinned;
-        int64_t ran = 0;
+        int64_t ran = 0, total = 0;
         bool stopped = false;
         bool not_resident = false;
-        GL_TRY(persistent_launch(s, maxit, tol, true));
+        // Converge mode on the tile engine, long calls: the rule (smooth_learning.py:166-167) needs BOTH ratios below tol, and
+        // the dual one -- ||qbar - ybar|| / ||d||, n numbers that the owners of the node blocks form in passing -- is the one
+        // that holds it up for most of a run (measured on the bench problem and its smaller siblings: above tol for 94 % of
+        // the iterations to tol = 1e-5, while the primal ratio sits orders of magnitude below).  The primal norms cost a third
+        // of the pass (three of nine fp64 operations per edge).  So a long call runs in up to three launches:
+        //   head    the variant with the norms, GATE_HEAD iterations, judged as ever (it may stop the run);
+        //   middle  if the head's last dual ratio is at least GATE_IN x tol: the variant WITHOUT the norms, which only
+        //           watches the dual ratio and ends when it comes within GATE_OUT x tol (TileDev::gate) -- no iteration of
+        //           it can meet the rule, so none has to be judged;
+        //   tail    the variant with the norms to the end, every iteration judged.
+        // The stopping iteration is the reference's as long as the dual ratio does not fall from GATE_OUT x tol (25 % above tol:
+        // the threshold of the tile engine's lagged rule as well) to tol within the two iterations between the gate's look
+        // and the tail's first judgement -- it decays like 1/k, k >= 16, and the largest drop per iteration seen where edges
+        // switch on or off is 0.5 %.  GRAPHLEARN_AMD_TILE_GATE=0 switches the middle off.
+        constexpr int64_t GATE_HEAD = 16, GATE_MIN_CALL = 512;
+        constexpr double GATE_IN = 2.0, GATE_OUT = 1.25;
+        const bool try_gate = s->tile != nullptr && tol > 0 && maxit >= GATE_MIN_CALL &&
+                              !(getenv("GRAPHLEARN_AMD_TILE_GATE") && atoi(getenv("GRAPHLEARN_AMD_TILE_GATE")) == 0);
+        int64_t left = maxit;
+        GL_TRY(persistent_launch(s, try_gate ? GATE_HEAD : left, tol, true));
         GL_TRY(gl_resident_finish(s, &ran, &stopped, &not_resident));
         if (!not_resident) {
+            total += ran, left -= ran;
             GL_HIP(ctx, hipMemcpyAsync(st, D.dstat, 2 * 8, hipMemcpyDeviceToHost, ctx->stream));
             GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (n_iter_out) *n_iter_out = ran;
+            if (try_gate && !stopped && left > 0) {
+                int phases = 1;
+                // (st[1]: the dual ratio of the head's last iteration; a NaN or inf -- degenerate norms -- keeps the norms on)
+                if (st[1] >= GATE_IN * tol && st[1] < std::numeric_limits<double>::infinity() && left > 2 * GATE_HEAD) {
+                    bool gated = false, nr2 = false, st2 = false;
+                    // (the tail keeps at least GATE_HEAD iterations of the budget: the ratios a call reports are those of
+                    //  its last iteration, which only the variant with the norms forms)
+                    GL_TRY(persistent_launch(s, left - GATE_HEAD, tol, false, -1, GATE_OUT));
+                    GL_TRY(gl_resident_finish(s, &ran, &st2, &nr2, &gated));
+                    if (nr2) return gl_set_error(ctx, GL_E_HIP, "tile engine: the workgroups of a continued call did not meet");
+                    total += ran, left -= ran;
+                    ++phases;
+                }
+                GL_TRY(persistent_launch(s, left, tol, true));
+                GL_TRY(gl_resident_finish(s, &ran, &stopped, &not_resident));
+                if (not_resident) return gl_set_error(ctx, GL_E_HIP, "tile engine: the workgroups of a continued call did not meet");
+                total += ran, left -= ran;
+                ++phases;
+                GL_HIP(ctx, hipMemcpyAsync(st, D.dstat, 2 * 8, hipMemcpyDeviceToHost, ctx->stream));
+                GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (getenv("GRAPHLEARN_AMD_TILE_DEBUG"))
+                    fprintf(stderr, "[tile gate] n %lld: %d launches, %lld iterations, stopped %d\n", (long long)s->n, phases, (long long)total, (int)stopped);
+            }
+            if (n_iter_out) *n_iter_out = total;
             if (converged_out) *converged_out = stopped ? 1 : 0;
             if (rel_out) {
                 rel_out[0] = st[0];
@@ -1791,7 +1834,7 @@ GL_API int gl_logdeg_get_weights_square(gl_logdeg *s, double edge_tol, double *w
     GL_HIP(ctx, hipSetDevice(ctx->device));
     GL_TRY(resident_check(s));
     // the square result (n^2) is staged in session-owned scratch (allocated at the first use, then kept)
-    if (!s->square_out) GL_HIP(ctx, hipMalloc((void **)&s->square_out, (size_t)s->n * s->n * 8));
+    if (!s->square_out) GL_MALLOC(ctx, (void **)&s->square_out, (size_t)s->n * s->n * 8, "logdeg");
     k_to_square<<<dim3((unsigned)s->dev.ntiles), dim3(256), 0, ctx->stream>>>(s->dev.w[s->it & 1], s->square_out, s->n,
                                                                            s->dev.nb, edge_tol);
     GL_HIP(ctx, hipGetLastError());
@@ -2021,7 +2064,17 @@ static int batch_cruise_get(gl_ctx *ctx, gl_logdeg **sessions, int B, BatchCruis
                               {(void **)&D.bnorm, (size_t)2 * D.nb * 4 * 8}, {(void **)&D.dstat, 8 * 8}, {(void **)&D.ctr, 8 * 8}};
         size_t total = 0;
         for (const Part &q : parts) total += (q.bytes + 255) / 256 * 256;
-        if (hipMalloc(&bc->arena, total) != hipSuccess) return GL_OK;  // (no room: the launches below serve the batch)
+        // No room for the B-fold stand-in: the batched launches serve the batch (their buffers are the sessions' own).  Nothing
+        // half-built stays behind -- the next call tries again --, and the runtime's last-error word is clean (gl_ctx_malloc),
+        // so that the launch path's hipGetLastError() checks do not report this allocation as their own failure.
+        ctx->batch_cruise_busy = true;  // (gl_ctx_malloc may trim what the context retains: not this half-built entry)
+        const hipError_t ea = gl_ctx_malloc(ctx, &bc->arena, total, "cruise");
+        ctx->batch_cruise_busy = false;
+        if (ea != hipSuccess) {
+            batch_cruise_free(bc);
+            ctx->batch_cruise = nullptr;
+            return GL_OK;
+        }
         char *at = (char *)bc->arena;
         for (const Part &q : parts) {
             *q.p = at;
@@ -2029,6 +2082,11 @@ static int batch_cruise_get(gl_ctx *ctx, gl_logdeg **sessions, int B, BatchCruis
         }
         GL_HIP(ctx, hipMemsetAsync(bc->arena, 0, total, ctx->stream));
         GL_TRY(gl_tile_prepare_batch(&cs, B));
+        if (!cs.tile) {  // the batch does not fit the chip: the entry stays (so that the next call does not try again) without its arena
+            GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(bc->arena);
+            bc->arena = nullptr;
+        }
     }
     if (bc->cs.tile && bc->arena) *out = bc;
     return GL_OK;
@@ -2200,6 +2258,11 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
         BatchCruise *bc = nullptr;
         const auto t_get0 = std::chrono::steady_clock::now();
         if (same) GL_TRY(batch_cruise_get(ctx, sessions, B, &bc));
+        struct Busy {  // while this call works on the stand-in, an allocation that runs short must not trim it away
+            gl_ctx *c;
+            ~Busy() { c->batch_cruise_busy = false; }
+        } busy{ctx};
+        ctx->batch_cruise_busy = bc != nullptr;
         if (getenv("GRAPHLEARN_AMD_BATCH_DEBUG"))
             fprintf(stderr, "[batch setup] stand-in session: %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_get0).count());
         if (bc) {
@@ -2255,7 +2318,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
                     const size_t b_ring = up((K + 1) * slot), b_dring = up((K + 1) * dslot), b_ck = up(3 * dslot);
                     const size_t b_part = up((size_t)K * (ge + 1) * 2 * nbk * 256 * 8), b_j = up(sizeof(RingJudge));
-                    if (hipMalloc(&bc->ring_arena, b_ring + b_dring + b_ck + b_part + b_j) == hipSuccess) {
+                    if (gl_ctx_malloc(ctx, &bc->ring_arena, b_ring + b_dring + b_ck + b_part + b_j, "ring") == hipSuccess) {
                         char *at = (char *)bc->ring_arena;
                         bc->ring = (double *)at, at += b_ring;
                         bc->dring = (double *)at, at += b_dring;
@@ -2264,8 +2327,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                         bc->judge = (RingJudge *)at;
                         bc->ring_k = K;
                         GL_HIP(ctx, hipMemsetAsync(bc->judge, 0, sizeof(RingJudge), ctx->stream));
-                    } else {
-                        (void)hipGetLastError();
+                    } else {  // (no room for the ring: the batched launches judge the rest of the run)
                         bc->ring_arena = nullptr;
                         ring_ok = false;
                     }
@@ -2367,6 +2429,19 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                     if (ring_ok && !back_to_launches) ring_finished = true;  // (n_done == maxit)
                 }
                 cruised = n_done;
+                // a ring beyond half a GiB is given back at the end of the call (the next long batch pays ~1 ms for a new one;
+                // a context that keeps 3 GiB for the sake of that millisecond starves its neighbours on a shared device)
+                if (bc->ring_arena && getenv("GRAPHLEARN_AMD_BATCH_KEEP_RING") == nullptr) {
+                    size_t ring_bytes = (size_t)(bc->ring_k + 1) * wbytes;
+                    if (ring_bytes > ((size_t)512 << 20)) {
+                        GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                        (void)hipFree(bc->ring_arena);
+                        bc->ring_arena = nullptr;
+                        bc->ring = bc->dring = bc->ckpt = bc->gpart = nullptr;
+                        bc->judge = nullptr;
+                        bc->ring_k = 0;
+                    }
+                }
             }
         }
     }

@@ -94,8 +94,8 @@ int check_dims(gl_ctx *ctx, const void *a, const void *b, int64_t B, int64_t n) 
     const int64_t E = n * (n - 1) / 2;                                                             \
     (void)E;                                                                                       \
     DevBuf din, dout;                                                                              \
-    GL_HIP(ctx, hipMalloc((void **)&din.p, (size_t)(in_elems) * 8));                               \
-    GL_HIP(ctx, hipMalloc((void **)&dout.p, (size_t)(out_elems) * 8));                             \
+    GL_MALLOC(ctx, (void **)&din.p, (size_t)(in_elems) * 8, "ops");                               \
+    GL_MALLOC(ctx, (void **)&dout.p, (size_t)(out_elems) * 8, "ops");                             \
     GL_TRY(gl_h2d(ctx, din.p, in, (size_t)(in_elems) * 8)); \
     const dim3 grid((unsigned)((n + 255) / 256), (unsigned)n, (unsigned)B), block(256)
 
@@ -136,8 +136,8 @@ GL_API int gl_theta_from_distances(gl_ctx *ctx, const double *zsq, int64_t n, in
     if (n < 2) return gl_set_error(ctx, GL_E_INVALID, "n must be >= 2");
     GL_HIP(ctx, hipSetDevice(ctx->device));
     DevBuf dz, dt;
-    GL_HIP(ctx, hipMalloc((void **)&dz.p, (size_t)n * n * 8));
-    GL_HIP(ctx, hipMalloc((void **)&dt.p, (size_t)2 * n * 8));
+    GL_MALLOC(ctx, (void **)&dz.p, (size_t)n * n * 8, "ops");
+    GL_MALLOC(ctx, (void **)&dt.p, (size_t)2 * n * 8, "ops");
     GL_TRY(gl_h2d(ctx, dz.p, zsq, (size_t)n * n * 8));
     return gl_theta_from_square(ctx, dz.p, n, avg_degree, dt.p, theta_out);
 }
@@ -149,8 +149,8 @@ GL_API int gl_theta_from_matrix(gl_ctx *ctx, const double *zsq, int64_t rows, in
     if (rows < 1 || cols < 2) return gl_set_error(ctx, GL_E_INVALID, "need rows >= 1 and cols >= 2");
     GL_HIP(ctx, hipSetDevice(ctx->device));
     DevBuf dz, dt;
-    GL_HIP(ctx, hipMalloc((void **)&dz.p, (size_t)rows * cols * 8));
-    GL_HIP(ctx, hipMalloc((void **)&dt.p, (size_t)2 * rows * 8));
+    GL_MALLOC(ctx, (void **)&dz.p, (size_t)rows * cols * 8, "ops");
+    GL_MALLOC(ctx, (void **)&dt.p, (size_t)2 * rows * 8, "ops");
     GL_TRY(gl_h2d(ctx, dz.p, zsq, (size_t)rows * cols * 8));
     return gl_theta_from_rows(ctx, dz.p, rows, cols, avg_degree, dt.p, theta_out);
 }

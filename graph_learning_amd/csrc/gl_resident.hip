@@ -629,7 +629,7 @@ int gl_resident_prepare(gl_logdeg *s) {
     if (!r) return GL_E_NOMEM;
     s->res = r;
     auto up = [&](int **dst, const std::vector<int> &v) -> int {
-        GL_HIP(ctx, hipMalloc((void **)dst, std::max<size_t>(v.size(), 1) * sizeof(int)));
+        GL_MALLOC(ctx, (void **)dst, std::max<size_t>(v.size(), 1) * sizeof(int), "resident1");
         if (!v.empty()) GL_HIP(ctx, hipMemcpy(*dst, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
         return GL_OK;
     };
@@ -640,9 +640,9 @@ int gl_resident_prepare(gl_logdeg *s) {
         return rc;
     }
     const size_t ncol = (size_t)F + (size_t)S * KF;
-    if (hipMalloc((void **)&r->colslab, ncol * 2 * GL_TB * 8) != hipSuccess ||
-        hipMalloc((void **)&r->tnorm, (size_t)S * 2 * 8) != hipSuccess ||
-        hipMalloc((void **)&r->bar, GL_BAR_WORDS * 4) != hipSuccess) {
+    if (gl_ctx_malloc(ctx, (void **)&r->colslab, ncol * 2 * GL_TB * 8, "resident1") != hipSuccess ||
+        gl_ctx_malloc(ctx, (void **)&r->tnorm, (size_t)S * 2 * 8, "resident1") != hipSuccess ||
+        gl_ctx_malloc(ctx, (void **)&r->bar, GL_BAR_WORDS * 4, "resident1") != hipSuccess) {
         gl_resident_free(s);
         return gl_set_error(ctx, GL_E_NOMEM, "resident engine: hipMalloc failed");
     }
@@ -714,7 +714,7 @@ int gl_resident_launch(gl_logdeg *s, int64_t iters, double tol) {
 // *not_resident: the workgroups never met at the start-up rendezvous (the GPU is shared, or fewer
 // CUs are available than the grid needs); nothing was modified and the caller runs the streaming
 // engine instead.  A barrier that fails after the rendezvous is an error.
-int gl_resident_finish(gl_logdeg *s, int64_t *iters_done, bool *stopped, bool *not_resident) {
+int gl_resident_finish(gl_logdeg *s, int64_t *iters_done, bool *stopped, bool *not_resident, bool *gated_out) {
     gl_ctx *ctx = s->ctx;
     long long *ct = (long long *)((double *)ctx->pinned + 8);
     GL_HIP(ctx, hipMemcpyAsync(ct, s->dev.ctr, 5 * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -777,7 +777,8 @@ int gl_resident_finish(gl_logdeg *s, int64_t *iters_done, bool *stopped, bool *n
                     ph[0] / cnt / 100, ph[1] / cnt / 100, ph[2] / cnt / 100, ph[3] / cnt / 100, ph[4] / cnt / 100, NWG);
     }
     if (iters_done) *iters_done = itf - s->it;
-    if (stopped) *stopped = ct[0] != 0;
+    if (stopped) *stopped = ct[0] == 1;  // (2: the tile engine's dual gate ended the launch -- not the stopping rule; see gated_out)
+    if (gated_out) *gated_out = ct[0] == 2;
     s->it = itf;
     // the done flag belongs to the call that raised it
     GL_HIP(ctx, hipMemsetAsync(s->dev.ctr, 0, 2 * 8, ctx->stream));

@@ -57,6 +57,7 @@
 #include "gl_gridbar.h"
 #include "gl_lanes.h"
 #include "gl_logdeg.h"
+#include "gl_tile_plan.h"
 
 #ifndef GL_TILE_LDS_PREFETCH
 #define GL_TILE_LDS_PREFETCH 1  // request the LDS operands of row pair s + 1 before row pair s is computed
@@ -86,57 +87,13 @@
 #ifndef GL_TILE_EXACT_HEAD
 #define GL_TILE_EXACT_HEAD 3  // the stopping rule is evaluated exactly (no lag) for this many iterations at the start of a call
 #endif
-#ifndef GL_TILE_MIN_BULK_TILES
-#define GL_TILE_MIN_BULK_TILES 3
-#endif
 
 namespace {
 
-constexpr int TB = GL_TB;
-constexpr int SLOTS = TB / 2;  // 32 row pairs per tile
-constexpr int TW = 8;          // waves per workgroup (two per SIMD)
-constexpr int TT = TW * 64;
-constexpr int NBW = 16;        // node blocks one workgroup may touch in the rounds (8 columns + up to 8 rows); descriptor size
-constexpr int NBW_FIT = 13;    // ... while the lattice fits the register files (8 chunks: 9 seen); what s_node holds there
-constexpr int FRMAX = 2;       // fringe row pairs per wave
-constexpr int RING = 4;        // register ring of streamed z row pairs (U = 32)
-constexpr int NACQ = (NBW + TW - 1) / TW;  // node blocks one wave fetches
-constexpr int RND = 4;         // records per wave and round of an owner's poll
-constexpr int XMAX = 3;        // split extra tiles per workgroup (rounds just past the register files)
+using namespace gl_tile_plan;
+static_assert(TB == GL_TB, "tile edge");
 
 typedef unsigned int tl_u4 __attribute__((ext_vector_type(4)));
-
-struct WaveDesc {  // 16 ints
-    int tile;      // bulk tile of my chunk (-1: none)
-    int I, J;      // its node blocks
-    int a0;        // first row pair of the chunk inside the tile
-    int si, sj;    // slots of I and J in the workgroup's block list
-    int fcnt;      // fringe group: row pairs fa0 .. fa0 + fcnt - 1 of diagonal tile (fB, fB); 0: none
-    int fa0, fB, fs;  // ... its first row pair, node block, slot of that block in the workgroup's list
-    int ftgt;      // where its degree partials are folded: 0 = my row vector (fB == I, or no chunk), 1 = my column vector (fB == J)
-    // n > 4096 ("rounds", see k_tile): the wave works on tiles (I + r, J), r = 0 .. nr - 1, one per round; the first one
-    // is resident (tile >= 0) when it is not a diagonal tile, the others stream
-    int nr;        // rounds this wave takes part in
-    int rs;        // slot of node block I + r in the workgroup's block list: 4 bits per round
-    int pad[3];
-};
-struct WgDesc {  // 128 ints
-    int nblk;
-    int own;             // node block this workgroup owns (-1: none)
-    int own_e0, own_e1;  // its records in `part`
-    int blk[NBW], ent[NBW], rowmask[NBW], colmask[NBW];
-    unsigned slice_lo, slice_hi;  // owners: bit r set = workgroup own + r nb takes part (publishes norm records)
-    int active;                   // this workgroup has edges or owns a block (the others leave after the rendezvous)
-    int nrnd;                     // rounds of this workgroup (n > 4096; rowmask holds 8 bits per round, rowmask2 rounds 4 .. 7)
-    int rowmask2[NBW];
-    // rounds, "split extras" (just past the register files): tiles (beyond the rectangle) that ALL eight waves of the
-    // workgroup stream together, 4 row pairs each
-    int nx;            // how many (<= XMAX)
-    int xt[4];         // their tile ids
-    int xs[4];         // slots of their row block (bits 0..7) and column block (8..15) in the workgroup's block list; bit 16: diagonal tile
-    int pad[128 - 8 - 5 * NBW - 9];
-};
-static_assert(sizeof(WaveDesc) == 64 && sizeof(WgDesc) == 512, "descriptor sizes");
 
 constexpr double ZG_OUTSIDE = 1e300;  // zg at entries outside i < j < n: p = max(0, y - zg) is exactly 0 there
 
@@ -162,6 +119,11 @@ struct TileDev {
     int64_t n, nb;
     int NWG, n_entries;
     double gamma, c, omc, nm2, a4g, tol;  // omc = 1 - c (exact: c is in [1/2, 2]), nm2 = n - 2
+    // The variants WITHOUT the norms, tol > 0 (gl_logdeg_iterate's middle phase): the launch runs while the DUAL ratio alone
+    // rules the stopping rule out -- ||qbar - ybar|| / ||d|| >= gate (= a small multiple of tol; smooth_learning.py:159,166:
+    // both ratios must be below tol) -- and ends (ctr[0] = 2) once it comes below it; the primal norms, a third of the pass,
+    // are not formed at all.  0: no gate (a fixed number of iterations).
+    double gate;
     long long it0;
     int maxit;
     unsigned tag0;
@@ -189,6 +151,10 @@ __device__ __forceinline__ tl_u4 tl_gran(double v, unsigned tag) {
     return g;
 }
 __device__ __forceinline__ bool tl_ok(tl_u4 g, unsigned tag) { return g.y == tag && g.w == tag; }
+// v when bit 0 of `bits` is set, else +0.0 -- by an AND, so that a wave-uniform mask costs no branch
+__device__ __forceinline__ double tl_keep(double v, int bits) {
+    return __longlong_as_double(__double_as_longlong(v) & -(long long)(bits & 1));
+}
 __device__ __forceinline__ double lane_bcast(double v, int l) {  // lane l's value in every lane
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
@@ -814,6 +780,8 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     int done_iters = 0, stopped = 0, fail_it = 0;
     double rel_p = INFINITY, rel_d = INFINITY;
     const bool rule_on = P.tol > 0;
+    const bool gate_on = !NORMS && !BATCH && P.gate > 0 && P.tol > 0;  // (see TileDev::gate)
+    constexpr int QN0 = NORMS ? 0 : 2;  // the norm records there are: all four, or the dual pair only (the gate)
     bool evaluated = false, exact = false;
     double screen_prev = INFINITY;  // BATCH: the screen's figure of the previous iteration (wave TW - 1)
 
@@ -831,7 +799,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             for (;;) {
                 bool ok = true;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = QN0; q < 4; ++q) {
                     r[q] = tl_u4{0u, tag, 0u, tag};
                     if (mine)
                         r[q] = __builtin_amdgcn_raw_buffer_load_b128(r_bn, (((j & 3) * (int)P.nb + b0 + lane) * 4 + q) * 16, 0, 16);
@@ -842,7 +810,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 if (!tl_spin(spins, t0, err)) return false;
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) b[q] += wave_sum(mine ? tl_val(r[q]) : 0.0);
+            for (int q = QN0; q < 4; ++q) b[q] += wave_sum(mine ? tl_val(r[q]) : 0.0);
         }
         return true;
     };
@@ -903,6 +871,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         if (last_pass && !want_rule) return false;
         const bool stamp = P.dbg != nullptr && it >= 8 && it < 24 && !last_pass;
         unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long tx[4] = {0, 0, 0, 0};  // per wave: node values seen, records stored, (owners) records seen, node values stored
         if (stamp) ts[0] = __builtin_amdgcn_s_memrealtime();
 
         // ================= acquire: {gamma d, gamma u} of my node blocks, and the norm records of iteration it - 1 =================
@@ -936,6 +905,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                             break;
                         }
                     }
+                    if (stamp) tx[0] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
                     for (int j = 0; j < NACQ; ++j) {
                         const int k = wave + TW * j;
@@ -1029,12 +999,37 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 }
                 }
             }
+            if (!NORMS && gate_on && !FIRST && !last_pass && it >= 2 && wave == TW - 1) {
+                // the gate: what the look at the dual norms of iteration it - 2 found (one workgroup takes it for all, below; its
+                // record has been on its way for a whole hand-off): 2 = the dual ratio has come within gate x tol
+                const unsigned tag = P.tag0 + (unsigned)it;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                unsigned spins = 0;
+                tl_u4 r;
+                for (;;) {
+                    r = tl_u4{0u, tag, 0u, tag};
+                    if (lane < 3) r = __builtin_amdgcn_raw_buffer_load_b128(r_lk, ((((it - 1) & 3) * 4) + lane) * 16, 0, 16);
+                    asm volatile("" ::: "memory");
+                    if (__all(tl_ok(r, tag))) break;
+                    if (!tl_spin(spins, t0, err)) {
+                        good = false;
+                        break;
+                    }
+                }
+                const int look = good ? (int)lane_bcast(tl_val(r), 0) : -1;
+                good = good && look >= 0;
+                if (lane == 0) s_flag[2] = look == 2 ? 2 : 0;
+            }
             if (!good) s_flag[1] = 1;
         }
         tl_barrier();
         if (s_flag[1]) {
             failed = true;
             fail_it = it;
+            return false;
+        }
+        if (!NORMS && gate_on && s_flag[2] == 2) {  // the same record, the same iteration, in every workgroup
+            stopped = 2;
             return false;
         }
         if (want_rule) {
@@ -1230,21 +1225,21 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             nqy = wave_sum(nqy);
             nw = wave_sum(nw);
         }
-        if (lane == 0) {
+        if (NORMS && lane == 0) {
             // ||w_old||^2 of this iteration was accumulated when w_old was produced (squaring the old values inside
             // the pass keeps them alive and costs 75 registers): the sum over the new values is for the next one
             s_wn[wave][0] = nqy;
-            s_wn[wave][1] = NORMS ? s_wcarry[wave] : 0.0;
-            if (NORMS) s_wcarry[wave] = nw;
+            s_wn[wave][1] = s_wcarry[wave];
+            s_wcarry[wave] = nw;
         }
         // (the rule's early look, after the publish phase: its records are requested now)
-        const bool look_on = !BATCH && NORMS && rule_on && !exact && wg == P.rule_wg && wave == TW - 1 && it >= 1 && it + 1 < P.maxit;
+        const bool look_on = !BATCH && (NORMS ? (rule_on && !exact) : gate_on) && wg == P.rule_wg && wave == TW - 1 && it >= 1 && it + 1 < P.maxit;
         tl_u4 lk[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) lk[q] = tl_u4{0u, P.tag0 + (unsigned)it, 0u, P.tag0 + (unsigned)it};
         if (!BIG && look_on && lane < P.nb) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = QN0; q < 4; ++q)
                 lk[q] = __builtin_amdgcn_raw_buffer_load_b128(r_bn, ((((it - 1) & 3) * (int)P.nb + lane) * 4 + q) * 16, 0, 16);
         }
         if (stamp) ts[2] = __builtin_amdgcn_s_memrealtime();
@@ -1267,14 +1262,31 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 const int r = gd_int(GD_NRND) - 1;
                 rm = ((r < 4 ? rm : gd_int(GD_ROW2 + k)) >> (8 * (r & 3))) & 255;
             }
+            // All sixteen vectors are requested at once and the ones the masks leave out are zeroed by an AND (x + 0.0 = x: the
+            // sum and its order are what they were): written as `if (bit) sp += s_part[..]` the masks -- wave-uniform -- become
+            // sixteen scalar branches with one LDS round trip each, three to five of them taken one after the other, between
+            // the end of the workgroup's slowest pass and its records (0.5 us measured; the owners wait for exactly that).
+            // (two halves: sixteen values at once cost the variants with the norms, which have no register to spare, a few
+            //  dwords of scratch right here)
+            int lp = lane;
+            asm volatile("" : "+v"(lp));  // (the LDS addresses are formed here and now: hoisted out of the iteration loop they live in scratch)
 #pragma unroll
-            for (int cs2 = 0; cs2 < TW; ++cs2) {
-                if ((rm >> cs2) & 1) sp += s_part[cs2][0][lane];
-                if ((cm >> cs2) & 1) sp += s_part[cs2][1][lane];
+            for (int h4 = 0; h4 < TW; h4 += TW / 2) {
+                double rvec[TW / 2], cvec[TW / 2];
+#pragma unroll
+                for (int q = 0; q < TW / 2; ++q) {
+                    rvec[q] = s_part[h4 + q][0][lp];
+                    cvec[q] = s_part[h4 + q][1][lp];
+                }
+#pragma unroll
+                for (int q = 0; q < TW / 2; ++q) {
+                    sp += tl_keep(rvec[q], rm >> (h4 + q));
+                    sp += tl_keep(cvec[q], cm >> (h4 + q));
+                }
             }
-            __builtin_amdgcn_raw_buffer_store_b128(tl_gran(sp, tag_out), r_part, (gd_int(GD_ENT + k) * TB + lane) * 16, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(tl_gran(sp, tag_out), r_part, (gd_int(GD_ENT + k) * TB + lp) * 16, 0, 16);
         }
-        if (tid == 0) {
+        if (NORMS && tid == 0) {  // (without the norms nobody reads these records)
             double a = s_wn[0][0], b = s_wn[0][1];
 #pragma unroll
             for (int v = 1; v < TW; ++v) {
@@ -1286,7 +1298,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             __builtin_amdgcn_raw_buffer_store_b128(tl_gran(b, tag_out), r_wn, off + 16, 0, 16);
         }
         done_iters = it + 1;
-        if (stamp) ts[3] = __builtin_amdgcn_s_memrealtime();
+        if (stamp) ts[3] = tx[1] = __builtin_amdgcn_s_memrealtime();
         // The rule's early look for the top of iteration it + 1: the records of iteration it - 1 (a whole iteration old).
         // ONE workgroup takes it for all (P.rule_wg: no node block of its own, so it would only wait for node values now)
         // and publishes what it found as a tagged record that every workgroup reads at its next top -- in the owners the
@@ -1301,17 +1313,23 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 const unsigned tag = P.tag0 + (unsigned)it;  // records of local iteration it - 1
                 bool ok = true;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) ok = ok && tl_ok(lk[q], tag);
+                for (int q = QN0; q < 4; ++q) ok = ok && tl_ok(lk[q], tag);
                 if (__all(ok)) {
                     have = true;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) b[q] = wave_sum(lane < P.nb ? tl_val(lk[q]) : 0.0);
+                    for (int q = QN0; q < 4; ++q) b[q] = wave_sum(lane < P.nb ? tl_val(lk[q]) : 0.0);
                 }
             }
             int look = 0;
             if (!have) look = norms_of(it - 1, b) ? 0 : -1;
             double lp = INFINITY, ld = INFINITY;
-            if (look == 0 && P.it0 + it - 1 >= 1) {  // never for iteration 0 (:156-161)
+            if (!NORMS) {  // the gate: the dual ratio alone, against gate x tol (squares: no root, no division)
+                if (look == 0 && P.it0 + it - 1 >= 1) {
+                    double tl = P.gate;
+                    asm volatile("" : "+s"(tl));
+                    if (b[2] < tl * tl * b[3]) look = 2;
+                }
+            } else if (look == 0 && P.it0 + it - 1 >= 1) {  // never for iteration 0 (:156-161)
                 double tl = P.tol;
                 asm volatile("" : "+s"(tl));  // (formed here: hoisted out of the iteration loop the squares live in scratch)
                 const double t2 = tl * tl, u2 = (1.25 * tl) * (1.25 * tl);
@@ -1335,6 +1353,12 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             double (*s_own)[TB] = reinterpret_cast<double (*)[TB]>(&s_part[0][0][0]);
             bool good = true;
             double sp = 0;
+            // (wave 0: what its update needs of the dual state, requested while the records are still on their way)
+            int lnp = lane;
+            asm volatile("" : "+v"(lnp));  // (the address is formed here and now, see below)
+            // (not in the variants with the norms: eight more registers across the poll put theirs into scratch)
+            double d_cur = 0, yb_cur = 0, pb_cur = 0, gsw_cur = 0;
+            if (!NORMS && wave == 0) d_cur = s_dual[0][lnp], yb_cur = s_dual[1][lnp], pb_cur = s_dual[2][lnp], gsw_cur = s_dual[4][lnp];
             {
                 early_look();  // (wave TW - 1: before its share of the poll, whose records are still on their way)
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -1375,6 +1399,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     for (int u = 0; u < RND; ++u)
                         if (eb + u * TW < own_e1) sp += tl_val(g[u]);
                 }
+                if (stamp) tx[2] = __builtin_amdgcn_s_memrealtime();
                 s_own[wave][lane] = sp;
                 if (wave == 1) {
                     for (;;) {
@@ -1413,7 +1438,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
 #pragma unroll
                 for (int v = 1; v < TW; ++v) sp += s_own[v][ln];
                 const bool real = (int64_t)in_graph(own) * TB + ln < P.n;
-                const double d_cur = s_dual[0][ln], yb_cur = s_dual[1][ln], pb_cur = s_dual[2][ln], gsw_cur = s_dual[4][ln];
+                if (NORMS) d_cur = s_dual[0][ln], yb_cur = s_dual[1][ln], pb_cur = s_dual[2][ln], gsw_cur = s_dual[4][ln];
                 const double gsp = P.gamma * sp;
                 const double qb = pb_cur + gsp;           // :154
                 const double dq = qb - yb_cur;            // == -ybar + qbar (:159)
@@ -1440,7 +1465,8 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 __builtin_amdgcn_raw_buffer_store_b128(tl_gran(gu_new, tag_out), r_nval, off + TB * 16, 0, 16);
                 const double us = wave_sum(gu_new);
                 if (ln == 0) __builtin_amdgcn_raw_buffer_store_b128(tl_gran(us, tag_out), r_us, (int)(((tag_out & 1u) * (unsigned)P.nb + (unsigned)own) * 16u), 0, 16);
-                if (NORMS) {  // my block's norm partials (the node values are out: nobody waits for these)
+                if (stamp) tx[3] = __builtin_amdgcn_s_memrealtime();
+                if (NORMS || gate_on) {  // my block's norm partials (the node values are out: nobody waits for these)
                     dq2 = wave_sum(dq2);
                     d2 = wave_sum(d2);
                     if (ln == 2 || ln == 3) {
@@ -1490,6 +1516,10 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see the prologue (by now everything has long completed)
         if (it == 0) call_stamp(3);  // end of the first iteration
+        if (stamp && lane == 0) {
+            unsigned long long *o = P.dbg + (size_t)P.NWG * (16 * (6 + 2 * TW) + 8 * TW) + (((size_t)wg * 16 + (it - 8)) * TW + wave) * 4;
+            for (int q = 0; q < 4; ++q) o[q] = tx[q];
+        }
         if (stamp && tid == 0) {
             ts[5] = __builtin_amdgcn_s_memrealtime();
             unsigned long long *o = P.dbg + ((size_t)wg * 16 + (it - 8)) * 6;
@@ -1676,7 +1706,7 @@ static int tile_finish(gl_logdeg *s, std::vector<WaveDesc> &wd, std::vector<WgDe
     const size_t b_bar = up256((size_t)GL_BAR_WORDS * 4);
     const size_t b_zg = up256((size_t)D.ntiles * GL_TILE_ELEMS * sizeof(double));
     const size_t total = b_wd + b_gd + b_part + b_nval + b_us + b_wn + b_bn + b_lk + b_bar + b_zg;
-    if (hipMalloc(&t->arena, total) != hipSuccess) {
+    if (gl_ctx_malloc(ctx, &t->arena, total, "tile") != hipSuccess) {
         delete t;
         return gl_set_error(ctx, GL_E_NOMEM, "tile engine: hipMalloc(%zu) failed", total);
     }
@@ -1737,8 +1767,8 @@ static int tile_finish(gl_logdeg *s, std::vector<WaveDesc> &wd, std::vector<WgDe
         if (const char *e = getenv("GRAPHLEARN_AMD_TILE_NT")) t->nt = atoi(e) != 0;
     }
     P.dbg = nullptr;
-    if (getenv("GRAPHLEARN_AMD_RES_STAMPS") && hipMalloc((void **)&t->dbg, (size_t)NWG * (16 * (6 + 2 * TW) + 8 * TW) * 8) == hipSuccess) {
-        (void)hipMemset(t->dbg, 0, (size_t)NWG * (16 * (6 + 2 * TW) + 8 * TW) * 8);
+    if (getenv("GRAPHLEARN_AMD_RES_STAMPS") && hipMalloc((void **)&t->dbg, (size_t)NWG * (16 * (6 + 2 * TW) + 8 * TW + 16 * 4 * TW) * 8) == hipSuccess) {
+        (void)hipMemset(t->dbg, 0, (size_t)NWG * (16 * (6 + 2 * TW) + 8 * TW + 16 * 4 * TW) * 8);
         P.dbg = t->dbg;
         int maxblk = 0;
         for (const WgDesc &G : gd) maxblk = std::max(maxblk, G.nblk);
@@ -1918,133 +1948,6 @@ static int tile_prepare_rounds(gl_logdeg *s, bool allow_split = true) {
     return tile_finish(s, wd, gd, NWG, SLOTS, true);
 }
 
-// The static work decomposition of ONE lattice of nb node blocks on at most ncu workgroups (below the rounds).
-// NWG_out = 0: it does not apply.
-static int tile_plan_fit(const int nb, const int ncu, const bool forced, std::vector<WaveDesc> &wd_out, std::vector<WgDesc> &gd_out,
-                         int &NWG_out, int &U_out) {
-    NWG_out = 0;
-    U_out = SLOTS;
-    const int F = nb * (nb - 1) / 2;  // bulk (off-diagonal) tiles
-    if (nb > 64 || F > TW * ncu) return GL_OK;  // does not fit the register files
-    if (!forced && F < GL_TILE_MIN_BULK_TILES) return GL_OK;  // (n <= 128 belongs to the small engine)
-    // chunk length: the finest split that still fits one chunk per wave of the chip (shorter edge phase)
-    int U = F * 4 <= TW * ncu ? 8 : (F * 2 <= TW * ncu ? 16 : 32);
-    if (const char *e = getenv("GRAPHLEARN_AMD_TILE_U")) {
-        const int u = atoi(e);
-        if ((u == 8 || u == 16 || u == 32) && F * (SLOTS / u) <= TW * ncu) U = u;
-    }
-    // Order of the bulk tiles.  A workgroup's 8 chunks are U / 4 tiles: one "super-tile" of SR block rows x SC block
-    // columns (2 x 4, 2 x 2, 1 x 2), which touches SR + SC node blocks only.  Complete super-tiles come first, one per
-    // workgroup; the tiles of incomplete ones (along the diagonal and the lattice's edge) follow row by row.
-    const int SR = U == 8 ? 1 : 2, SC = U == 32 ? 4 : 2;
-    std::vector<std::pair<int, int>> bulk, rest;
-    for (int IB = 0; SR * IB < nb; ++IB)
-        for (int JB = 0; SC * JB < nb; ++JB) {
-            std::vector<std::pair<int, int>> st;
-            for (int a = 0; a < SR; ++a)
-                for (int b = 0; b < SC; ++b) {
-                    const int I = SR * IB + a, J = SC * JB + b;
-                    if (I < J && J < nb) st.push_back({I, J});
-                }
-            auto &dst = (int)st.size() == SR * SC ? bulk : rest;
-            dst.insert(dst.end(), st.begin(), st.end());
-        }
-    std::sort(rest.begin(), rest.end());
-    bulk.insert(bulk.end(), rest.begin(), rest.end());
-    const int per_tile = SLOTS / U, nchunks = F * per_tile;
-    int NWG = (nchunks + TW - 1) / TW;
-    NWG = std::max(NWG, (SLOTS * nb * 4 + TW * FRMAX * 3 - 1) / (TW * FRMAX * 3));  // room for the fringe, a third to spare
-    NWG = std::max(NWG, nb);                                                         // every node block needs an owner
-    if (NWG > ncu || NWG > 64 * nb) return GL_OK;
-    const int nwaves = NWG * TW;
-    std::vector<WaveDesc> wd((size_t)nwaves);
-    for (WaveDesc &w : wd) {
-        memset(&w, 0, sizeof w);
-        w.tile = -1;
-        w.fB = -1;
-    }
-    for (int q = 0; q < nchunks; ++q) {
-        WaveDesc &w = wd[(size_t)q];
-        const int f = q / per_tile;
-        w.tile = (int)gl_tile_id(bulk[(size_t)f].first, bulk[(size_t)f].second, nb);
-        w.I = bulk[(size_t)f].first;
-        w.J = bulk[(size_t)f].second;
-        w.a0 = (q % per_tile) * U;
-    }
-    // fringe: the 32 row pairs of diagonal tile (B, B) go, in groups of <= FRMAX, to waves whose chunk already works on
-    // block B as its row or column block (then the workgroup's block list does not grow and the partials fold into
-    // the chunk's vectors), else to waves without a chunk.  A chunk of tile (I, J) can serve I or J: it prefers one of
-    // them by parity, so that every block finds takers among its row and its column; what is left goes to any taker.
-    {
-        std::vector<int> need((size_t)nb, SLOTS);
-        const int cap = nchunks > 0 ? std::max(1, std::min(FRMAX, (SLOTS * nb + nchunks - 1) / nchunks)) : FRMAX;
-        auto give = [&](WaveDesc &w, int B, int most) {
-            const int take = std::min(most, need[(size_t)B]);
-            if (take <= 0 || w.fcnt != 0) return;
-            w.fB = B;
-            w.fa0 = SLOTS - need[(size_t)B];
-            w.fcnt = take;
-            w.ftgt = (w.tile >= 0 && w.I != B) ? 1 : 0;  // my column vector when B is my column block
-            need[(size_t)B] -= take;
-        };
-        // (passes 0, 1: the older half of every workgroup's waves -- waves 0..3 win the issue arbitration of their SIMD
-        //  and finish their pass first --, preferred block then the other one; passes 2, 3: the younger half)
-        for (int pass = 0; pass < 5; ++pass)
-            for (int v = 0; v < nwaves; ++v) {
-                WaveDesc &w = wd[(size_t)v];
-                if (w.fcnt != 0) continue;
-                if (w.tile >= 0 && pass < 4) {
-                    if (((v % TW) < TW / 2) != (pass < 2)) continue;
-                    const bool odd = ((w.I + w.J + w.a0 / U) & 1) != 0;
-                    give(w, (odd != ((pass & 1) == 1)) ? w.J : w.I, (pass & 1) == 0 ? cap : FRMAX);
-                } else if (w.tile < 0 && pass == 4) {
-                    int B = 0;
-                    for (int b = 1; b < nb; ++b)
-                        if (need[(size_t)b] > need[(size_t)B]) B = b;
-                    give(w, B, FRMAX);
-                }
-            }
-        for (int B = 0; B < nb; ++B)
-            if (need[(size_t)B] > 0) return GL_OK;  // (tiny lattices on few workgroups: the other engines serve them)
-    }
-    // block lists, records, masks
-    std::vector<WgDesc> gd((size_t)NWG);
-    for (int g = 0; g < NWG; ++g) {
-        WgDesc &G = gd[(size_t)g];
-        memset(&G, 0, sizeof G);
-        G.own = g < nb ? g : -1;
-        auto slot_of = [&](int B) -> int {
-            for (int k = 0; k < G.nblk; ++k)
-                if (G.blk[k] == B) return k;
-            if (G.nblk >= NBW_FIT) return -1;
-            G.blk[G.nblk] = B;
-            return G.nblk++;
-        };
-        for (int v = 0; v < TW; ++v) {
-            WaveDesc &w = wd[(size_t)(g * TW + v)];
-            if (w.tile >= 0) {
-                w.si = slot_of(w.I);
-                w.sj = slot_of(w.J);
-                if (w.si < 0 || w.sj < 0) return GL_OK;  // too many node blocks for one workgroup's LDS
-                G.rowmask[w.si] |= 1 << v;
-                G.colmask[w.sj] |= 1 << v;
-            }
-            if (w.fcnt > 0) {
-                w.fs = slot_of(w.fB);
-                if (w.fs < 0) return GL_OK;
-                if (w.tile < 0) G.rowmask[w.fs] |= 1 << v;  // a wave without a chunk: its row vectors carry the group alone
-            }
-        }
-        G.active = (G.nblk > 0 || G.own >= 0) ? 1 : 0;
-    }
-    wd_out.swap(wd);
-    gd_out.swap(gd);
-    NWG_out = NWG;
-    U_out = U;
-    return GL_OK;
-}
-
-
 // Builds the static work decomposition.  GL_OK with s->tile == nullptr when the engine does not apply.
 int gl_tile_prepare(gl_logdeg *s) {
     gl_ctx *ctx = s->ctx;
@@ -2061,7 +1964,8 @@ int gl_tile_prepare(gl_logdeg *s) {
     std::vector<WaveDesc> wd;
     std::vector<WgDesc> gd;
     int NWG = 0, U = SLOTS;
-    GL_TRY(tile_plan_fit(nb, ncu, forced, wd, gd, NWG, U));
+    (void)tile_plan_fit(nb, ncu, forced, wd, gd, NWG, U, getenv("GRAPHLEARN_AMD_TILE_U") ? atoi(getenv("GRAPHLEARN_AMD_TILE_U")) : 0,
+                        getenv("GRAPHLEARN_AMD_TILE_NO_EXTRA_WG") == nullptr);
     if (NWG == 0) return GL_OK;
     return tile_finish(s, wd, gd, NWG, U, false);
 }
@@ -2081,7 +1985,8 @@ int gl_tile_prepare_batch(gl_logdeg *s, int B) {
     std::vector<WaveDesc> wd1;
     std::vector<WgDesc> gd1;
     int NWG1 = 0, U = SLOTS;
-    GL_TRY(tile_plan_fit(nb1, ncu / B, false, wd1, gd1, NWG1, U));
+    (void)tile_plan_fit(nb1, ncu / B, false, wd1, gd1, NWG1, U, getenv("GRAPHLEARN_AMD_TILE_U") ? atoi(getenv("GRAPHLEARN_AMD_TILE_U")) : 0,
+                        getenv("GRAPHLEARN_AMD_TILE_NO_EXTRA_WG") == nullptr);
     if (NWG1 == 0 || NWG1 > 64 * nb1) return GL_OK;
     std::vector<WaveDesc> wd((size_t)B * NWG1 * TW);
     std::vector<WgDesc> gd((size_t)B * NWG1);
@@ -2125,7 +2030,9 @@ bool gl_tile_writes_final_parity(const gl_logdeg *s) { return s->tile != nullptr
 // caller fixes the ping-pong parity afterwards; 0 / 1 (fixed-iteration calls below the rounds): it is written to that
 // buffer directly.  norms = false (only with tol = 0): the ratios of the stopping rule are not formed at all (dstat
 // keeps its previous values).
-int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int final_parity) {
+// gate > 0 (with norms = false and tol > 0): the variant without the norms runs while the dual ratio alone rules the stopping
+// rule out and ends (ctr[0] = 2) when it comes within gate x tol (TileDev::gate).
+int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int final_parity, double gate) {
     gl_ctx *ctx = s->ctx;
     gl_tile *t = s->tile;
     TileDev P = t->dev;
@@ -2155,7 +2062,8 @@ int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int fina
     P.dring = t->batch ? t->dring : nullptr;
     P.ring_stride = t->ring_stride;
     P.dring_stride = t->dring_stride;
-    if (tol > 0 || t->batch) norms = true;
+    if ((tol > 0 && !(gate > 0 && !norms)) || t->batch) norms = true;
+    P.gate = (!norms && tol > 0) ? gate * tol : 0.0;
     P.it0 = s->it;
     P.maxit = (int)std::min<int64_t>(iters, 1 << 30);
     if (t->next_tag == 0u || t->next_tag > 0xE0000000u - (unsigned)P.maxit) {  // the tags would wrap into old ones
@@ -2211,8 +2119,16 @@ int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int fina
 void gl_tile_dump_stamps(gl_logdeg *s) {
     if (!s || !s->tile || !s->tile->dbg) return;
     const int NWG = s->tile->dev.NWG, nb = (int)s->tile->dev.nb;
-    std::vector<unsigned long long> h((size_t)NWG * (16 * (6 + 2 * TW) + 8 * TW));
+    std::vector<unsigned long long> h((size_t)NWG * (16 * (6 + 2 * TW) + 8 * TW + 16 * 4 * TW));
     (void)hipMemcpy(h.data(), s->tile->dbg, h.size() * 8, hipMemcpyDeviceToHost);
+    if (const char *raw = getenv("GRAPHLEARN_AMD_RES_STAMPS_RAW")) {  // the stamps themselves, for tools/stamps_raw.py
+        if (FILE *f = fopen(raw, "ab")) {
+            const unsigned long long hdr[4] = {0x544c5354414d5053ull, (unsigned long long)NWG, (unsigned long long)nb, (unsigned long long)TW};
+            fwrite(hdr, 8, 4, f);
+            fwrite(h.data(), 8, h.size(), f);
+            fclose(f);
+        }
+    }
     {  // the call as a whole (100 MHz ticks -> us), relative to the earliest entry of any wave
         const unsigned long long *cw = h.data() + (size_t)NWG * 16 * (6 + 2 * TW);
         unsigned long long t0 = ~0ull;

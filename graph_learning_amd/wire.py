@@ -12,7 +12,8 @@ self-describing record so that a gathered (or saved) block of bytes can be split
     32      8     iterations run (int64)
     40      8     theta (float64)
     48      8     edge_tol applied to the weights (float64)
-    56      8     flags (uint64): bit 0 = stopped on the tolerance
+    56      8     flags (uint64): bit 0 = stopped on the tolerance, bit 1 = the sender FAILED to solve this problem
+                  (the record still travels, so that no rank waits for it and every rank learns of the failure)
     64      8 E   condensed fp64 weights, upper triangle row by row (scipy ``squareform`` order)
 
 Little-endian, fixed 64-byte header, so a (world, 8 + E) float64 all-gather buffer of such records is
@@ -32,7 +33,7 @@ HEADER_DOUBLES = HEADER.size // 8
 assert HEADER.size == 64
 
 
-def pack(weights_condensed, *, problem_id=0, n_iter=0, theta=1.0, edge_tol=0.0, converged=False) -> np.ndarray:
+def pack(weights_condensed, *, problem_id=0, n_iter=0, theta=1.0, edge_tol=0.0, converged=False, failed=False) -> np.ndarray:
     """One record as a float64 vector of length 8 + E (header bytes reinterpreted as 8 doubles)."""
     w = np.ascontiguousarray(weights_condensed, dtype=np.float64)
     if w.ndim != 1:
@@ -42,7 +43,7 @@ def pack(weights_condensed, *, problem_id=0, n_iter=0, theta=1.0, edge_tol=0.0, 
     if n * (n - 1) // 2 != e:
         raise ValueError(f"{e} is not a valid number of edges")
     head = HEADER.pack(MAGIC, VERSION, n, e, int(problem_id), int(n_iter), float(theta), float(edge_tol),
-                       1 if converged else 0)
+                       (1 if converged else 0) | (2 if failed else 0))
     out = np.empty(HEADER_DOUBLES + e)
     out[:HEADER_DOUBLES] = np.frombuffer(head, dtype=np.float64)
     out[HEADER_DOUBLES:] = w
@@ -63,7 +64,7 @@ def unpack(record) -> dict:
     if e != n * (n - 1) // 2 or buf.size < HEADER_DOUBLES + e:
         raise ValueError("inconsistent record size")
     return {"n_nodes": n, "n_edges": e, "problem_id": pid, "n_iter": n_iter, "theta": theta, "edge_tol": edge_tol,
-            "converged": bool(flags & 1), "weights": buf[HEADER_DOUBLES:HEADER_DOUBLES + e]}
+            "converged": bool(flags & 1), "failed": bool(flags & 2), "weights": buf[HEADER_DOUBLES:HEADER_DOUBLES + e]}
 
 
 def save(path, records) -> None:

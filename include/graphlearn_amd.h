@@ -53,6 +53,12 @@ int gl_ctx_destroy(gl_ctx *ctx);
 const char *gl_last_error(gl_ctx *ctx);
 int gl_ctx_device_name(gl_ctx *ctx, char *buf, int buflen);
 int gl_ctx_sync(gl_ctx *ctx);
+/* Gives back the device memory the context retains between calls for speed: the pool of released session
+ * blocks, the batched solver's stand-in session with its ring of iterates, the scratch of the batched entry
+ * points.  The library does this itself before it reports GL_E_NOMEM from any of its own allocations; call it
+ * on a shared device when a long-lived context should shrink.  No reference counterpart (NumPy arrays are
+ * garbage-collected, smooth_learning.py:286-300 keeps only theta_ / weights_). */
+int gl_ctx_trim(gl_ctx *ctx);
 /* HIP-event timer on the context's stream (bench.py's timed region). */
 int gl_ctx_timer_start(gl_ctx *ctx);
 int gl_ctx_timer_stop(gl_ctx *ctx, double *elapsed_ms);
@@ -120,10 +126,13 @@ int gl_logdeg_time_edge_pass(gl_logdeg *s, int reps, double *avg_us_out);
 
 /* Which iteration engine serves long gl_logdeg_iterate / _async calls of this session (after
  * gl_logdeg_init): 0 = streaming (one edge-pass + one node-pass launch per iteration, iterate in
- * HBM), 1 = resident (one persistent launch per call, iterate held in registers / LDS, grid
- * barriers; chosen when the lattice fits the register files and is large enough to pay off),
- * 2 = small (n <= 128: one workgroup, the whole problem in LDS / registers, one launch per call).
- * GRAPHLEARN_AMD_ENGINE=stream|resident|small overrides.  Same iterates up to summation order. */
+ * HBM; n >~ 11 400 and calls shorter than 4 iterations), 1 = resident (one persistent launch per
+ * call: the tile engine -- iterate in registers, distances in LDS, tagged hand-offs between
+ * workgroups instead of grid barriers, rounds of streamed tiles past n = 4096 -- for
+ * 129 <= n <~ 11 400; round 1's grid-barrier engine only on request), 2 = small (n <= 128: one
+ * workgroup, the whole problem in LDS / registers, one launch per call).
+ * GRAPHLEARN_AMD_ENGINE = stream | tile | resident (= tile where it applies, else round 1's
+ * engine) | resident1 (round 1's engine) | small forces one.  Same iterates up to summation order. */
 int gl_logdeg_engine(gl_logdeg *s);
 
 /* Batched (2-D) path of gsp_learn_graph_log_degrees (smooth_learning.py:128-129,158-159):
@@ -182,6 +191,14 @@ int gl_theta_from_matrix(gl_ctx *ctx, const double *zsq, int64_t rows, int64_t c
  * host channel; then every rank calls gl_comm_create. */
 int gl_comm_unique_id(void *out128);
 int gl_comm_create(gl_ctx *ctx, int rank, int nranks, const void *unique_id128, gl_comm **out);
+/* A collective completes only when every rank enters it.  So that a failing rank cannot hang the others (and the
+ * node): every wait of the calls below is bounded by the wall clock (`seconds`, default 300, or the environment
+ * variable GRAPHLEARN_AMD_COMM_TIMEOUT_S at creation) and returns GL_E_COMM when a peer never arrives; a rank
+ * that meets a local error on its way INTO a collective (allocation, copy, the solver's staging) aborts the
+ * communicator before it returns that error, as gl_comm_abort does for a caller that cannot go on.  After
+ * either, every later call on this communicator fails at once with GL_E_COMM: the process should exit non-zero. */
+int gl_comm_set_timeout(gl_comm *c, double seconds);
+int gl_comm_abort(gl_comm *c);
 int gl_comm_destroy(gl_comm *c);
 int gl_comm_barrier(gl_comm *c);
 int gl_comm_allreduce_max(gl_comm *c, double *value);
@@ -192,11 +209,13 @@ int gl_comm_allgather_weights(gl_comm *c, gl_logdeg *s, double edge_tol, double 
 int gl_comm_allgather_f64(gl_comm *c, const double *host_in, int64_t count, double *host_out);
 /* The gather payload: one self-describing record per rank -- the 64-byte header of
  * graph_learning_amd/wire.py (magic, version, n_nodes, n_edges, problem id, iterations, theta, edge_tol,
- * flags bit 0 = stopped on the tolerance) followed by the E condensed, thresholded weights -- gathered
- * device-to-device; host_out is (nranks, 8 + E) doubles or NULL.  The reference keeps results as ndarray
- * attributes (smooth_learning.py:299-300: theta_, weights_); this is their wire form. */
+ * flags) followed by the E condensed, thresholded weights -- gathered device-to-device; host_out is
+ * (nranks, 8 + E) doubles or NULL.  flags: bit 0 = stopped on the tolerance, bit 1 = this rank FAILED to
+ * solve its problem (it still takes part, so nobody waits for it, and every rank reads the failure from the
+ * record).  The reference keeps results as ndarray attributes (smooth_learning.py:299-300: theta_,
+ * weights_); this is their wire form. */
 int gl_comm_allgather_records(gl_comm *c, gl_logdeg *s, double edge_tol, int64_t problem_id, int64_t n_iter,
-                              double theta, int converged, double *host_out);
+                              double theta, int flags, double *host_out);
 
 /* ---- Laplacian-constrained GMRF (graph_learn/lgmrf.py, graph_learn/evaluation.py) ---- */
 /* relative_error(y_true, y_pred) (evaluation.py:8-25): ||pred-true||_F / ||true||_F, or the

@@ -41,7 +41,15 @@ VERS = np.array([f"numpy {np.__version__}", f"scipy {scipy.__version__}",
 
 
 def save(name, **arrays):
+    """Write the fixture.  A regeneration must reproduce the committed DATA bit for bit (only `versions` may change):
+    asserted here, array by array, before anything is overwritten."""
     path = os.path.join(HERE, name + ".npz")
+    if os.path.exists(path) and not os.environ.get("GOLDEN_ALLOW_CHANGE"):
+        old = np.load(path)
+        assert sorted(k for k in old.files if k != "versions") == sorted(arrays), f"{name}: the set of arrays changed"
+        for k, v in arrays.items():
+            a, b = np.asarray(old[k]), np.asarray(v)
+            assert a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes(), f"{name}[{k}] differs from the committed fixture"
     np.savez_compressed(path, versions=VERS, **arrays)
     print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
 
@@ -437,6 +445,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if sys.argv[1:] == ["lgmrf_mask"]:
         gen_lgmrf_mask()
+        sys.exit(0)
+    if sys.argv[1:] == ["fast"]:          # everything but the two slow LGMRF fixtures
+        for gen in (gen_sum_squareform, gen_theta, gen_logmodel, gen_batched, gen_lgmrf, gen_operators, gen_graphdict, gen_clustering):
+            gen()
         sys.exit(0)
     gen_sum_squareform()
     gen_theta()

@@ -165,3 +165,87 @@ def test_world_size_2_logmodel_batch_carries_headers(tmp_path):
         assert (rec["problem_id"], rec["n_nodes"], rec["n_iter"], rec["theta"]) == (k, 8, o.info_["n_iter"], o.theta_)
         seen_iters.add(int(r0["n_iter"][k]))
     assert len(set(r0["theta"])) == 5 and len(seen_iters) > 1   # the headers really differ per problem
+
+
+# ---------------------------------------------------------------------------------- a rank that fails
+#  Every collective is entered by all ranks or the process exits non-zero: nobody hangs.
+FAIL_WORKER = textwrap.dedent("""
+    import os, sys, time
+    import numpy as np
+    sys.path.insert(0, os.environ["GL_ROOT"])
+    from graph_learning_amd.batch import GlooComm, LogModelBatch, BatchError
+
+    MODE = os.environ["GL_FAIL_MODE"]
+
+    class Session:
+        def __init__(self, n, ctx=None):
+            self.n, self.n_edges = n, n * (n - 1) // 2
+            self.raw = np.zeros(self.n_edges)
+        def __enter__(self): return self
+        def __exit__(self, *a): pass
+        def set_signals(self, x, k):
+            self.cur = float(np.asarray(x)[0, 0])
+            return 1.0
+        def set_distances(self, z): self.raw = np.zeros(self.n_edges)
+        def init(self, a, b, step, edge_init): pass
+        def iterate(self, maxit, tol):
+            if self.cur == 1.0:                       # problem 1 = rank 1's first problem
+                if MODE == "raise":
+                    raise FloatingPointError("the solver of problem 1 blew up")
+                os._exit(3)                           # MODE == "die": the rank is gone before the gather
+            self.raw = np.full(self.n_edges, self.cur)
+            return 7, True, (0.0, 0.0)
+        def weights_condensed(self, edge_tol=-np.inf): return self.raw.copy()
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    comm = GlooComm(rank, world, timeout_s=float(os.environ["GL_BOUND"]))
+    xs = [np.full((4, 6), float(k)) for k in range(4)]
+    t0 = time.time()
+    try:
+        LogModelBatch(session_factory=Session).fit(xs, comm)
+    except BatchError as exc:
+        print(f"BatchError after {time.time() - t0:.1f}s: {exc}", flush=True)
+        sys.exit(17)
+    except Exception as exc:                          # the collective itself gave up (peer gone / bound reached)
+        print(f"collective error after {time.time() - t0:.1f}s: {type(exc).__name__}: {exc}", flush=True)
+        sys.exit(18)
+    sys.exit(0)
+""")
+
+
+def run_fail_workers(tmp_path, mode, bound):
+    import time
+
+    port = free_port()
+    procs = []
+    t0 = time.time()
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GL_ROOT=ROOT, GL_OUT=str(tmp_path), OMP_NUM_THREADS="1", GL_FAIL_MODE=mode,
+                   GL_BOUND=str(bound))
+        env.pop("GRAPHLEARN_AMD_COMM_TIMEOUT_S", None)
+        procs.append(subprocess.Popen([sys.executable, "-c", FAIL_WORKER], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    return [p.returncode for p in procs], outs, time.time() - t0
+
+
+@pytest.mark.timeout(300)
+def test_rank_whose_solver_raises_still_enters_the_gather(tmp_path):
+    """Rank 1's solver raises on its first problem.  It still takes part in the round's gather with a record flagged
+    `failed`, so rank 0 -- which solved its own problem -- gets the SAME BatchError at the same point, at once."""
+    codes, outs, _ = run_fail_workers(tmp_path, "raise", bound=120)
+    assert codes == [17, 17], outs
+    for o in outs:
+        assert "rank 1 (problem 1) failed to solve its problem" in o, o
+    assert "blew up" in outs[1]
+
+
+@pytest.mark.timeout(300)
+def test_rank_that_dies_before_the_gather_does_not_hang_the_other(tmp_path):
+    """Rank 1 is gone before the gather (os._exit in its solver).  Rank 0 must come back with an error within the
+    communicator's bound (20 s here) -- not wait for the launcher's kill -- and exit non-zero."""
+    codes, outs, took = run_fail_workers(tmp_path, "die", bound=20)
+    assert codes[1] == 3, outs
+    assert codes[0] in (17, 18), outs            # an error, never 0 and never a kill by this test's timeout
+    assert took < 120, (took, outs)

@@ -63,3 +63,44 @@ def test_logmodel_batch_through_rccl_records(tmp_path):
         assert rec["problem_id"] == k and rec["n_iter"] == b.n_iter_[k] and rec["theta"] == b.theta_[k]
     comm.close()
     ctx.close()
+
+
+def test_rank_that_fails_in_front_of_a_collective_aborts_the_communicator(tmp_path, monkeypatch):
+    """a rank that meets a local error on its way INTO a collective (here: the receive buffer's
+    allocation, forced to fail) must not leave the others waiting for it.  It aborts the communicator (ncclCommAbort)
+    before it returns the error; every later call fails at once with GL_E_COMM instead of entering a collective that the
+    peers have left; the solver session and the context stay usable."""
+    ctx = _lib.Context(0)
+    comm = RcclComm(ctx, 0, 1, rendezvous_key=f"abort_{tmp_path.name}")
+    x, _ = logmodel_problem(40, 80, seed=5)
+    with _lib.LogDegreeSession(40, ctx) as s:
+        s.set_signals(x, 4)
+        s.init(1, 1, 0.5, None)
+        s.iterate(20, 0.0)
+        monkeypatch.setenv("GRAPHLEARN_AMD_TEST_ALLOC_FAIL", "comm")
+        with pytest.raises(MemoryError):
+            comm.allgather_records(s, 1e-3, problem_id=0, n_iter=20, theta=1.0)
+        monkeypatch.delenv("GRAPHLEARN_AMD_TEST_ALLOC_FAIL")
+        with pytest.raises(_lib.GraphLearnError, match="aborted"):
+            comm.barrier()
+        with pytest.raises(_lib.GraphLearnError, match="aborted"):
+            comm.allgather_records(s, 1e-3, problem_id=0, n_iter=20, theta=1.0)
+        s.iterate(5, 0.0)                                   # the context and the session are untouched
+        assert s.total_iterations == 25
+    comm.close()
+    ctx.close()
+
+
+def test_logmodel_batch_reports_a_failed_problem_through_the_gather(tmp_path):
+    """A problem whose solve raises (here: a signal matrix with the wrong number of nodes, refused by the library) still goes
+    through the round's gather as a record flagged `failed`; fit raises BatchError naming it, on every rank alike."""
+    from graph_learning_amd.batch import BatchError
+
+    ctx = _lib.Context(0)
+    comm = RcclComm(ctx, 0, 1, rendezvous_key=f"fail_{tmp_path.name}")
+    xs = [logmodel_problem(24, 50, seed=0)[0], np.ones((50, 23))]      # the second has the wrong number of nodes
+    with pytest.raises(BatchError, match=r"rank 0 \(problem 1\) failed"):
+        LogModelBatch(avg_degree=3, maxit=50, tol=0.0).fit(xs, comm)
+    comm.barrier()                                          # the communicator is alive: every rank entered the gather
+    comm.close()
+    ctx.close()

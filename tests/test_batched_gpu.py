@@ -120,7 +120,8 @@ def test_batched_launch_path_chunks_and_budget(chunk, monkeypatch):
 
 
 @pytest.mark.parametrize("n,b,hook", [(256, 8, None), (256, 20, None), (160, 30, None), (1000, 3, None), (256, 8, "overshoot"),
-                                      (256, 8, "not_resident"), (256, 8, "off"), (300, 20, "no_room")])
+                                      (256, 8, "not_resident"), (256, 8, "off"), (300, 20, "no_room"), (256, 8, "alloc_cruise"),
+                                      (256, 8, "alloc_ring")])
 def test_batched_cruise_on_the_tile_engine(n, b, hook, monkeypatch, capfd):
     """Above n = 128 a batched call first cruises on the tile engine: the B graphs as ONE block-diagonal lattice in one
     persistent launch (k_tile<..., BATCH>), stopped by the screen of the coupled rule (lambda_max of a Gram matrix lies in
@@ -129,7 +130,9 @@ def test_batched_cruise_on_the_tile_engine(n, b, hook, monkeypatch, capfd):
     oracle's 2-D branch for: the headline case; 80 node blocks in total and two groups of 16 graphs (256, 20); thirty graphs
     of three node blocks on eight CUs each; a large graph; a cruise whose result is
     discarded (the screen overshot: redone from the sessions' own state); workgroups that are not co-resident; the cruise
-    switched off; a batch the chip has no room for (300 nodes x 20 graphs: one graph needs 14 workgroups, has 12 CUs)."""
+    switched off; a batch the chip has no room for (300 nodes x 20 graphs: one graph needs 14 workgroups, has 12 CUs); a device
+    that has no memory for the B-fold stand-in session (the allocation fails, the batched launches serve the call
+    with a clean last-error word, nothing half-built stays cached) or for the ring of the deciding chunks."""
     monkeypatch.setenv("GRAPHLEARN_AMD_BATCH_DEBUG", "1")
     if hook == "overshoot":
         monkeypatch.setenv("GRAPHLEARN_AMD_BATCH_TEST_OVERSHOOT", "1")
@@ -137,6 +140,10 @@ def test_batched_cruise_on_the_tile_engine(n, b, hook, monkeypatch, capfd):
         monkeypatch.setenv("GRAPHLEARN_AMD_RES_TEST_NOT_RESIDENT", "1")
     if hook == "off":
         monkeypatch.setenv("GRAPHLEARN_AMD_BATCH_NO_CRUISE", "1")
+    if hook in ("alloc_cruise", "alloc_ring"):
+        from graph_learning_amd import _lib
+        _lib.default_context().trim()       # (no stand-in cached from an earlier test: the allocation is really asked for)
+        monkeypatch.setenv("GRAPHLEARN_AMD_TEST_ALLOC_FAIL", hook[len("alloc_"):])
     rng = default_rng(1000 * n + b)
     z = rng.uniform(0.1, 3.0, size=(b, n * (n - 1) // 2))
     maxit = 300 if n < 1000 else 120
@@ -144,8 +151,10 @@ def test_batched_cruise_on_the_tile_engine(n, b, hook, monkeypatch, capfd):
     out, got = gsp_learn_graph_log_degrees(z, 1.1, 0.9, maxit=maxit, tol=1e-4, edge_tol=-np.inf, return_info=True)
     err = capfd.readouterr().err
     cruised = [l for l in err.splitlines() if l.startswith("[batch cruise]")]
-    if hook in ("off", "no_room"):
+    if hook in ("off", "no_room", "alloc_cruise"):
         assert not cruised
+    elif hook == "alloc_ring":
+        assert len(cruised) == 1 and cruised[0].rstrip().endswith("kept 1") and "[batch ring]" not in err
     else:
         assert len(cruised) == 1 and f"n {n} B {b}:" in cruised[0]
         kept = cruised[0].rstrip().endswith("kept 1")
@@ -160,6 +169,12 @@ def test_batched_cruise_on_the_tile_engine(n, b, hook, monkeypatch, capfd):
     # a second call on the cached stand-in session: bit-identical
     out2 = gsp_learn_graph_log_degrees(z, 1.1, 0.9, maxit=maxit, tol=1e-4, edge_tol=-np.inf)
     assert np.array_equal(out, out2)
+    if hook == "alloc_cruise":   # with memory again the very next call cruises: the failed attempt left nothing behind
+        monkeypatch.delenv("GRAPHLEARN_AMD_TEST_ALLOC_FAIL")
+        capfd.readouterr()
+        out3 = gsp_learn_graph_log_degrees(z, 1.1, 0.9, maxit=maxit, tol=1e-4, edge_tol=-np.inf)
+        assert "[batch cruise]" in capfd.readouterr().err
+        np.testing.assert_allclose(out3, ref, rtol=0, atol=1e-10)
 
 
 @pytest.mark.parametrize("ring_k", ["2", "7", "32", "off"])

@@ -18,7 +18,29 @@ from oracle import lgmrf as olg
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["launch", "wave", "quad", "one", "resident", "tagged", "wide", "auto"])
+import os
+
+# The forms the library chooses by itself (wave / quad / tagged / wide) and the automatic choice run in every default
+# session.  The superseded forms -- one launch per step, the single-workgroup LDS form, the grid-barrier persistent form;
+# DESIGN.md section 5 -- run the whole matrix only with GRAPHLEARN_AMD_TEST_ALL=1; by default they keep ONE smoke case each
+# (test_superseded_admm_forms_smoke, below), so the suite's wall time stays inside the driver's step limit.
+ALL_FORMS = os.environ.get("GRAPHLEARN_AMD_TEST_ALL", "0") not in ("", "0")
+SUPERSEDED = ["launch", "one", "resident"]
+FORMS = ["wave", "quad", "tagged", "wide", "auto"] + (SUPERSEDED if ALL_FORMS else [])
+
+
+def set_form(monkeypatch, form):
+    monkeypatch.delenv("GRAPHLEARN_AMD_LGMRF_WIDE", raising=False)
+    if form == "auto":
+        monkeypatch.delenv("GRAPHLEARN_AMD_LGMRF_ADMM", raising=False)
+    elif form in ("tagged", "wide"):
+        monkeypatch.setenv("GRAPHLEARN_AMD_LGMRF_ADMM", "tagged")
+        monkeypatch.setenv("GRAPHLEARN_AMD_LGMRF_WIDE", "1" if form == "wide" else "0")
+    else:
+        monkeypatch.setenv("GRAPHLEARN_AMD_LGMRF_ADMM", form)
+
+
+@pytest.fixture(autouse=True, params=FORMS)
 def admm_form(request, monkeypatch):
     """Every test runs with every form of the QP's ADMM loop: one launch per step, the single-wave kernel
     (n <= 64, rows of the inverse in registers), the single-workgroup kernel with four lanes per row
@@ -27,15 +49,28 @@ def admm_form(request, monkeypatch):
     the right-hand side handed over as self-validating tagged records -- "tagged": up to 8 rows per workgroup,
     all in LDS; "wide": up to 16, half of them in registers) and the automatic choice (wave to n = 64, quad to
     n = 160, tagged above, wide from n = 256)."""
-    monkeypatch.delenv("GRAPHLEARN_AMD_LGMRF_WIDE", raising=False)
-    if request.param == "auto":
-        monkeypatch.delenv("GRAPHLEARN_AMD_LGMRF_ADMM", raising=False)
-    elif request.param in ("tagged", "wide"):
-        monkeypatch.setenv("GRAPHLEARN_AMD_LGMRF_ADMM", "tagged")
-        monkeypatch.setenv("GRAPHLEARN_AMD_LGMRF_WIDE", "1" if request.param == "wide" else "0")
-    else:
-        monkeypatch.setenv("GRAPHLEARN_AMD_LGMRF_ADMM", request.param)
+    set_form(monkeypatch, request.param)
     return request.param
+
+
+@pytest.mark.parametrize("form", SUPERSEDED)
+def test_superseded_admm_forms_smoke(golden, monkeypatch, admm_form, form):
+    """One golden fit (n = 32, fast and general path) and one golden QP on each superseded form of the ADMM loop: they stay
+    selectable (GRAPHLEARN_AMD_LGMRF_ADMM) as comparison points, so they stay correct."""
+    if admm_form != "auto":
+        pytest.skip("once per session")
+    set_form(monkeypatch, form)
+    g = golden("lgmrf")
+    for path in (1, 2):
+        m = LGMRF(norm_par=1, regularization_type=1).fit(g["cov_32"].copy(), path=path)
+        assert m.converged_ == int(g["conv_32_np1_rt1"])
+        assert close(m.laplacian_, g["lapl_32_np1_rt1"]) and close(m.inv_laplacian_, g["inv_32_np1_rt1"])
+    q, p = g["qp_a_Q"], g["qp_a_p"]
+    tol, mi = float(g["qp_a_tol"]), int(g["qp_a_maxit"])
+    z, iters = nonnegative_qp_solver(q, p, step=0.1, tol=tol, max_iter=mi, return_iters=True)
+    _, ref_iters = olg.nonneg_qp_admm(q, p, step=0.1, tol=tol, max_iter=mi, return_iters=True)
+    assert abs(iters - ref_iters) <= 1
+    np.testing.assert_allclose(z, g["qp_a_z"], rtol=0, atol=1e-7 if iters != ref_iters else 1e-11)
 
 
 def close(a, b, rel=1e-6):
@@ -276,8 +311,8 @@ def test_lgmrf_c3_shape_n1024_blow_up_matches_reference(golden, admm_form):
     Frobenius norm and maximum.  This is the evidence for DESIGN.md section 5 ("C3 as specified is ill-posed").
     Tolerance: the fixture (ONE BLAS thread) records that the reference's own Theta moves by 9.7e-7 of max|Theta| and
     its inverse by 1.7e-6 of max|C| when only the thread count changes to 8 (n1024_thread_sensitivity); the device
-    path is held to 20 x those figures (2e-5 / 3.5e-5), relative to the same maxima (the sampled rows hold the
-    largest entries of both matrices)."""
+    path is held to 20 x those figures (2e-5 / 3.5e-5), relative to the REFERENCE's maxima (max|Theta| and max|C| both
+    sit on the diagonals the fixture stores); the observed errors are printed (DESIGN.md section 5 records them)."""
     if admm_form != "auto":
         pytest.skip("once, on the default form")
     g = golden("lgmrf_c3")
@@ -293,14 +328,17 @@ def test_lgmrf_c3_shape_n1024_blow_up_matches_reference(golden, admm_form):
     rows = g["n1024_rows"]
     e_rows = np.abs(m.laplacian_[rows] - g["n1024_lapl_rows"]).max() / scale
     e_diag = np.abs(np.diag(m.laplacian_) - g["n1024_lapl_diag"]).max() / scale
-    inv_scale = np.abs(m.inv_laplacian_).max()
+    # (normalised by REFERENCE quantities only: C is positive definite, so max|C| sits on its diagonal -- the fixture's)
+    inv_scale = np.abs(g["n1024_inv_diag"]).max()
+    assert inv_scale == pytest.approx(72801073.87114467, rel=1e-12)
     e_inv = np.abs(m.inv_laplacian_[rows] - g["n1024_inv_rows"]).max() / inv_scale
+    e_inv_diag = np.abs(np.diag(m.inv_laplacian_) - g["n1024_inv_diag"]).max() / inv_scale
     print(f"[lgmrf c3 n=1024] Theta rows {e_rows:.2e} diag {e_diag:.2e} (of max|Theta| = {scale:.6g}; reference 1 vs 8 threads "
-          f"{s_th:.1e}); C rows {e_inv:.2e} (of max|C| = {inv_scale:.4g}; reference {s_inv:.1e})")
+          f"{s_th:.1e}); C rows {e_inv:.2e} diag {e_inv_diag:.2e} (of the reference's max|C| = {inv_scale:.4g}; reference {s_inv:.1e})")
     assert e_rows < tol_th and e_diag < tol_th     # 1.5e4-fold growth in one cycle: rounding is amplified accordingly
     assert np.abs(m.laplacian_).max() == pytest.approx(scale, rel=tol_th)
     assert np.linalg.norm(m.laplacian_) == pytest.approx(float(g["n1024_lapl_fro"]), rel=tol_th)
-    assert e_inv < tol_inv
+    assert e_inv < tol_inv and e_inv_diag < tol_inv
 
 
 def test_lgmrf_c3_full_size_one_cycle_properties(admm_form):

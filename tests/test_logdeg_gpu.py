@@ -12,6 +12,8 @@ The contract checked is SURVEY.md section 7 "Parity definition":
   (iii) converge mode stops within +-1 iteration of the oracle.
 """
 
+import os
+
 import numpy as np
 import pytest
 from scipy.spatial.distance import squareform
@@ -27,16 +29,49 @@ ATOL = 1e-10
 CASES = ["logmodel_n7_d23", "logmodel_n16_d40", "logmodel_n64_d256"]
 
 
-@pytest.fixture(autouse=True, params=["stream", "resident", "resident1", "small"])
+# The engines the library chooses by itself run the whole file in every default session; round 1's grid-barrier engine
+# (gl_resident.hip, superseded by the tile engine everywhere: DESIGN.md section 3a') runs it only with
+# GRAPHLEARN_AMD_TEST_ALL=1 and keeps one smoke test by default (test_round1_resident_engine_smoke), so that the
+# suite's wall time stays inside the driver's step limit.
+ALL_ENGINES = os.environ.get("GRAPHLEARN_AMD_TEST_ALL", "0") not in ("", "0")
+ENGINES = ["stream", "resident", "small"] + (["resident1"] if ALL_ENGINES else [])
+
+
+@pytest.fixture(autouse=True, params=ENGINES)
 def engine(request, monkeypatch):
     """Every test of this file runs on every iteration engine: streaming (one edge-pass + one node-pass launch
     per iteration), the resident family forced -- "resident": the tile engine (gl_tile.hip: iterate in registers,
     z in LDS, tagged hand-offs) wherever its work decomposition applies, else the first resident engine;
-    "resident1": the first resident engine (gl_resident.hip: grid barriers); by default the family is only
-    chosen for n > 2240 -- and small (n <= 128: one workgroup, one launch per call; where it does not apply the
-    automatic choice takes over)."""
+    "resident1" (opt-in, see above): the first resident engine (gl_resident.hip: grid barriers) -- and small
+    (n <= 128: one workgroup, one launch per call; where it does not apply the automatic choice takes over, so the
+    tests of larger lattices skip it: they would repeat the "resident" run)."""
     monkeypatch.setenv("GRAPHLEARN_AMD_ENGINE", request.param)
     return request.param
+
+
+def skip_small_above_128(engine):
+    if engine == "small":
+        pytest.skip("n > 128: the small engine does not apply and the automatic choice repeats the tile engine's run")
+
+
+_C2 = {}
+
+
+def c2_reference():
+    """The n = 4096, d = 1024 problem of BASELINE configs[1] and the oracle's iterates after 5 and 40 iterations --
+    computed ONCE per session (the oracle needs ~25 s for the operators, distances and 40 iterations)."""
+    if not _C2:
+        x, _ = logmodel_problem(4096, 1024, seed=1)
+        z_ref = old.signal_distances(x)
+        theta_ref = old.theta_for_degree(squareform(z_ref), 10)
+        solver = old.FBFSolver(z_ref * theta_ref, 1, 1)
+        snaps = {}
+        for k in range(1, 41):
+            rel = solver.step()
+            if k in (5, 40):
+                snaps[k] = (solver.w.copy(), solver.d.copy(), rel)
+        _C2.update(x=x, z=z_ref, theta=theta_ref, zt=z_ref * theta_ref, snaps=snaps)
+    return _C2
 
 
 def raw_iterate(z, alpha, beta, k, step_size=0.5, edge_init=None):
@@ -190,25 +225,25 @@ def test_sklearn_surface():
 
 
 # ------------------------------------------------------------------ BASELINE sizes
-def test_c2_size_five_iterations_against_oracle():
+def test_c2_size_five_iterations_against_oracle(engine):
     """n=4096, d=1024 (BASELINE config 2): distances, theta and 5 iterations vs the oracle."""
-    x, _ = logmodel_problem(4096, 1024, seed=0)
-    z_ref = old.signal_distances(x)
-    theta_ref = old.theta_for_degree(squareform(z_ref), 10)
+    skip_small_above_128(engine)
+    ref = c2_reference()
+    z_ref, theta_ref = ref["z"], ref["theta"]
     with _lib.LogDegreeSession(4096) as s:
-        theta = s.set_signals(x, 10)
+        theta = s.set_signals(ref["x"], 10)
         z = s.get_distances()
         np.testing.assert_allclose(z, z_ref, rtol=1e-10, atol=1e-12 * z_ref.max())
         assert theta == pytest.approx(theta_ref, rel=1e-10)
         # iterate on the oracle's own z*theta so that both sides see identical inputs
-        s.set_distances(z_ref * theta_ref)
+        s.set_distances(ref["zt"])
         s.init(1, 1, 0.5, None)
         s.iterate(5, 0.0)
         w = s.weights_condensed()
         d = s.dual()
-    _, info = old.learn_log_degrees(z_ref * theta_ref, 1, 1, maxit=5, tol=0.0, edge_tol=-np.inf, return_info=True)
-    np.testing.assert_allclose(w, info["raw"], rtol=0, atol=ATOL)
-    np.testing.assert_allclose(d, info["dual"], rtol=0, atol=ATOL)
+    w5, d5, _ = ref["snaps"][5]
+    np.testing.assert_allclose(w, w5, rtol=0, atol=ATOL)
+    np.testing.assert_allclose(d, d5, rtol=0, atol=ATOL)
 
 
 def test_c2_size_persistent_engine_against_oracle(engine):
@@ -217,13 +252,12 @@ def test_c2_size_persistent_engine_against_oracle(engine):
     second starts from an odd iteration count), w and the dual variable to 1e-10."""
     if engine == "stream":
         pytest.skip("the streaming engine at this size is covered by the five-iteration test")
-    x, _ = logmodel_problem(4096, 1024, seed=1)
-    z_ref = old.signal_distances(x)
-    zt = z_ref * old.theta_for_degree(squareform(z_ref), 10)
+    skip_small_above_128(engine)
+    ref = c2_reference()
     with _lib.LogDegreeSession(4096) as s:
-        s.set_distances(zt)
+        s.set_distances(ref["zt"])
         s.init(1, 1, 0.5, None)
-        assert s.engine == "resident"          # forced, and the automatic choice ("small" does not apply)
+        assert s.engine == "resident"          # forced
         assert s.engine_kernel == ("k_resident" if engine == "resident1" else "k_tile")
         n_it, conv, rel17 = s.iterate(17, 0.0)
         assert n_it == 17 and not conv and s.engine == "resident"
@@ -231,16 +265,17 @@ def test_c2_size_persistent_engine_against_oracle(engine):
         assert n_it == 23 and not conv and s.total_iterations == 40
         w = s.weights_condensed()
         d = s.dual()
-    _, info = old.learn_log_degrees(zt, 1, 1, maxit=40, tol=0.0, edge_tol=-np.inf, return_info=True)
-    np.testing.assert_allclose(w, info["raw"], rtol=0, atol=ATOL)
-    np.testing.assert_allclose(d, info["dual"], rtol=0, atol=ATOL)
-    assert rel[0] == pytest.approx(info["rel"][0], rel=1e-9)
-    assert rel[1] == pytest.approx(info["rel"][1], rel=1e-9)
+    w40, d40, rel40 = ref["snaps"][40]
+    np.testing.assert_allclose(w, w40, rtol=0, atol=ATOL)
+    np.testing.assert_allclose(d, d40, rtol=0, atol=ATOL)
+    assert rel[0] == pytest.approx(rel40[0], rel=1e-9)
+    assert rel[1] == pytest.approx(rel40[1], rel=1e-9)
 
 
-def test_c2_size_properties_after_many_iterations():
+def test_c2_size_properties_after_many_iterations(engine):
     """Size-independent properties at n=4096 after 300 iterations: determinism, dual = prox
     fixed-point structure (dvar < 0), symmetry of the square output, degree identity."""
+    skip_small_above_128(engine)
     x, _ = logmodel_problem(4096, 256, seed=3)
     outs = []
     for _ in range(2):
@@ -489,16 +524,14 @@ def test_large_lattice_n8192_against_dense_restatement(engine):
 
 # ------------------------------------------------------------------ the instantiations bench.py times
 def test_c2_size_timed_instantiation_against_oracle(engine):
-    """bench.py times gl_logdeg_iterate_async -> k_tile<32, false, false, 0> (the variant WITHOUT the norms of the
+    """bench.py times gl_logdeg_iterate_async -> k_tile<32, true, false, 0> (the variant WITHOUT the norms of the
     stopping rule) at n=4096, d=1024; the driver runs it as `--steps 20`.  Exactly that: two asynchronous calls of 20
     iterations against 40 iterations of the oracle (smooth_learning.py:146-167), w and the dual variable to 1e-10."""
     if engine != "resident":
         pytest.skip("the tile engine's asynchronous variant")
-    x, _ = logmodel_problem(4096, 1024, seed=2)
-    z_ref = old.signal_distances(x)
-    zt = z_ref * old.theta_for_degree(squareform(z_ref), 10)
+    ref = c2_reference()
     with _lib.LogDegreeSession(4096) as s:
-        s.set_distances(zt)
+        s.set_distances(ref["zt"])
         s.init(1, 1, 0.5, None)
         assert s.engine == "resident" and s.engine_kernel == "k_tile"
         s.iterate_async(20)
@@ -507,9 +540,9 @@ def test_c2_size_timed_instantiation_against_oracle(engine):
         w = s.weights_condensed()
         d = s.dual()
         assert s.engine == "resident"          # no fall-back happened: the tile engine produced these
-    _, info = old.learn_log_degrees(zt, 1, 1, maxit=40, tol=0.0, edge_tol=-np.inf, return_info=True)
-    np.testing.assert_allclose(w, info["raw"], rtol=0, atol=ATOL)
-    np.testing.assert_allclose(d, info["dual"], rtol=0, atol=ATOL)
+    w40, d40, _ = ref["snaps"][40]
+    np.testing.assert_allclose(w, w40, rtol=0, atol=ATOL)
+    np.testing.assert_allclose(d, d40, rtol=0, atol=ATOL)
 
 
 @pytest.mark.parametrize("n,iters", [(4096, 2000), (8192, 48), (3000, 301), (2048, 500), (1030, 333)])
@@ -584,3 +617,168 @@ def test_rule_that_fires_at_the_head_of_a_call_fires_at_the_same_iteration_on_ev
     assert res["stream"][:2] == (2, True)
     assert res[engine][:2] == (2, True)
     np.testing.assert_allclose(res[engine][2], res["stream"][2], rtol=0, atol=1e-12)
+
+
+# ------------------------------------------------------------------ round 4: converge mode at mid sizes, against the ORACLE
+def oracle_trajectory(zt, iters, edge_init=None, snaps=()):
+    """The oracle's ratios after every iteration (smooth_learning.py:156-161) and its state after the iterations in `snaps`
+    (number of iterations done)."""
+    solver = old.FBFSolver(zt, 1, 1, edge_init=None if edge_init is None else edge_init.copy())
+    rel, states = [], {}
+    for k in range(1, iters + 1):
+        rel.append(solver.step())
+        if k in snaps:
+            states[k] = (solver.w.copy(), solver.d.copy())
+    return rel, states, solver
+
+
+def pick_stopping_iteration(rel, lo, hi):
+    """An iteration index K (0-based, lo <= K < hi) and a tol such that the reference's rule (:166-167) fires at K and
+    nowhere before: max(ratios) of K is below that of EVERY earlier iteration (iteration 0 is never judged), and tol is the
+    geometric mean of the two -- late in a run the ratios fall by 1/k per iteration, so the gap is small, but the engines
+    reproduce the ratios to ~1e-9."""
+    m = [max(a, b) for a, b in rel]
+    for K in range(lo, hi):
+        before = min(m[1:K])
+        if before > m[K] * (1 + 1e-5):
+            return K, float(np.sqrt(before * m[K]))
+    raise AssertionError("no usable stopping iteration in the window")
+
+
+@pytest.mark.parametrize("n,iters", [(1200, 260), (2600, 150), (3500, 60)])
+def test_converge_mode_at_mid_sizes_stops_where_the_oracle_stops(engine, n, iters):
+    """VERDICT r03 'missing 2': converge mode on the TILE engine against the oracle's own stopping iteration beyond the
+    golden sizes -- n = 1200 (chunks of 8 row pairs), n = 2600 (16) and n = 3500 (32, ragged) on smooth signals, tol set so
+    that the reference's rule (smooth_learning.py:156-167) fires after a few hundred / a hundred / some tens of iterations:
+    the same stopping iteration, the iterate and the dual variable of THAT iteration to 1e-10, the same ratios."""
+    if engine != "resident":
+        pytest.skip("the tile engine; the streaming engine's rule is checked at the golden sizes and against it at n = 5000 / 9300")
+    x, _ = logmodel_problem(n, 256, seed=n)
+    z = old.signal_distances(x)
+    zt = z * old.theta_for_degree(squareform(z), 10)
+    rel, _, _ = oracle_trajectory(zt, iters)
+    K, tol = pick_stopping_iteration(rel, (2 * iters) // 3, iters)
+    _, states, _ = oracle_trajectory(zt, K + 1, snaps=(K + 1,))
+    with _lib.LogDegreeSession(n) as s:
+        s.set_distances(zt)
+        s.init(1, 1, 0.5, None)
+        assert s.engine_kernel == "k_tile"
+        n_it, conv, r = s.iterate(100000, tol)
+        w, d = s.weights_condensed(), s.dual()
+        assert s.engine == "resident"
+    print(f"[converge n={n}] the oracle stops after {K + 1} iterations at tol {tol:.3e}; the tile engine after {n_it}")
+    assert conv and n_it == K + 1
+    np.testing.assert_allclose(w, states[K + 1][0], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(d, states[K + 1][1], rtol=0, atol=ATOL)
+    assert r[0] == pytest.approx(rel[K][0], rel=1e-8) and r[1] == pytest.approx(rel[K][1], rel=1e-8)
+
+
+@pytest.mark.parametrize("n", [700, 1200])
+def test_warm_start_that_converges_early_in_a_second_call(engine, n):
+    """VERDICT r03 'weak 2': the tile engine looks at the rule with a lag of one iteration while the ratios are far from tol,
+    except during the first iterations of a call.  A warm start (edge_init = an almost converged iterate, the dual variable
+    restarted from S w: smooth_learning.py:140-144) makes the ratios fall steeply; the first call runs 4 fixed iterations,
+    the SECOND call runs to a tol that the oracle meets a few iterations into it: same stopping iteration as the oracle,
+    iterate to 1e-10 -- on every engine."""
+    if engine == "small":
+        pytest.skip("n > 128")
+    x, _ = logmodel_problem(n, 256, seed=3 * n)
+    z = old.signal_distances(x)
+    zt = z * old.theta_for_degree(squareform(z), 10)
+    _, st, _ = oracle_trajectory(zt, 150, snaps=(150,))
+    warm = st[150][0]
+    warm[warm < 1e-4] = 0.0
+    rel, _, _ = oracle_trajectory(zt, 40, edge_init=warm)
+    K, tol = pick_stopping_iteration(rel, 4 + 3, 4 + 12)      # inside the second call, beyond its exactly judged head
+    _, states, _ = oracle_trajectory(zt, K + 1, edge_init=warm, snaps=(K + 1,))
+    with _lib.LogDegreeSession(n) as s:
+        s.set_distances(zt)
+        s.init(1, 1, 0.5, warm)
+        s.iterate(4, 0.0)
+        n_it, conv, r = s.iterate(1000, tol)
+        w, d = s.weights_condensed(), s.dual()
+    print(f"[warm start n={n}] ratios of the oracle around the stop: {[f'{max(a, b):.3e}' for a, b in rel[K - 2:K + 1]]}; "
+          f"stops {K + 1 - 4} iterations into the second call; engine {engine}: {n_it}")
+    assert conv and n_it == K + 1 - 4
+    np.testing.assert_allclose(w, states[K + 1][0], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(d, states[K + 1][1], rtol=0, atol=ATOL)
+
+
+def test_round1_resident_engine_smoke(golden, engine, monkeypatch):
+    """Round 1's grid-barrier engine (gl_resident.hip) stays selectable as the comparison point (GRAPHLEARN_AMD_ENGINE=resident1;
+    the whole file runs on it with GRAPHLEARN_AMD_TEST_ALL=1): one golden case (fixed iterations, converge mode) and 60
+    iterations at n = 2600 against the streaming engine in every default session."""
+    if engine != "resident":
+        pytest.skip("once per session")
+    monkeypatch.setenv("GRAPHLEARN_AMD_ENGINE", "resident1")
+    g = golden("logmodel_n64_d256")
+    zt = g["z"] * float(g["theta_deg6"])
+    with _lib.LogDegreeSession(64) as s:
+        s.set_distances(zt)
+        s.init(1, 1, 0.5, None)
+        assert s.engine == "resident" and s.engine_kernel == "k_resident"
+        s.iterate(50, 0.0)
+        np.testing.assert_allclose(s.weights_condensed(), g["raw_w_it50"], rtol=0, atol=ATOL)
+    w, info = gsp_learn_graph_log_degrees(zt, 1, 1, maxit=20000, tol=1e-5, edge_tol=-np.inf, return_info=True)
+    assert info["converged"] and info["n_iter"] == int(g["n_iter_converged"])
+    np.testing.assert_allclose(squareform(w, checks=False), g["raw_w_converged"], rtol=0, atol=ATOL)
+    n = 2600
+    z = np.random.default_rng(n).uniform(0.05, 3.0, size=n * (n - 1) // 2)
+    out = {}
+    for eng in ("stream", "resident1"):
+        monkeypatch.setenv("GRAPHLEARN_AMD_ENGINE", eng)
+        with _lib.LogDegreeSession(n) as s:
+            s.set_distances(z)
+            s.init(1.2, 0.8, 0.5, None)
+            assert s.engine_kernel == ("k_edge" if eng == "stream" else "k_resident")
+            s.iterate(60, 0.0)
+            out[eng] = (s.weights_condensed(), s.dual())
+    np.testing.assert_allclose(out["resident1"][0], out["stream"][0], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(out["resident1"][1], out["stream"][1], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("n,iters", [(300, 1500), (1000, 700)])
+def test_long_converge_calls_run_through_the_dual_gate(engine, monkeypatch, capfd, n, iters):
+    """Round 4: a long converge-mode call on the tile engine runs in three launches -- a head with the norms, a middle WITHOUT
+    the primal norms that only watches the dual ratio (the rule needs both ratios below tol, smooth_learning.py:166-167, and the
+    dual one holds it up for most of a run), a tail with the norms that judges every iteration.  Against the oracle: the same
+    stopping iteration, the same iterate (1e-10) and ratios; and against the same call with the gate switched off: EQUAL
+    iterates (the variants share the iterate's arithmetic)."""
+    if engine != "resident":
+        pytest.skip("the tile engine")
+    x, _ = logmodel_problem(n, 256, seed=7 * n)
+    z = old.signal_distances(x)
+    zt = z * old.theta_for_degree(squareform(z), 6 if n < 1000 else 10)
+    rel, states, _ = oracle_trajectory(zt, iters, snaps=(iters,))
+    try:
+        K, tol = pick_stopping_iteration(rel, iters - 1, iters)  # the last iteration, if the ratios are at their minimum there
+    except AssertionError:                                       # else an earlier one, at the price of a second run
+        K, tol = pick_stopping_iteration(rel, (2 * iters) // 3, iters)
+        _, states, _ = oracle_trajectory(zt, K + 1, snaps=(K + 1,))
+    assert rel[16][1] > 2 * tol                                   # the dual ratio is well above tol after the head: the gate opens
+    out = {}
+    for gate in ("1", "0"):
+        monkeypatch.setenv("GRAPHLEARN_AMD_TILE_GATE", gate)
+        monkeypatch.setenv("GRAPHLEARN_AMD_TILE_DEBUG", "1")
+        with _lib.LogDegreeSession(n) as s:
+            s.set_distances(zt)
+            s.init(1, 1, 0.5, None)
+            assert s.engine_kernel == "k_tile"
+            n_it, conv, r = s.iterate(100000, tol)
+            out[gate] = (n_it, conv, r, s.weights_condensed(), s.dual())
+            assert s.engine == "resident"
+        err = capfd.readouterr().err
+        lines = [l for l in err.splitlines() if l.startswith("[tile gate]")]
+        if gate == "1":
+            assert len(lines) == 1 and "3 launches" in lines[0], err[-300:]
+        else:
+            assert not lines
+    n_it, conv, r, w, d = out["1"]
+    gated_to = next((k for k in range(17, K) if rel[k][1] < 1.25 * tol), K)
+    print(f"[dual gate n={n}] the oracle stops after {K + 1} iterations (tol {tol:.3e}); the dual ratio is above 1.25 tol until iteration {gated_to}; "
+          f"the tile engine: {n_it} with the gate, {out['0'][0]} without")
+    assert conv and n_it == K + 1 and out["0"][0] == K + 1
+    np.testing.assert_allclose(w, states[K + 1][0], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(d, states[K + 1][1], rtol=0, atol=ATOL)
+    assert r[0] == pytest.approx(rel[K][0], rel=1e-8) and r[1] == pytest.approx(rel[K][1], rel=1e-8)
+    assert np.array_equal(w, out["0"][3]) and np.array_equal(d, out["0"][4])

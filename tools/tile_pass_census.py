@@ -1,6 +1,6 @@
 """Instruction census of the tile engine's pass, from the assembly hipcc wrote for the shipped build flags.
 
-usage: python tools/tile_pass_census.py [--kernel ILi32ELb1ELb0ELi0E] [--out profiles/r03_tile_census.json]
+usage: python tools/tile_pass_census.py [--kernel ILi32ELb1ELb0ELi0E] [--out profiles/r04_tile_census.json]
 
 Compiles graph_learning_amd/csrc/gl_tile.hip with the Makefile's flags plus -save-temps (tools/build_tile.sh), takes the
 kernel bench.py times (k_tile<32, true, false, 0, false>: U = 32, no norms), and counts the instructions of the basic blocks that
@@ -13,7 +13,7 @@ import argparse, hashlib, json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ap = argparse.ArgumentParser()
 ap.add_argument("--kernel", default="ILi32ELb1ELb0ELi0E")
-ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_tile_census.json"))
+ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_tile_census.json"))
 ap.add_argument("--no-build", action="store_true")
 a = ap.parse_args()
 if not a.no_build:
@@ -28,7 +28,7 @@ for l in body:
         blocks.append(cur); cur = []
     cur.append(l)
 blocks.append(cur)
-CLASSES = [("valu_f64", r"^v_(add|mul|fma|fmac|max|min)_f64"), ("valu_other", r"^v_"), ("lds", r"^ds_"),
+CLASSES = [("valu_f64_fma", r"^v_(fma|fmac)_f64"), ("valu_f64_other", r"^v_(add|mul|max|min)_f64"), ("valu_other", r"^v_"), ("lds", r"^ds_"),
            ("vmem", r"^(global_|buffer_|scratch_)"), ("wait", r"^s_(waitcnt|nop)"), ("salu", r"^s_")]
 def census(lines):
     c = {k: 0 for k, _ in CLASSES}
@@ -59,6 +59,8 @@ tot = {}
 for b in pass_blocks:
     for k, v in census(b).items():
         tot[k] = tot.get(k, 0) + v
+tot["valu_f64"] = tot["valu_f64_fma"] + tot["valu_f64_other"]      # fp64 vector instructions (issue slots of the fp64 pipe)
+tot["flop_f64"] = 2 * tot["valu_f64_fma"] + tot["valu_f64_other"]  # real flops per lane: a fused multiply-add is 2, add / mul / max 1
 nmax = sum(sum("v_max_f64" in l for l in b) for b in pass_blocks)
 assert nmax == 64, f"expected the 64 v_max_f64 of one pass (32 row pairs x 2 edges per lane), found {nmax}"
 src = open(os.path.join(ROOT, "graph_learning_amd", "csrc", "gl_tile.hip"), "rb").read()
