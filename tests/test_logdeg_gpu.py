@@ -620,10 +620,17 @@ def test_rule_that_fires_at_the_head_of_a_call_fires_at_the_same_iteration_on_ev
 
 
 # ------------------------------------------------------------------ round 4: converge mode at mid sizes, against the ORACLE
+_OPS = {}
+
+
 def oracle_trajectory(zt, iters, edge_init=None, snaps=()):
     """The oracle's ratios after every iteration (smooth_learning.py:156-161) and its state after the iterations in `snaps`
     (number of iterations done)."""
-    solver = old.FBFSolver(zt, 1, 1, edge_init=None if edge_init is None else edge_init.copy())
+    n = old.n_nodes_from_edges(zt.size)
+    if n not in _OPS:
+        _OPS.clear()                  # (one size at a time: the operators of n = 3500 take 200 MB)
+        _OPS[n] = old.degree_operator(n)
+    solver = old.FBFSolver(zt, 1, 1, edge_init=None if edge_init is None else edge_init.copy(), ops=_OPS[n])
     rel, states = [], {}
     for k in range(1, iters + 1):
         rel.append(solver.step())
@@ -645,20 +652,23 @@ def pick_stopping_iteration(rel, lo, hi):
     raise AssertionError("no usable stopping iteration in the window")
 
 
-@pytest.mark.parametrize("n,iters", [(1200, 260), (2600, 150), (3500, 60)])
+@pytest.mark.parametrize("n,iters", [(1200, 200), (2600, 80), (3500, 36)])
 def test_converge_mode_at_mid_sizes_stops_where_the_oracle_stops(engine, n, iters):
     """VERDICT r03 'missing 2': converge mode on the TILE engine against the oracle's own stopping iteration beyond the
     golden sizes -- n = 1200 (chunks of 8 row pairs), n = 2600 (16) and n = 3500 (32, ragged) on smooth signals, tol set so
-    that the reference's rule (smooth_learning.py:156-167) fires after a few hundred / a hundred / some tens of iterations:
+    that the reference's rule (smooth_learning.py:156-167) fires after some two hundred / eighty / thirty iterations:
     the same stopping iteration, the iterate and the dual variable of THAT iteration to 1e-10, the same ratios."""
     if engine != "resident":
         pytest.skip("the tile engine; the streaming engine's rule is checked at the golden sizes and against it at n = 5000 / 9300")
     x, _ = logmodel_problem(n, 256, seed=n)
     z = old.signal_distances(x)
     zt = z * old.theta_for_degree(squareform(z), 10)
-    rel, _, _ = oracle_trajectory(zt, iters)
-    K, tol = pick_stopping_iteration(rel, (2 * iters) // 3, iters)
-    _, states, _ = oracle_trajectory(zt, K + 1, snaps=(K + 1,))
+    rel, states, _ = oracle_trajectory(zt, iters, snaps=(iters,))
+    try:
+        K, tol = pick_stopping_iteration(rel, iters - 1, iters)  # the last iteration, if the ratios are at their minimum there
+    except AssertionError:                                       # else an earlier one, at the price of a second run
+        K, tol = pick_stopping_iteration(rel, (2 * iters) // 3, iters)
+        _, states, _ = oracle_trajectory(zt, K + 1, snaps=(K + 1,))
     with _lib.LogDegreeSession(n) as s:
         s.set_distances(zt)
         s.init(1, 1, 0.5, None)
