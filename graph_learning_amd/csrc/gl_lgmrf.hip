@@ -113,6 +113,8 @@ struct LgDev {
     double *part;                         // ADMM norm partials [2][nblk][6]
     double *act;                          // 1.0 where the entry takes part in the QP of node u
     double *beta, *t, *a, *h, *gcol;      // post-QP vectors (n)
+    double *gcol_next;                    // fused node update (round 4): column u + 1 of the UPDATED G, written by k_lg_update_g2
+    const double *KT;                     // ... and K transposed (column u of K as a contiguous row); null: k_lg_qp_setup sets the QP up
     double *scal;                         // scalars: [0] done, [1] qp iterations, [2..] scratch
     int64_t n;
     double rho, qp_tol;
@@ -615,50 +617,50 @@ __global__ __launch_bounds__(NT) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u
     double x1 = 0, z1 = 0, u1 = 0, x2g = 0, z2g = 0, u2g = 0;  // the state one / two steps earlier
     if (tid < nrows) {
         const int64_t i = r0 + tid;
-        xo = D.x[i];
-        zo = D.z[i];
-        uo = D.uu[i];
-        pi = D.p[i];
-        on = D.act[i];
-        if (!((test_missing & 1) && blockIdx.x == 0)) publish(0, i, D.v[i], tag0);  // the input of step 0
+        double v0;
+        if (D.KT != nullptr && u_fast >= 0) {
+            // the QP's set-up (k_lg_qp_setup: lgmrf.py:177-202,55) for my rows, here: active set = everybody but u (full mask),
+            // p = k_u / k_uu from the transposed K (column u as a contiguous row), x = z = u = 0, v = rho p
+            on = (i != u_fast) ? 1.0 : 0.0;
+            pi = on != 0.0 ? D.KT[u_fast * n + i] / D.K[u_fast * n + u_fast] : 0.0;
+            v0 = on != 0.0 ? (0.0 - 0.0) + D.rho * pi : 0.0;
+        } else {
+            xo = D.x[i];
+            zo = D.z[i];
+            uo = D.uu[i];
+            pi = D.p[i];
+            on = D.act[i];
+            v0 = D.v[i];
+        }
+        if (!((test_missing & 1) && blockIdx.x == 0)) publish(0, i, v0, tag0);  // the input of step 0
     }
     lg_u4 pr[4][3];  // wave 0: the partials {dx2, x2 | xm, dz2 | z2, zm} of workgroups lane, lane + 64, ...
     bool pending = false;
     int steps = 0;
     bool stopped = false, failed = false;
     for (int it = 0; it <= max_iter + 1; ++it) {
-        // (1) my columns of v: thread t takes columns t, t + 256, ...; re-read until every record carries this step's tag
+        // (1) my columns of v: thread t takes columns t, t + NT, ...  All of a thread's records are requested at once; they are
+        // then taken IN ORDER, each re-read alone until it carries this step's tag, and multiplied into the rows at once:
+        // the products of the columns that are there run underneath the wait for the ones that are not (before round 4 the
+        // whole sweep was repeated until every tag matched and the multiply -- 0.6 us of a 4.2 us step at n = 2048 --
+        // started after the last one).  Every row sum keeps its order of summation (columns ascending): bit-identical.
         const unsigned tag = tag0 + (unsigned)it;
-        double vj[CPT];
-        if (it <= max_iter) {
-            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-            bool good = true;
-            for (unsigned spins = 0;; ++spins) {
-                bool ok = true;
+        double acc[RLDS], acr[RREG > 0 ? RREG : 1];
 #pragma unroll
-                for (int c = 0; c < CPT; ++c) {
-                    const int64_t j = tid + NT * (int64_t)c;
-                    lg_u4 g = {0u, tag, 0u, tag};
-                    if (j < n) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((((it & 1) * n) + j) * 16), 0, 16);
-                    ok = ok && g.y == tag && g.w == tag;
-                    vj[c] = lg_pack(g.x, g.z);
-                }
-                asm volatile("" ::: "memory");  // the loads stay in the loop
-                if (__all(ok)) break;
-                // ~0.1 us: leave the fabric to the stores we wait for (development: GRAPHLEARN_AMD_LGMRF_POLL = 1 / 2 / 3)
-                const int pm = test_missing >> 1;
-                if (pm == 0) __builtin_amdgcn_s_sleep(4);
-                else if (pm == 1) __builtin_amdgcn_s_sleep(1);
-                else if (pm == 3) __builtin_amdgcn_s_sleep(12);
-                if ((spins & 63u) == 63u &&
-                    (gl_ld_u32(err) != 0u || __builtin_amdgcn_s_memrealtime() - t_start > 100000000ull)) {
-                    good = false;  // 1 s: a producer is not on the chip
-                    break;
-                }
+        for (int r = 0; r < RLDS; ++r) acc[r] = 0.0;
+#pragma unroll
+        for (int r = 0; r < (RREG > 0 ? RREG : 1); ++r) acr[r] = 0.0;
+        lg_u4 gq[CPT];
+        if (it <= max_iter) {
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                const int64_t j = tid + NT * (int64_t)c;
+                gq[c] = lg_u4{0u, tag, 0u, tag};
+                if (j < n) gq[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((((it & 1) * n) + j) * 16), 0, 16);
             }
-            if (!good) s_fail = 1;
         }
-        // (2) the rule of step it-3 from the partials requested one step ago (all arrived by now)
+        // (2) the rule of step it-3 from the partials requested one step ago -- wave 0, while the records above are on their
+        // way (in front of the multiply it held the whole workgroup up at the barrier below)
         if (wave == 0) {
             int stop = 0;
             if (pending) {
@@ -683,34 +685,53 @@ __global__ __launch_bounds__(NT) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u
             }
             if (lane == 0) s_stop[it & 1] = stop;
         }
-        // (3) my rows times v
-        if (it < max_iter) {
-            double acc[RLDS];
-#pragma unroll
-            for (int r = 0; r < RLDS; ++r) acc[r] = 0.0;
+        if (it <= max_iter) {
+            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+            bool good = true;
+            unsigned spins = 0;
 #pragma unroll
             for (int c = 0; c < CPT; ++c) {
                 const int64_t j = tid + NT * (int64_t)c;
-                if (j < n) {
+                for (;;) {
+                    const bool ok = gq[c].y == tag && gq[c].w == tag;
+                    if (__all(ok)) break;
+                    // ~0.1 us: leave the fabric to the stores we wait for (development: GRAPHLEARN_AMD_LGMRF_POLL = 1 / 2 / 3)
+                    const int pm = test_missing >> 1;
+                    if (pm == 0) __builtin_amdgcn_s_sleep(4);
+                    else if (pm == 1) __builtin_amdgcn_s_sleep(1);
+                    else if (pm == 3) __builtin_amdgcn_s_sleep(12);
+                    if ((++spins & 63u) == 0u &&
+                        (gl_ld_u32(err) != 0u || __builtin_amdgcn_s_memrealtime() - t_start > 100000000ull)) {
+                        good = false;  // 1 s: a producer is not on the chip
+                        break;
+                    }
+                    if (j < n) gq[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((((it & 1) * n) + j) * 16), 0, 16);
+                    asm volatile("" ::: "memory");  // the load stays in the loop
+                }
+                if (!good) break;
+                // (3) my rows times v, column by column
+                if (it < max_iter && j < n) {
+                    const double vjc = lg_pack(gq[c].x, gq[c].z);
 #pragma unroll
                     for (int r = 0; r < RLDS; ++r)
-                        if (r < nrows) acc[r] += s_W[(int64_t)r * n + j] * vj[c];
+                        if (r < nrows) acc[r] += s_W[(int64_t)r * n + j] * vjc;
+#pragma unroll
+                    for (int r = 0; r < RREG; ++r) acr[r] += wr[RREG > 0 ? r : 0][c] * vjc;  // (zero where there is no row: wr is)
                 }
             }
+            if (!good) s_fail = 1;
+        }
+        if (it < max_iter) {
             // the eight row sums of the wave in ONE halving butterfly (10 exchanges instead of 8 x 6): afterwards
             // lane 4 r holds row r
             const double rs = add_xor32(halfwave_rows8(acc, lane));
             if (lane < 32 && (lane & 3) == 0) s_acc[it & 1][wave][lane >> 2] = rs;
 #pragma unroll
-            for (int gr = 0; gr < RREG / 8; ++gr) {  // the rows kept in registers (zero where there is no row / column: wr is)
-                double acr[8];
+            for (int gr = 0; gr < RREG / 8; ++gr) {  // the rows kept in registers
+                double a8[8];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    acr[r] = 0.0;
-#pragma unroll
-                    for (int c = 0; c < CPT; ++c) acr[r] += wr[RREG > 0 ? 8 * gr + r : 0][c] * vj[c];
-                }
-                const double rs2 = add_xor32(halfwave_rows8(acr, lane));
+                for (int r = 0; r < 8; ++r) a8[r] = acr[RREG > 0 ? 8 * gr + r : 0];
+                const double rs2 = add_xor32(halfwave_rows8(a8, lane));
                 if (lane < 32 && (lane & 3) == 0) s_acc[it & 1][wave][RLDS + 8 * gr + (lane >> 2)] = rs2;
             }
         }
@@ -1687,6 +1708,120 @@ __global__ void k_lg_update_g(LgDev D) {
     D.G[i * n + j] -= corr;
 }
 
+// ---- the node update around the QP in two launches per matrix instead of three (round 4) ----
+// K transposed once per fit (the fused QP set-up reads column u of K as a row)
+__global__ void k_lg_transpose(const double *__restrict__ A, double *__restrict__ AT, int64_t n) {
+    __shared__ double tile[32][33];
+    const int64_t bx = (int64_t)blockIdx.x * 32, by = (int64_t)blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int64_t i = by + r, j = bx + threadIdx.x;
+        tile[r][threadIdx.x] = (i < n && j < n) ? A[i * n + j] : 0.0;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int64_t i = bx + r, j = by + threadIdx.x;
+        if (i < n && j < n) AT[i * n + j] = tile[threadIdx.x][r];
+    }
+}
+// column u of G (the first node of a cycle; afterwards k_lg_update_g2 writes the next node's column as it goes)
+__global__ __launch_bounds__(VT) void k_lg_gcol(LgDev D, int64_t u) {
+    for (int64_t i = threadIdx.x; i < D.n; i += VT) D.gcol[i] = D.G[i * D.n + u];
+}
+constexpr int LG_RB = 8;  // rows per workgroup of the fused updates (n = 2048: 256 workgroups of 16 waves)
+// k_lg_node_update + k_lg_update_c in ONE launch.  Every workgroup forms the two sums of k_lg_node_update itself (same thread
+// count, same order: the same bits) -- c'beta over the snapshot h of column u, and beta'(M beta) --, derives
+// (M beta)_j = t_j - h_j (c'beta) / c_uu on the fly for its rows and columns and updates LG_RB rows of C; workgroup 0 also
+// writes Theta's row / column u, Theta_uu and the change vector `a`.  c_uu comes from the snapshot (h_u): C_uu itself is
+// rewritten by the workgroup of row u during this launch.
+__global__ __launch_bounds__(VT) void k_lg_update_c2(LgDev D, int64_t u) {
+    __shared__ double sh[VT / 64];
+    const int64_t n = D.n;
+    const double cuu = D.h[u], kuu = D.K[u * n + u];
+    double part = 0;
+    for (int64_t i = threadIdx.x; i < n; i += VT)
+        if (i != u) part += D.h[i] * D.beta[i];
+    const double cb = block_sum(part, sh);
+    auto mbeta = [&](int64_t i) { return i != u ? D.t[i] - D.h[i] * cb / cuu : 0.0; };  // (M beta)_i  (t = C beta)
+    double quad = 0;
+    for (int64_t i = threadIdx.x; i < n; i += VT) quad += D.beta[i] * mbeta(i);
+    quad = block_sum(quad, sh);
+    if (blockIdx.x == 0) {
+        const double th_uu_old = D.Th[u * n + u];
+        const double th_uu_new = 1.0 / kuu + quad;
+        for (int64_t i = threadIdx.x; i < n; i += VT) {
+            if (i == u) {
+                D.a[i] = 0.5 * (th_uu_new - th_uu_old);
+                continue;
+            }
+            D.a[i] = D.beta[i] - D.Th[u * n + i];  // (Theta is symmetric bit for bit: row and column u are written together)
+            D.Th[i * n + u] = D.beta[i];
+            D.Th[u * n + i] = D.beta[i];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) D.Th[u * n + u] = th_uu_new;
+    }
+    const int64_t i0 = (int64_t)blockIdx.x * LG_RB;
+    __shared__ double s_gi[LG_RB], s_hi[LG_RB];  // (one division per row and workgroup, not per entry)
+    if (threadIdx.x < LG_RB && i0 + threadIdx.x < n) {
+        s_gi[threadIdx.x] = mbeta(i0 + threadIdx.x) * kuu;
+        s_hi[threadIdx.x] = D.h[i0 + threadIdx.x];
+    }
+    __syncthreads();
+    for (int64_t j = threadIdx.x; j < n; j += VT) {
+        const double gj = mbeta(j) * kuu, hj = D.h[j];
+#pragma unroll
+        for (int r = 0; r < LG_RB; ++r) {
+            const int64_t i = i0 + r;
+            if (i >= n) break;
+            const double gi = s_gi[r];
+            double out;
+            if (i == u && j == u)
+                out = kuu;
+            else if (i == u)
+                out = -gj;
+            else if (j == u)
+                out = -gi;
+            else {
+                const double m = D.C[i * n + j] - (s_hi[r] * hj) / cuu;  // lapl_u_inv (lgmrf.py:186-188)
+                out = m + (gi * gj) / kuu;                               // Sherman-Morrison (:217-219)
+            }
+            D.C[i * n + j] = out;
+        }
+    }
+}
+// k_lg_wood_scal + k_lg_update_g in ONE launch, after h = G a: every workgroup forms the two sums of k_lg_wood_scal itself
+// (same thread count, same order) and the inverse of the 2 x 2 matrix S, corrects LG_RB rows of G and leaves column u_next of
+// the corrected G in gcol_next for the next node's QP (gcol, column u before the correction, is read by everybody throughout:
+// two buffers).  G_uu comes from the snapshot (gcol_u).
+__global__ __launch_bounds__(VT) void k_lg_update_g2(LgDev D, int64_t u, int64_t u_next) {
+    __shared__ double sh[VT / 64];
+    const int64_t n = D.n;
+    double ag = 0, ah = 0;
+    for (int64_t i = threadIdx.x; i < n; i += VT) {
+        ag += D.a[i] * D.gcol[i];
+        ah += D.a[i] * D.h[i];
+    }
+    ag = block_sum(ag, sh);
+    ah = block_sum(ah, sh);
+    const double s11 = 1.0 + ag, s12 = ah, s21 = D.gcol[u], s22 = 1.0 + D.h[u];
+    const double det = s11 * s22 - s12 * s21;
+    const double i11 = s22 / det, i12 = -s12 / det, i21 = -s21 / det, i22 = s11 / det;  // inverse of S
+    const int64_t i0 = (int64_t)blockIdx.x * LG_RB;
+    for (int64_t j = threadIdx.x; j < n; j += VT) {
+        const double gj = D.gcol[j], hj = D.h[j];
+#pragma unroll
+        for (int r = 0; r < LG_RB; ++r) {
+            const int64_t i = i0 + r;
+            if (i >= n) break;
+            const double gi = D.gcol[i], hi = D.h[i];
+            const double corr = gi * (i11 * hj + i12 * gj) + hi * (i21 * hj + i22 * gj);  // [g_i h_i] S^-1 [h_j ; g_j]
+            const double gn = D.G[i * n + j] - corr;
+            D.G[i * n + j] = gn;
+            if (j == u_next) D.gcol_next[i] = gn;
+        }
+    }
+}
+
 // G0 = Theta + rho I (then inverted in place by Gauss-Jordan)
 __global__ void k_lg_shift(const double *__restrict__ Th, double *__restrict__ G, int64_t n, double rho) {
     const int64_t i = blockIdx.y;
@@ -2370,7 +2505,20 @@ static int lgmrf_fit_impl(gl_ctx *ctx, const double *x, int64_t n, double norm_p
             return GL_OK;
         }
     }
+    // fused node update (fast path, tagged ADMM): K transposed into the buffer of the explicit inverse, which that path never
+    // forms (a fit that falls back to one launch per step rebuilds W per node and no longer reads KT)
+    const bool fuse3 = fast && ares.on && ares.tagged &&
+                       !(getenv("GRAPHLEARN_AMD_LGMRF_FUSE3") && atoi(getenv("GRAPHLEARN_AMD_LGMRF_FUSE3")) == 0);
+    bool gcol_ready = false;
+    D.gcol_next = V + 14 * n;
+    D.KT = nullptr;
+    if (fuse3) {
+        k_lg_transpose<<<dim3((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32)), dim3(32, 8), 0, ctx->stream>>>(D.K, D.W, n);
+        GL_HIP(ctx, hipGetLastError());
+        D.KT = D.W;
+    }
     for (int cycle = 0; cycle < max_cycle; ++cycle) {
+        gcol_ready = false;
         GL_HIP(ctx, hipMemcpyAsync(D.ThPrev, D.Th, nn, hipMemcpyDeviceToDevice, ctx->stream));  // l_pre (:173)
         if (bCprev.p) GL_HIP(ctx, hipMemcpyAsync(bCprev.p, D.C, nn, hipMemcpyDeviceToDevice, ctx->stream));  // to redo the cycle
         if (fast) {  // fresh G = (Theta + rho I)^-1 once per cycle; rank-2 corrections in between
@@ -2408,6 +2556,22 @@ static int lgmrf_fit_impl(gl_ctx *ctx, const double *x, int64_t n, double norm_p
                     } else GL_TRY(run_admm(ctx, Dc, max_qp_iter));
                 }
                 k_lg_scatter_beta<<<1, VT, 0, ctx->stream>>>(D, Dc, idx);
+            } else if (fuse3 && ares.on && ares.tagged) {
+                // Round 4: the node update in five launches instead of eight.  The QP's set-up rides in the ADMM kernel's
+                // prologue (p = k_u / k_uu from the transposed K; column u of G is left in gcol by the previous node's
+                // k_lg_update_g2, for the cycle's first node by k_lg_gcol), k_lg_node_update in k_lg_update_c2 and
+                // k_lg_wood_scal in k_lg_update_g2: 69 -> 43 us of launches around the QP at n = 2048.
+                if (u == 0 || !gcol_ready) k_lg_gcol<<<1, VT, 0, ctx->stream>>>(D, u);
+                fused_winv = true;
+                GL_TRY(run_admm_res(ctx, D, ares, max_qp_iter, u));
+                k_matvec<<<mvb, 256, 0, ctx->stream>>>(D.C, D.beta, D.t, n, D.scal, 0);
+                k_lg_update_c2<<<dim3((unsigned)((n + LG_RB - 1) / LG_RB)), VT, 0, ctx->stream>>>(D, u);
+                k_matvec<<<mvb, 256, 0, ctx->stream>>>(D.G, D.a, D.h, n, D.scal, 0);
+                k_lg_update_g2<<<dim3((unsigned)((n + LG_RB - 1) / LG_RB)), VT, 0, ctx->stream>>>(D, u, (u + 1) % n);
+                std::swap(D.gcol, D.gcol_next);  // (u + 1's column of the corrected G)
+                gcol_ready = u + 1 < n;          // (a new cycle starts from a fresh inverse)
+                GL_HIP(ctx, hipGetLastError());
+                continue;
             } else {
                 k_lg_qp_setup<<<1, VT, 0, ctx->stream>>>(D, u);
                 fused_winv = ares.wave || ares.quad || (ares.on && ares.tagged);  // the ADMM kernel forms its rows of the inverse itself
@@ -2449,6 +2613,7 @@ static int lgmrf_fit_impl(gl_ctx *ctx, const double *x, int64_t n, double norm_p
                 GL_HIP(ctx, hipMemsetAsync(D.scal, 0, 16 * 8, ctx->stream));
                 ares.on = false;
                 persistent_ok = false;
+                D.KT = nullptr;  // (the launch form sets the QP up with k_lg_qp_setup and builds W, where K transposed lay)
                 --cycle;
                 continue;
             }

@@ -645,14 +645,14 @@ def pick_stopping_iteration(rel, lo, hi):
     geometric mean of the two -- late in a run the ratios fall by 1/k per iteration, so the gap is small, but the engines
     reproduce the ratios to ~1e-9."""
     m = [max(a, b) for a, b in rel]
-    for K in range(lo, hi):
+    for K in range(hi - 1, lo - 1, -1):      # the latest one (early in a run the primal ratio rises again for a while)
         before = min(m[1:K])
         if before > m[K] * (1 + 1e-5):
             return K, float(np.sqrt(before * m[K]))
     raise AssertionError("no usable stopping iteration in the window")
 
 
-@pytest.mark.parametrize("n,iters", [(1200, 200), (2600, 80), (3500, 36)])
+@pytest.mark.parametrize("n,iters", [(1200, 200), (2600, 110), (3500, 40)])
 def test_converge_mode_at_mid_sizes_stops_where_the_oracle_stops(engine, n, iters):
     """VERDICT r03 'missing 2': converge mode on the TILE engine against the oracle's own stopping iteration beyond the
     golden sizes -- n = 1200 (chunks of 8 row pairs), n = 2600 (16) and n = 3500 (32, ragged) on smooth signals, tol set so
@@ -666,8 +666,8 @@ def test_converge_mode_at_mid_sizes_stops_where_the_oracle_stops(engine, n, iter
     rel, states, _ = oracle_trajectory(zt, iters, snaps=(iters,))
     try:
         K, tol = pick_stopping_iteration(rel, iters - 1, iters)  # the last iteration, if the ratios are at their minimum there
-    except AssertionError:                                       # else an earlier one, at the price of a second run
-        K, tol = pick_stopping_iteration(rel, (2 * iters) // 3, iters)
+    except AssertionError:                                       # else the latest earlier one, at the price of a second run
+        K, tol = pick_stopping_iteration(rel, 8, iters)
         _, states, _ = oracle_trajectory(zt, K + 1, snaps=(K + 1,))
     with _lib.LogDegreeSession(n) as s:
         s.set_distances(zt)
@@ -762,8 +762,8 @@ def test_long_converge_calls_run_through_the_dual_gate(engine, monkeypatch, capf
     rel, states, _ = oracle_trajectory(zt, iters, snaps=(iters,))
     try:
         K, tol = pick_stopping_iteration(rel, iters - 1, iters)  # the last iteration, if the ratios are at their minimum there
-    except AssertionError:                                       # else an earlier one, at the price of a second run
-        K, tol = pick_stopping_iteration(rel, (2 * iters) // 3, iters)
+    except AssertionError:                                       # else the latest earlier one, at the price of a second run
+        K, tol = pick_stopping_iteration(rel, 600, iters)
         _, states, _ = oracle_trajectory(zt, K + 1, snaps=(K + 1,))
     assert rel[16][1] > 2 * tol                                   # the dual ratio is well above tol after the head: the gate opens
     out = {}
