@@ -354,8 +354,8 @@ def main():
                 import hashlib
                 with open(os.path.join(ROOT, "profiles", CENSUS_JSON)) as f:
                     census = json.load(f)
-                with open(os.path.join(ROOT, "graph_learning_amd", "csrc", "gl_tile.hip"), "rb") as f:
-                    census_ok = hashlib.sha256(f.read()).hexdigest()[:16] == census["source_sha16"]
+                src = b"".join(open(os.path.join(ROOT, "graph_learning_amd", "csrc", f), "rb").read() for f in census["sources"])
+                census_ok = hashlib.sha256(src).hexdigest()[:16] == census["source_sha16"]
             except Exception:
                 census = None
             streamed_bytes = 2 * n * (n - 1)      # half of z per iteration (4 E); records ~3 MB on top

@@ -76,23 +76,39 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
+// t where the lane's bit of the CONSTANT 64-lane mask M is set, else f.  The masks of the butterflies below are lane
+// patterns ((lane & 8) != 0, (lane & 4) != 0); derived from the lane number they are live SGPR pairs that the compiler,
+// short of scalar registers in the tile engine's pass, spills to VGPR lanes and reads back with v_readlane + s_nop before
+// every select (34 + 27 instructions per pass, measured from the assembly).  As literals they cost an s_mov_b64 each.
+template <unsigned long long M>
+__device__ __forceinline__ double lane_select(double f, double t) {
+    const long long fb = __double_as_longlong(f), tb = __double_as_longlong(t);
+    int lo, hi;
+    const unsigned long long m = M;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"((int)fb), "v"((int)tb), "s"(m));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"((int)(fb >> 32)), "v"((int)(tb >> 32)), "s"(m));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+constexpr unsigned long long LANES_BIT3 = 0xFF00FF00FF00FF00ull;  // (lane & 8) != 0
+constexpr unsigned long long LANES_BIT2 = 0xF0F0F0F0F0F0F0F0ull;  // (lane & 4) != 0
+
 // Sums of 8 per-lane values over the 32 lanes of a half-wave, "halving" butterfly: every step
 // exchanges half of what is left, so 4 + 2 + 1 + 1 + 1 = 9 exchanges instead of 8 x 5.  Afterwards
 // lane l holds the total of value ((l >> 2) & 7) of its half-wave.
 __device__ __forceinline__ double halfwave_rows8(const double (&v)[8], int lane) {
-    const bool b3 = lane & 8, b2 = lane & 4;
+    (void)lane;
     double a[4], b[2], c;
 #pragma unroll
     for (int m = 0; m < 4; ++m) a[m] = swap16_halve(v[m], v[m + 4]);  // even rows keep m, odd rows m + 4
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-        const double keep = b3 ? a[m + 2] : a[m];
-        const double send = b3 ? a[m] : a[m + 2];
+        const double keep = lane_select<LANES_BIT3>(a[m], a[m + 2]);
+        const double send = lane_select<LANES_BIT3>(a[m + 2], a[m]);
         b[m] = keep + dpp_mov<DPP_ROW_ROR8>(send);
     }
     {
-        const double keep = b2 ? b[1] : b[0];
-        const double send = b2 ? b[0] : b[1];
+        const double keep = lane_select<LANES_BIT2>(b[0], b[1]);
+        const double send = lane_select<LANES_BIT2>(b[1], b[0]);
         c = keep + dpp_mov<DPP_HALF_MIRROR>(send);  // partner 7 - i instead of i ^ 4: also across bit 2
     }
     c += dpp_mov<DPP_QUAD_XOR2>(c);
@@ -103,13 +119,13 @@ __device__ __forceinline__ double halfwave_rows8(const double (&v)[8], int lane)
 // Same for 4 values per half-wave: 2 + 1 halving exchanges, then 3 full ones.  Afterwards lane l holds
 // the total of value ((l >> 3) & 3).
 __device__ __forceinline__ double halfwave_rows4(const double (&v)[4], int lane) {
-    const bool b3 = lane & 8;
+    (void)lane;
     double a[2], c;
 #pragma unroll
     for (int m = 0; m < 2; ++m) a[m] = swap16_halve(v[m], v[m + 2]);
     {
-        const double keep = b3 ? a[1] : a[0];
-        const double send = b3 ? a[0] : a[1];
+        const double keep = lane_select<LANES_BIT3>(a[0], a[1]);
+        const double send = lane_select<LANES_BIT3>(a[1], a[0]);
         c = keep + dpp_mov<DPP_ROW_ROR8>(send);
     }
     c += dpp_mov<DPP_HALF_MIRROR>(c);

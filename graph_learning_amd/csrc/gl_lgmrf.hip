@@ -614,7 +614,13 @@ __global__ __launch_bounds__(NT) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u
     };
     // thread r < nrows owns row r0 + r; three generations of its ADMM state stay in registers
     double xo = 0, zo = 0, uo = 0, pi = 0, on = 0;
-    double x1 = 0, z1 = 0, u1 = 0, x2g = 0, z2g = 0, u2g = 0;  // the state one / two steps earlier
+    // the state one / two steps earlier: in LDS, [generation][x, z, u][row] -- only the threads that own a row need it, and the
+    // sixteen registers it took in every thread put the wide form into scratch
+    __shared__ double s_hist[2][3][RTOT];
+    if (tid < RTOT) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) s_hist[g][0][tid] = s_hist[g][1][tid] = s_hist[g][2][tid] = 0.0;
+    }
     if (tid < nrows) {
         const int64_t i = r0 + tid;
         double v0;
@@ -705,8 +711,15 @@ __global__ __launch_bounds__(NT) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u
                         good = false;  // 1 s: a producer is not on the chip
                         break;
                     }
-                    if (j < n) gq[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((((it & 1) * n) + j) * 16), 0, 16);
-                    asm volatile("" ::: "memory");  // the load stays in the loop
+                    // re-read what is still missing -- this column's record AND the later ones (a lane whose record carries
+                    // the tag keeps it): one round trip serves every column that was late, not one round trip each
+#pragma unroll
+                    for (int c2 = 0; c2 < CPT; ++c2) {
+                        const int64_t j2 = tid + NT * (int64_t)c2;
+                        if (c2 >= c && j2 < n && !(gq[c2].y == tag && gq[c2].w == tag))
+                            gq[c2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((((it & 1) * n) + j2) * 16), 0, 16);
+                    }
+                    asm volatile("" ::: "memory");  // the loads stay in the loop
                 }
                 if (!good) break;
                 // (3) my rows times v, column by column
@@ -743,8 +756,10 @@ __global__ __launch_bounds__(NT) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u
         }
         if (s_stop[it & 1]) {  // step it-3 met the rule: its z is the result, the steps after it are dropped
             stopped = true;
-            if (it <= max_iter) xo = x2g, zo = z2g, uo = u2g;
-            else xo = x1, zo = z1, uo = u1;  // the last pass follows a pass without an update
+            if (tid < nrows) {
+                const int g = it <= max_iter ? 1 : 0;  // (the last pass follows a pass without an update)
+                xo = s_hist[g][0][tid], zo = s_hist[g][1][tid], uo = s_hist[g][2][tid];
+            }
             steps = it - 2;
             break;
         }
@@ -769,8 +784,8 @@ __global__ __launch_bounds__(NT) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u
                     z2 = zo * zo;
                     zm = fabs(zo);
                 }
-                x2g = x1, z2g = z1, u2g = u1;
-                x1 = xo, z1 = zo, u1 = uo;
+                s_hist[1][0][tid] = s_hist[0][0][tid], s_hist[1][1][tid] = s_hist[0][1][tid], s_hist[1][2][tid] = s_hist[0][2][tid];
+                s_hist[0][0][tid] = xo, s_hist[0][1][tid] = zo, s_hist[0][2][tid] = uo;
                 xo = xn;
                 zo = active ? zn : 0.0;
                 uo = active ? un : 0.0;

@@ -109,3 +109,26 @@ def test_tile_kernels_keep_their_pass_out_of_scratch():
         norms = re.search(r"k_tileILi\d+ELb[01]ELb([01])ELi", name).group(1) == "1"
         assert vgpr <= 256 and lds <= 160 * 1024, l
         assert scratch == 0 if not norms else scratch <= 32, l
+
+
+def test_timed_kernels_pass_is_the_one_the_roofline_prices():
+    """bench.py prices the timed kernel's pass from an instruction census of the shipped build's assembly
+    (profiles/r04_tile_census.json, tools/tile_pass_census.py).  The census must have been made from THIS gl_tile.hip (else
+    bench.py reports no roofline at all), and the pass must be the good build of it: the same source has compiled to passes
+    with 4.8 and with 9.0 other-than-fp64 vector instructions per row pair (scalar registers spilled to VGPR lanes and read
+    back inside the pass), 6.9 against 7.3 us per iteration on the same GPU."""
+    import hashlib
+    import json
+
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc here")
+    census = json.load(open(os.path.join(ROOT, "profiles", "r04_tile_census.json")))
+    src = b"".join(open(os.path.join(ROOT, "graph_learning_amd", "csrc", f), "rb").read() for f in census["sources"])
+    assert "gl_tile.hip" in census["sources"] and "gl_lanes.h" in census["sources"]
+    assert census["source_sha16"] == hashlib.sha256(src).hexdigest()[:16], "re-run tools/tile_pass_census.py: the kernel's sources changed"
+    out = os.path.join(ROOT, "graph_learning_amd", "csrc", "build", "report", "census_check.json")
+    r = subprocess.run(["python", os.path.join(ROOT, "tools", "tile_pass_census.py"), "--out", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    now = json.load(open(out))["per_row_pair"]
+    assert now == census["per_row_pair"], (now, census["per_row_pair"])   # the committed census IS this build's
+    assert now["scratch"] == 0 and now["valu_f64"] <= 18.2 and now["valu_other"] <= 5.5, now

@@ -752,8 +752,8 @@ def test_long_converge_calls_run_through_the_dual_gate(engine, monkeypatch, capf
     """Round 4: a long converge-mode call on the tile engine runs in three launches -- a head with the norms, a middle WITHOUT
     the primal norms that only watches the dual ratio (the rule needs both ratios below tol, smooth_learning.py:166-167, and the
     dual one holds it up for most of a run), a tail with the norms that judges every iteration.  Against the oracle: the same
-    stopping iteration, the same iterate (1e-10) and ratios; and against the same call with the gate switched off: EQUAL
-    iterates (the variants share the iterate's arithmetic)."""
+    stopping iteration, the same iterate (1e-10) and ratios; and against the same call with the gate switched off: the same
+    stopping iteration, iterates equal to 1e-13."""
     if engine != "resident":
         pytest.skip("the tile engine")
     x, _ = logmodel_problem(n, 256, seed=7 * n)
@@ -791,4 +791,7 @@ def test_long_converge_calls_run_through_the_dual_gate(engine, monkeypatch, capf
     np.testing.assert_allclose(w, states[K + 1][0], rtol=0, atol=ATOL)
     np.testing.assert_allclose(d, states[K + 1][1], rtol=0, atol=ATOL)
     assert r[0] == pytest.approx(rel[K][0], rel=1e-8) and r[1] == pytest.approx(rel[K][1], rel=1e-8)
-    assert np.array_equal(w, out["0"][3]) and np.array_equal(d, out["0"][4])
+    # (not bit for bit: every launch re-forms gamma S w = ybar - d from the stored dual state, where a single launch carries it
+    #  through its recurrence -- three launches round differently from one, at the 1e-16 level)
+    np.testing.assert_allclose(w, out["0"][3], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(d, out["0"][4], rtol=0, atol=1e-13)

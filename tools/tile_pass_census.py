@@ -63,9 +63,11 @@ tot["valu_f64"] = tot["valu_f64_fma"] + tot["valu_f64_other"]      # fp64 vector
 tot["flop_f64"] = 2 * tot["valu_f64_fma"] + tot["valu_f64_other"]  # real flops per lane: a fused multiply-add is 2, add / mul / max 1
 nmax = sum(sum("v_max_f64" in l for l in b) for b in pass_blocks)
 assert nmax == 64, f"expected the 64 v_max_f64 of one pass (32 row pairs x 2 edges per lane), found {nmax}"
-src = open(os.path.join(ROOT, "graph_learning_amd", "csrc", "gl_tile.hip"), "rb").read()
+# the sources the timed kernel is compiled from (the kernel file and the headers its pass draws on)
+SOURCES = ["gl_tile.hip", "gl_lanes.h", "gl_tile_plan.h", "gl_gridbar.h", "gl_logdeg.h", "gl_common.h"]
+src = b"".join(open(os.path.join(ROOT, "graph_learning_amd", "csrc", f), "rb").read() for f in SOURCES)
 out = {"kernel": m.group(1), "kernel_demangled": "k_tile<32, true, false, 0, false> (U = 32, write-back mask only, no norms, single graph)",
-       "source_sha16": hashlib.sha256(src).hexdigest()[:16], "row_pairs_per_pass": 32, "edges_per_lane_and_row_pair": 2,
+       "source_sha16": hashlib.sha256(src).hexdigest()[:16], "sources": SOURCES, "row_pairs_per_pass": 32, "edges_per_lane_and_row_pair": 2,
        "per_pass": tot, "per_row_pair": {k: v / 32.0 for k, v in tot.items()},
        "fp64_valu_peak_lane_ops_per_s": 256 * 4 * 16 * 2.4e9,
        "note": "basic blocks of the unrolled pass (those holding its 64 v_max_f64); per lane and row pair = 2 edges"}
