@@ -361,6 +361,15 @@ __global__ __launch_bounds__(256) void k_lg_admm(LgDev D, int it) {
 // it from the same partials in the same order).  Needs all workgroups co-resident (grid <= #CU,
 // one workgroup per CU); the start-up rendezvous fails cleanly otherwise (error word in scal[8]).
 constexpr int ADMM_RES_MAXR = 8;
+#ifndef LG_HIST_LDS
+#define LG_HIST_LDS 1    // tagged ADMM: the state one / two steps earlier in LDS (0: in registers, as before round 4)
+#endif
+#ifndef LG_RULE_EARLY
+#define LG_RULE_EARLY 1  // ... the stopping rule of three steps ago is evaluated while the records are on their way (0: after the poll)
+#endif
+#ifndef LG_SELECTIVE
+#define LG_SELECTIVE 1   // ... a retry re-reads only the records that are still missing (0: the whole sweep)
+#endif
 
 __device__ __forceinline__ double lg_ld_sc1(const double *p) {
     return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED,
@@ -545,11 +554,15 @@ __device__ __forceinline__ double lg_pack(unsigned lo, unsigned hi) {
 // first 8 in LDS and the others in the registers of the threads that multiply them (thread t: columns t, t + 512, ...) --
 // half as many workgroups poll the n records of a step and half as many publish: at n = 2048 a poll round moves 4 MB
 // through the fabric instead of 8.
-template <int NT, int RREG>
+// RLDS_ rows of a workgroup live in LDS, RREG in the registers of the threads that multiply them (their columns of them).
+// <256, 0, 8>: up to 8 rows, all in LDS; <512, 8, 8> ("wide"): 16 rows, half and half; <512, 16, 0> ("regs", round 4): 16 rows,
+// all in registers, four columns per thread (1024 or 768 threads leave 128 / 168 registers per wave: 45 / 21 of them spilled) -- the multiply reads no LDS at all (128 KB per step and workgroup in the wide form:
+// 0.4 us of a 4.2 us step at n = 2048).
+template <int NT, int RREG, int RLDS_ = ADMM_RES_MAXR>
 __global__ __launch_bounds__(NT) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u4 *gran, unsigned tag0, int R, int max_iter,
                                                     int64_t u_fast, int test_missing) {
-    constexpr int CPT = ADMM_RES_MAXR * 256 / NT;  // columns per thread (n <= 2048)
-    constexpr int NWV = NT / 64, RLDS = ADMM_RES_MAXR, RTOT = ADMM_RES_MAXR + RREG;
+    constexpr int CPT = (ADMM_RES_MAXR * 256 + NT - 1) / NT;  // columns per thread (n <= 2048)
+    constexpr int NWV = NT / 64, RLDS = RLDS_, RTOT = RLDS_ + RREG;
     extern __shared__ double s_W[];  // the first min(R, 8) rows of W, row-major
     __shared__ double s_acc[2][NWV][RTOT];
     __shared__ int s_fail, s_stop[2];
@@ -621,6 +634,9 @@ __global__ __launch_bounds__(NT) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u
 #pragma unroll
         for (int g = 0; g < 2; ++g) s_hist[g][0][tid] = s_hist[g][1][tid] = s_hist[g][2][tid] = 0.0;
     }
+#if !LG_HIST_LDS
+    double x1 = 0, z1 = 0, u1 = 0, x2g = 0, z2g = 0, u2g = 0;
+#endif
     if (tid < nrows) {
         const int64_t i = r0 + tid;
         double v0;
@@ -640,22 +656,17 @@ __global__ __launch_bounds__(NT) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u
         }
         if (!((test_missing & 1) && blockIdx.x == 0)) publish(0, i, v0, tag0);  // the input of step 0
     }
-    lg_u4 pr[4][3];  // wave 0: the partials {dx2, x2 | xm, dz2 | z2, zm} of workgroups lane, lane + 64, ...
+    // (sixteen rows per workgroup: at most 2048 / 16 = 128 workgroups, two per lane)
+    constexpr int NQ = RTOT >= 16 ? 2 : 4;
+    lg_u4 pr[NQ][3];  // wave 0: the partials {dx2, x2 | xm, dz2 | z2, zm} of workgroups lane, lane + 64, ...
     bool pending = false;
     int steps = 0;
     bool stopped = false, failed = false;
     for (int it = 0; it <= max_iter + 1; ++it) {
-        // (1) my columns of v: thread t takes columns t, t + NT, ...  All of a thread's records are requested at once; they are
-        // then taken IN ORDER, each re-read alone until it carries this step's tag, and multiplied into the rows at once:
-        // the products of the columns that are there run underneath the wait for the ones that are not (before round 4 the
-        // whole sweep was repeated until every tag matched and the multiply -- 0.6 us of a 4.2 us step at n = 2048 --
-        // started after the last one).  Every row sum keeps its order of summation (columns ascending): bit-identical.
+        // (1) my columns of v: thread t takes columns t, t + NT, ...  All of a thread's records are requested at once; what does
+        // not carry this step's tag yet is re-read -- only that: a lane whose record has arrived keeps it (before round 4
+        // the whole sweep, n records per workgroup, was repeated until every tag matched).
         const unsigned tag = tag0 + (unsigned)it;
-        double acc[RLDS], acr[RREG > 0 ? RREG : 1];
-#pragma unroll
-        for (int r = 0; r < RLDS; ++r) acc[r] = 0.0;
-#pragma unroll
-        for (int r = 0; r < (RREG > 0 ? RREG : 1); ++r) acr[r] = 0.0;
         lg_u4 gq[CPT];
         if (it <= max_iter) {
 #pragma unroll
@@ -665,86 +676,101 @@ __global__ __launch_bounds__(NT) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u
                 if (j < n) gq[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((((it & 1) * n) + j) * 16), 0, 16);
             }
         }
+        auto rule_of_three_steps_ago = [&]() {
         // (2) the rule of step it-3 from the partials requested one step ago -- wave 0, while the records above are on their
-        // way (in front of the multiply it held the whole workgroup up at the barrier below)
-        if (wave == 0) {
-            int stop = 0;
-            if (pending) {
-                double a0 = 0, a1 = 0, a3 = 0, a4 = 0, m2 = 0, m5 = 0;
+            // way (in front of the multiply it held the whole workgroup up at the barrier below)
+            if (wave == 0) {
+                int stop = 0;
+                if (pending) {
+                    double a0 = 0, a1 = 0, a3 = 0, a4 = 0, m2 = 0, m5 = 0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (lane + 64 * q < nblk) {
-                        a0 += lg_pack(pr[q][0].x, pr[q][0].y);
-                        a1 += lg_pack(pr[q][0].z, pr[q][0].w);
-                        m2 = fmax(m2, lg_pack(pr[q][1].x, pr[q][1].y));
-                        a3 += lg_pack(pr[q][1].z, pr[q][1].w);
-                        a4 += lg_pack(pr[q][2].x, pr[q][2].y);
-                        m5 = fmax(m5, lg_pack(pr[q][2].z, pr[q][2].w));
-                    }
-                a0 = wsum(a0);
-                a1 = wsum(a1);
-                a3 = wsum(a3);
-                a4 = wsum(a4);
-                m2 = wmax(m2);
-                m5 = wmax(m5);
-                stop = lg_rule_met(a0, a1, m2, a3, a4, m5, D.qp_tol) ? 1 : 0;
+                    for (int q = 0; q < NQ; ++q)
+                        if (lane + 64 * q < nblk) {
+                            a0 += lg_pack(pr[q][0].x, pr[q][0].y);
+                            a1 += lg_pack(pr[q][0].z, pr[q][0].w);
+                            m2 = fmax(m2, lg_pack(pr[q][1].x, pr[q][1].y));
+                            a3 += lg_pack(pr[q][1].z, pr[q][1].w);
+                            a4 += lg_pack(pr[q][2].x, pr[q][2].y);
+                            m5 = fmax(m5, lg_pack(pr[q][2].z, pr[q][2].w));
+                        }
+                    a0 = wsum(a0);
+                    a1 = wsum(a1);
+                    a3 = wsum(a3);
+                    a4 = wsum(a4);
+                    m2 = wmax(m2);
+                    m5 = wmax(m5);
+                    stop = lg_rule_met(a0, a1, m2, a3, a4, m5, D.qp_tol) ? 1 : 0;
+                }
+                if (lane == 0) s_stop[it & 1] = stop;
             }
-            if (lane == 0) s_stop[it & 1] = stop;
-        }
+        };
+#if LG_RULE_EARLY
+        rule_of_three_steps_ago();
+#endif
+        double vj[CPT];
         if (it <= max_iter) {
             const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
             bool good = true;
-            unsigned spins = 0;
+            for (unsigned spins = 0;; ++spins) {
+                bool ok = true;
 #pragma unroll
-            for (int c = 0; c < CPT; ++c) {
-                const int64_t j = tid + NT * (int64_t)c;
-                for (;;) {
-                    const bool ok = gq[c].y == tag && gq[c].w == tag;
-                    if (__all(ok)) break;
-                    // ~0.1 us: leave the fabric to the stores we wait for (development: GRAPHLEARN_AMD_LGMRF_POLL = 1 / 2 / 3)
-                    const int pm = test_missing >> 1;
-                    if (pm == 0) __builtin_amdgcn_s_sleep(4);
-                    else if (pm == 1) __builtin_amdgcn_s_sleep(1);
-                    else if (pm == 3) __builtin_amdgcn_s_sleep(12);
-                    if ((++spins & 63u) == 0u &&
-                        (gl_ld_u32(err) != 0u || __builtin_amdgcn_s_memrealtime() - t_start > 100000000ull)) {
-                        good = false;  // 1 s: a producer is not on the chip
-                        break;
-                    }
-                    // re-read what is still missing -- this column's record AND the later ones (a lane whose record carries
-                    // the tag keeps it): one round trip serves every column that was late, not one round trip each
-#pragma unroll
-                    for (int c2 = 0; c2 < CPT; ++c2) {
-                        const int64_t j2 = tid + NT * (int64_t)c2;
-                        if (c2 >= c && j2 < n && !(gq[c2].y == tag && gq[c2].w == tag))
-                            gq[c2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((((it & 1) * n) + j2) * 16), 0, 16);
-                    }
-                    asm volatile("" ::: "memory");  // the loads stay in the loop
+                for (int c = 0; c < CPT; ++c) ok = ok && gq[c].y == tag && gq[c].w == tag;
+                if (__all(ok)) break;
+                // ~0.1 us: leave the fabric to the stores we wait for (development: GRAPHLEARN_AMD_LGMRF_POLL = 1 / 2 / 3)
+                const int pm = test_missing >> 1;
+                if (pm == 0) __builtin_amdgcn_s_sleep(4);
+                else if (pm == 1) __builtin_amdgcn_s_sleep(1);
+                else if (pm == 3) __builtin_amdgcn_s_sleep(12);
+                if ((spins & 63u) == 63u &&
+                    (gl_ld_u32(err) != 0u || __builtin_amdgcn_s_memrealtime() - t_start > 100000000ull)) {
+                    good = false;  // 1 s: a producer is not on the chip
+                    break;
                 }
-                if (!good) break;
-                // (3) my rows times v, column by column
-                if (it < max_iter && j < n) {
-                    const double vjc = lg_pack(gq[c].x, gq[c].z);
 #pragma unroll
-                    for (int r = 0; r < RLDS; ++r)
-                        if (r < nrows) acc[r] += s_W[(int64_t)r * n + j] * vjc;
-#pragma unroll
-                    for (int r = 0; r < RREG; ++r) acr[r] += wr[RREG > 0 ? r : 0][c] * vjc;  // (zero where there is no row: wr is)
+                for (int c = 0; c < CPT; ++c) {
+                    const int64_t j = tid + NT * (int64_t)c;
+                    if (j < n && (!LG_SELECTIVE || !(gq[c].y == tag && gq[c].w == tag)))
+                        gq[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((((it & 1) * n) + j) * 16), 0, 16);
                 }
+                asm volatile("" ::: "memory");  // the loads stay in the loop
             }
             if (!good) s_fail = 1;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) vj[c] = lg_pack(gq[c].x, gq[c].z);
         }
+#if !LG_RULE_EARLY
+        rule_of_three_steps_ago();
+#endif
+        // (3) my rows times v
         if (it < max_iter) {
-            // the eight row sums of the wave in ONE halving butterfly (10 exchanges instead of 8 x 6): afterwards
-            // lane 4 r holds row r
-            const double rs = add_xor32(halfwave_rows8(acc, lane));
-            if (lane < 32 && (lane & 3) == 0) s_acc[it & 1][wave][lane >> 2] = rs;
+            if constexpr (RLDS > 0) {
+                double acc[RLDS > 0 ? RLDS : 1];
 #pragma unroll
-            for (int gr = 0; gr < RREG / 8; ++gr) {  // the rows kept in registers
-                double a8[8];
+                for (int r = 0; r < RLDS; ++r) acc[r] = 0.0;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) a8[r] = acr[RREG > 0 ? 8 * gr + r : 0];
-                const double rs2 = add_xor32(halfwave_rows8(a8, lane));
+                for (int c = 0; c < CPT; ++c) {
+                    const int64_t j = tid + NT * (int64_t)c;
+                    if (j < n) {
+#pragma unroll
+                        for (int r = 0; r < RLDS; ++r)
+                            if (r < nrows) acc[r] += s_W[(int64_t)r * n + j] * vj[c];
+                    }
+                }
+                // the eight row sums of the wave in ONE halving butterfly (10 exchanges instead of 8 x 6): afterwards
+                // lane 4 r holds row r
+                const double rs = add_xor32(halfwave_rows8(acc, lane));
+                if (lane < 32 && (lane & 3) == 0) s_acc[it & 1][wave][lane >> 2] = rs;
+            }
+#pragma unroll
+            for (int gr = 0; gr < RREG / 8; ++gr) {  // the rows kept in registers (zero where there is no row / column: wr is)
+                double acr[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    acr[r] = 0.0;
+#pragma unroll
+                    for (int c = 0; c < CPT; ++c) acr[r] += wr[RREG > 0 ? 8 * gr + r : 0][c] * vj[c];
+                }
+                const double rs2 = add_xor32(halfwave_rows8(acr, lane));
                 if (lane < 32 && (lane & 3) == 0) s_acc[it & 1][wave][RLDS + 8 * gr + (lane >> 2)] = rs2;
             }
         }
@@ -756,10 +782,15 @@ __global__ __launch_bounds__(NT) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u
         }
         if (s_stop[it & 1]) {  // step it-3 met the rule: its z is the result, the steps after it are dropped
             stopped = true;
+#if LG_HIST_LDS
             if (tid < nrows) {
                 const int g = it <= max_iter ? 1 : 0;  // (the last pass follows a pass without an update)
                 xo = s_hist[g][0][tid], zo = s_hist[g][1][tid], uo = s_hist[g][2][tid];
             }
+#else
+            if (it <= max_iter) xo = x2g, zo = z2g, uo = u2g;
+            else xo = x1, zo = z1, uo = u1;
+#endif
             steps = it - 2;
             break;
         }
@@ -784,8 +815,13 @@ __global__ __launch_bounds__(NT) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u
                     z2 = zo * zo;
                     zm = fabs(zo);
                 }
+#if LG_HIST_LDS
                 s_hist[1][0][tid] = s_hist[0][0][tid], s_hist[1][1][tid] = s_hist[0][1][tid], s_hist[1][2][tid] = s_hist[0][2][tid];
                 s_hist[0][0][tid] = xo, s_hist[0][1][tid] = zo, s_hist[0][2][tid] = uo;
+#else
+                x2g = x1, z2g = z1, u2g = u1;
+                x1 = xo, z1 = zo, u1 = uo;
+#endif
                 xo = xn;
                 zo = active ? zn : 0.0;
                 uo = active ? un : 0.0;
@@ -818,7 +854,7 @@ __global__ __launch_bounds__(NT) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u
             pending = true;
             if (wave == 0) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < NQ; ++q)
                     if (lane + 64 * q < nblk) {
                         const int off = (((it - 2) & 3) * nblk + lane + 64 * q) * 48;
                         pr[q][0] = __builtin_amdgcn_raw_buffer_load_b128(prsrc, off, 0, 16);
@@ -1485,6 +1521,8 @@ struct AdmmRes {
     // "tagged" form (k_lg_admm_tag): v travels as self-validating records, no grid barrier
     bool tagged = false;
     bool wide = false;      // tagged form with 512 threads and up to 16 rows per workgroup (8 of them in registers)
+    bool regs = false;      // tagged form with 512 threads and 16 rows per workgroup, all of them in registers
+    bool regs24 = false;    // ... and eight more in LDS
     lg_u4 *gran = nullptr;  // [2][n] records of 16 bytes
     unsigned next_tag = 0;  // first tag of the next launch (a launch uses max_iter + 1 consecutive ones)
 };
@@ -1534,11 +1572,27 @@ int admm_res_plan(gl_ctx *ctx, int64_t n, AdmmRes &A, bool set_lds_limit = true)
         R = 2 * ADMM_RES_MAXR;
         lds = (size_t)ADMM_RES_MAXR * n * 8;
     }
+    // "regs" (round 4, the default wherever the wide form applies): its sixteen rows ALL in registers -- the multiply reads no
+    // LDS (128 KB per step and workgroup before): 0.467 -> 0.362 ms per node update at n = 2048 (GRAPHLEARN_AMD_LGMRF_REGS = 0 | 1;
+    // 2: eight more rows in LDS, 24 per workgroup)
+    A.regs = A.wide;
+    A.regs24 = false;
+    if (const char *e = getenv("GRAPHLEARN_AMD_LGMRF_REGS")) {
+        A.regs = A.wide && atoi(e) != 0;
+        A.regs24 = A.regs && atoi(e) == 2 && n > 3 * ADMM_RES_MAXR;
+    }
+    if (A.regs) lds = 0;
+    if (A.regs24) {
+        R = 3 * ADMM_RES_MAXR;
+        lds = (size_t)ADMM_RES_MAXR * n * 8;
+    }
     A.R = R;
     A.nwg = (int)((n + R - 1) / R);
     A.lds = lds;
     if (set_lds_limit)
-        GL_HIP(ctx, hipFuncSetAttribute(A.wide     ? (const void *)k_lg_admm_tag<512, 8>
+        GL_HIP(ctx, hipFuncSetAttribute(A.regs24   ? (const void *)k_lg_admm_tag<512, 16, 8>
+                                        : A.regs   ? (const void *)k_lg_admm_tag<512, 16, 0>
+                                        : A.wide   ? (const void *)k_lg_admm_tag<512, 8>
                                         : A.tagged ? (const void *)k_lg_admm_tag<256, 0>
                                                    : (const void *)k_lg_admm_res,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1588,7 +1642,11 @@ int run_admm_res(gl_ctx *ctx, const LgDev &D, AdmmRes &A, int max_iter, int64_t 
         // error word: bar[32], zero since the allocation (a failure ends the use of this form)
         static const int poll_mode = getenv("GRAPHLEARN_AMD_LGMRF_POLL") ? atoi(getenv("GRAPHLEARN_AMD_LGMRF_POLL")) : 0;
         const int flags = (test_not_resident ? 1 : 0) | (poll_mode << 1);
-        if (A.wide)
+        if (A.regs24)
+            k_lg_admm_tag<512, 16, 8><<<dim3((unsigned)A.nwg), 512, A.lds, ctx->stream>>>(D, A.bar + 32, A.gran, tag0, A.R, max_iter, u_fast, flags);
+        else if (A.regs)
+            k_lg_admm_tag<512, 16, 0><<<dim3((unsigned)A.nwg), 512, A.lds, ctx->stream>>>(D, A.bar + 32, A.gran, tag0, A.R, max_iter, u_fast, flags);
+        else if (A.wide)
             k_lg_admm_tag<512, 8><<<dim3((unsigned)A.nwg), 512, A.lds, ctx->stream>>>(D, A.bar + 32, A.gran, tag0, A.R, max_iter, u_fast, flags);
         else
             k_lg_admm_tag<256, 0><<<dim3((unsigned)A.nwg), 256, A.lds, ctx->stream>>>(D, A.bar + 32, A.gran, tag0, A.R, max_iter, u_fast, flags);

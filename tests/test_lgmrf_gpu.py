@@ -25,17 +25,22 @@ import os
 # DESIGN.md section 5 -- run the whole matrix only with GRAPHLEARN_AMD_TEST_ALL=1; by default they keep ONE smoke case each
 # (test_superseded_admm_forms_smoke, below), so the suite's wall time stays inside the driver's step limit.
 ALL_FORMS = os.environ.get("GRAPHLEARN_AMD_TEST_ALL", "0") not in ("", "0")
-SUPERSEDED = ["launch", "one", "resident"]
-FORMS = ["wave", "quad", "tagged", "wide", "auto"] + (SUPERSEDED if ALL_FORMS else [])
+SUPERSEDED = ["launch", "one", "resident"]        # (+ "wide_lds", which only exists from n = 256 on: covered at n = 512 below)
+FORMS = ["wave", "quad", "tagged", "wide", "auto"] + (SUPERSEDED + ["wide_lds"] if ALL_FORMS else [])
 
 
 def set_form(monkeypatch, form):
     monkeypatch.delenv("GRAPHLEARN_AMD_LGMRF_WIDE", raising=False)
+    monkeypatch.delenv("GRAPHLEARN_AMD_LGMRF_REGS", raising=False)
     if form == "auto":
         monkeypatch.delenv("GRAPHLEARN_AMD_LGMRF_ADMM", raising=False)
-    elif form in ("tagged", "wide"):
+    elif form in ("tagged", "wide", "wide_lds"):
+        # "tagged": up to 8 rows per workgroup, in LDS; "wide": 16 rows, all in registers (round 4; the automatic choice from
+        # n = 256 on); "wide_lds": round 2's wide form, 8 of the 16 rows in LDS
         monkeypatch.setenv("GRAPHLEARN_AMD_LGMRF_ADMM", "tagged")
-        monkeypatch.setenv("GRAPHLEARN_AMD_LGMRF_WIDE", "1" if form == "wide" else "0")
+        monkeypatch.setenv("GRAPHLEARN_AMD_LGMRF_WIDE", "0" if form == "tagged" else "1")
+        if form == "wide_lds":
+            monkeypatch.setenv("GRAPHLEARN_AMD_LGMRF_REGS", "0")
     else:
         monkeypatch.setenv("GRAPHLEARN_AMD_LGMRF_ADMM", form)
 
@@ -261,7 +266,7 @@ def test_qp_solver_blocked_inverse_sizes(n):
 
 
 # ------------------------------------------------------------------ BASELINE configs[2] shape
-LARGE_FORMS = ("auto", "tagged", "wide", "resident", "launch")
+LARGE_FORMS = ("auto", "tagged", "wide", "wide_lds", "resident", "launch")
 
 
 def triu_to_square(v, n):
@@ -303,6 +308,25 @@ def test_lgmrf_c3_shape_n512_against_reference_fixture(golden, admm_form, path):
     assert np.abs(m.inv_laplacian_[rows] - g["n512_inv_rows"]).max() <= 1e-6 * np.abs(g["n512_inv_rows"]).max()
     assert np.abs(np.diag(m.inv_laplacian_) - g["n512_inv_diag"]).max() <= 1e-6 * np.abs(g["n512_inv_diag"]).max()
     assert np.array_equal(m.laplacian_, m.laplacian_.T)
+
+
+def test_wide_form_with_rows_in_lds_smoke(golden, admm_form, monkeypatch):
+    """Round 2's wide form (8 of a workgroup's 16 rows in LDS) stays selectable (GRAPHLEARN_AMD_LGMRF_REGS=0) beside round 4's
+    default (all 16 in registers): the n = 512 reference fixture once in every default session, and EQUAL matrices from the
+    two (same columns per thread, same butterflies: the same order of summation)."""
+    if admm_form != "auto":
+        pytest.skip("once per session")
+    g = golden("lgmrf_c3")
+    n = 512
+    cov = c3_covariance(g["n512_x32"])
+    ref = triu_to_square(g["n512_lapl_triu"], n)
+    out = {}
+    for form in ("wide_lds", "wide"):
+        set_form(monkeypatch, form)
+        m = LGMRF(max_cycle=int(g["n512_cycles"])).fit(cov.copy())
+        out[form] = (m.laplacian_, m.inv_laplacian_)
+        assert np.abs(m.laplacian_ - ref).max() / np.abs(ref).max() < 300 * float(g["n512_thread_sensitivity"][0])
+    assert np.array_equal(out["wide"][0], out["wide_lds"][0]) and np.array_equal(out["wide"][1], out["wide_lds"][1])
 
 
 def test_lgmrf_c3_shape_n1024_blow_up_matches_reference(golden, admm_form):
