@@ -208,6 +208,9 @@ def main():
     ap.add_argument("--no-converge", action="store_true")
     ap.add_argument("--converge-maxit", type=int, default=200000)
     ap.add_argument("--no-other-configs", action="store_true", help="skip the LGMRF / GraphDictLog legs (config.other_configs)")
+    ap.add_argument("--comm-timeout", type=float, default=300.0,
+                    help="N > 1: wall-clock bound in seconds of every barrier / reduction / gather (a rank that never arrives "
+                         "ends the run with an error and a non-zero exit code instead of the launcher's kill)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -229,7 +232,8 @@ def main():
 
         # RCCL over xGMI (bootstrap via a /tmp file); a run that cannot bring RCCL up fails instead of
         # quietly timing a gloo gather
-        comm = make_comm(rank, world, local_rank, ctx, allow_fallback=os.environ.get("GRAPHLEARN_AMD_COMM") == "gloo")
+        comm = make_comm(rank, world, local_rank, ctx, allow_fallback=os.environ.get("GRAPHLEARN_AMD_COMM") == "gloo",
+                         timeout_s=args.comm_timeout)
         if getattr(comm, "kind", None) != "rccl" and os.environ.get("GRAPHLEARN_AMD_COMM") != "gloo":
             sys.exit(f"bench.py --gpus {world}: RCCL communicator not available (got {getattr(comm, 'kind', None)})")
     x, _ = logmodel_problem(n, d, seed=rank)

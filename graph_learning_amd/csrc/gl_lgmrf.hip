@@ -367,6 +367,12 @@ constexpr int ADMM_RES_MAXR = 8;
 #ifndef LG_RULE_EARLY
 #define LG_RULE_EARLY 1  // ... the stopping rule of three steps ago is evaluated while the records are on their way (0: after the poll)
 #endif
+#ifndef LG_PROBES
+#define LG_PROBES 1      // ... sweeps of the records a workgroup keeps in flight (2: a second one half a round trip behind)
+#endif
+#ifndef LG_PROBE_GAP
+#define LG_PROBE_GAP 8
+#endif
 #ifndef LG_SELECTIVE
 #define LG_SELECTIVE 1   // ... a retry re-reads only the records that are still missing (0: the whole sweep)
 #endif
@@ -708,6 +714,20 @@ __global__ __launch_bounds__(NT) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u
         rule_of_three_steps_ago();
 #endif
         double vj[CPT];
+#if LG_PROBES == 2
+        // a second sweep in flight, half a round trip behind the first: what a probe finds is decided when it reaches memory
+        lg_u4 gq2[CPT];
+        if (it <= max_iter) {
+            __builtin_amdgcn_s_sleep(LG_PROBE_GAP);
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                const int64_t j = tid + NT * (int64_t)c;
+                gq2[c] = lg_u4{0u, tag, 0u, tag};
+                if (j < n) gq2[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((((it & 1) * n) + j) * 16), 0, 16);
+            }
+            asm volatile("" ::: "memory");
+        }
+#endif
         if (it <= max_iter) {
             const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
             bool good = true;
@@ -716,6 +736,27 @@ __global__ __launch_bounds__(NT) void k_lg_admm_tag(LgDev D, unsigned *err, lg_u
 #pragma unroll
                 for (int c = 0; c < CPT; ++c) ok = ok && gq[c].y == tag && gq[c].w == tag;
                 if (__all(ok)) break;
+#if LG_PROBES == 2
+                {   // the older sweep missed: request it again and look at the younger one meanwhile
+                    lg_u4 t[CPT];
+#pragma unroll
+                    for (int c = 0; c < CPT; ++c) {
+                        const int64_t j = tid + NT * (int64_t)c;
+                        t[c] = gq2[c];
+                        gq2[c] = lg_u4{0u, tag, 0u, tag};
+                        if (j < n) gq2[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((((it & 1) * n) + j) * 16), 0, 16);
+                    }
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int c = 0; c < CPT; ++c) gq[c] = t[c];
+                    if ((spins & 63u) == 63u &&
+                        (gl_ld_u32(err) != 0u || __builtin_amdgcn_s_memrealtime() - t_start > 100000000ull)) {
+                        good = false;
+                        break;
+                    }
+                    continue;
+                }
+#endif
                 // ~0.1 us: leave the fabric to the stores we wait for (development: GRAPHLEARN_AMD_LGMRF_POLL = 1 / 2 / 3)
                 const int pm = test_missing >> 1;
                 if (pm == 0) __builtin_amdgcn_s_sleep(4);

@@ -77,6 +77,9 @@ def test_batched_paths_agree_and_fall_back(golden, engine, monkeypatch):
     np.testing.assert_allclose(out[~near], g["w_converged"][~near], rtol=0, atol=1e-6)
 
 
+_SIZES_ORACLE = {}
+
+
 @pytest.mark.parametrize("rule", ["device", "host"])
 @pytest.mark.parametrize("n,b", [(2, 3), (5, 1), (5, 300), (64, 5), (65, 4), (128, 3), (129, 3), (30, 20), (64, 16),
                                  (100, 32), (128, 20), (128, 32), (256, 8), (300, 5)])
@@ -90,7 +93,9 @@ def test_batched_sizes_against_oracle(n, b, rule, monkeypatch):
     rng = default_rng(100 * n + b)
     e = n * (n - 1) // 2
     z = rng.uniform(0.1, 3.0, size=(b, e))
-    ref, info = old.learn_log_degrees(z, 1.1, 0.9, maxit=400, tol=1e-4, edge_tol=-np.inf, return_info=True)
+    if (n, b) not in _SIZES_ORACLE:      # (the oracle's answer serves both forms of the rule: its 300-graph case alone takes 9 s)
+        _SIZES_ORACLE[(n, b)] = old.learn_log_degrees(z.copy(), 1.1, 0.9, maxit=400, tol=1e-4, edge_tol=-np.inf, return_info=True)
+    ref, info = _SIZES_ORACLE[(n, b)]
     out, got = gsp_learn_graph_log_degrees(z, 1.1, 0.9, maxit=400, tol=1e-4, edge_tol=-np.inf, return_info=True)
     assert got["n_iter"] == info["n_iter"]
     np.testing.assert_allclose(out, ref, rtol=0, atol=1e-10)

@@ -652,10 +652,10 @@ def pick_stopping_iteration(rel, lo, hi):
     raise AssertionError("no usable stopping iteration in the window")
 
 
-@pytest.mark.parametrize("n,iters", [(1200, 200), (2600, 110), (3000, 30)])
+@pytest.mark.parametrize("n,iters", [(1200, 200), (2200, 100), (3000, 30)])
 def test_converge_mode_at_mid_sizes_stops_where_the_oracle_stops(engine, n, iters):
     """VERDICT r03 'missing 2': converge mode on the TILE engine against the oracle's own stopping iteration beyond the
-    golden sizes -- n = 1200 (chunks of 8 row pairs), n = 2600 (16) and n = 3000 (32, ragged) on smooth signals, tol set so
+    golden sizes -- n = 1200 (chunks of 8 row pairs), n = 2200 (16, ragged) and n = 3000 (32, ragged) on smooth signals, tol set so
     that the reference's rule (smooth_learning.py:156-167) fires after some two hundred / eighty / thirty iterations:
     the same stopping iteration, the iterate and the dual variable of THAT iteration to 1e-10, the same ratios."""
     if engine != "resident":
@@ -683,14 +683,14 @@ def test_converge_mode_at_mid_sizes_stops_where_the_oracle_stops(engine, n, iter
     assert r[0] == pytest.approx(rel[K][0], rel=1e-8) and r[1] == pytest.approx(rel[K][1], rel=1e-8)
 
 
-@pytest.mark.parametrize("n", [700, 1200])
+@pytest.mark.parametrize("n", [700, 1000])
 def test_warm_start_that_converges_early_in_a_second_call(engine, n):
     """VERDICT r03 'weak 2': the tile engine looks at the rule with a lag of one iteration while the ratios are far from tol,
     except during the first iterations of a call.  A warm start (edge_init = an almost converged iterate, the dual variable
     restarted from S w: smooth_learning.py:140-144) makes the ratios fall steeply; the first call runs 4 fixed iterations,
     the SECOND call runs to a tol that the oracle meets a few iterations into it: same stopping iteration as the oracle,
     iterate to 1e-10 -- on every engine."""
-    if engine == "small" or (engine == "stream" and n > 1000):
+    if engine == "small" or (engine == "stream" and n > 800):
         pytest.skip("n > 128" if engine == "small" else "the streaming engine at the smaller size")
     x, _ = logmodel_problem(n, 256, seed=3 * n)
     z = old.signal_distances(x)
@@ -747,7 +747,7 @@ def test_round1_resident_engine_smoke(golden, engine, monkeypatch):
     np.testing.assert_allclose(out["resident1"][1], out["stream"][1], rtol=0, atol=1e-12)
 
 
-@pytest.mark.parametrize("n,iters", [(300, 1500), (700, 1000)])
+@pytest.mark.parametrize("n,iters", [(300, 1500), (500, 900)])
 def test_long_converge_calls_run_through_the_dual_gate(engine, monkeypatch, capfd, n, iters):
     """Round 4: a long converge-mode call on the tile engine runs in three launches -- a head with the norms, a middle WITHOUT
     the primal norms that only watches the dual ratio (the rule needs both ratios below tol, smooth_learning.py:166-167, and the
@@ -763,7 +763,7 @@ def test_long_converge_calls_run_through_the_dual_gate(engine, monkeypatch, capf
     try:
         K, tol = pick_stopping_iteration(rel, iters - 1, iters)  # the last iteration, if the ratios are at their minimum there
     except AssertionError:                                       # else the latest earlier one, at the price of a second run
-        K, tol = pick_stopping_iteration(rel, 600, iters)
+        K, tol = pick_stopping_iteration(rel, 2 * iters // 3, iters)
         _, states, _ = oracle_trajectory(zt, K + 1, snaps=(K + 1,))
     assert rel[16][1] > 2 * tol                                   # the dual ratio is well above tol after the head: the gate opens
     out = {}
