@@ -1881,25 +1881,34 @@ __global__ __launch_bounds__(VT) void k_lg_update_c2(LgDev D, int64_t u) {
         s_hi[threadIdx.x] = D.h[i0 + threadIdx.x];
     }
     __syncthreads();
-    for (int64_t j = threadIdx.x; j < n; j += VT) {
-        const double gj = mbeta(j) * kuu, hj = D.h[j];
+    auto entry = [&](int64_t i, int64_t j, double cij, double gi, double hi, double gj, double hj) {
+        if (i == u && j == u) return kuu;
+        if (i == u) return -gj;
+        if (j == u) return -gi;
+        const double m = cij - (hi * hj) / cuu;  // lapl_u_inv (lgmrf.py:186-188)
+        return m + (gi * gj) / kuu;              // Sherman-Morrison (:217-219)
+    };
+    if ((n & 1) == 0) {  // rows start 16-byte aligned: two columns per access
+        for (int64_t j = 2 * (int64_t)threadIdx.x; j < n; j += 2 * VT) {
+            const double gj0 = mbeta(j) * kuu, hj0 = D.h[j], gj1 = mbeta(j + 1) * kuu, hj1 = D.h[j + 1];
 #pragma unroll
-        for (int r = 0; r < LG_RB; ++r) {
-            const int64_t i = i0 + r;
-            if (i >= n) break;
-            const double gi = s_gi[r];
-            double out;
-            if (i == u && j == u)
-                out = kuu;
-            else if (i == u)
-                out = -gj;
-            else if (j == u)
-                out = -gi;
-            else {
-                const double m = D.C[i * n + j] - (s_hi[r] * hj) / cuu;  // lapl_u_inv (lgmrf.py:186-188)
-                out = m + (gi * gj) / kuu;                               // Sherman-Morrison (:217-219)
+            for (int r = 0; r < LG_RB; ++r) {
+                const int64_t i = i0 + r;
+                if (i >= n) break;
+                double2 *p = reinterpret_cast<double2 *>(D.C + i * n + j);
+                const double2 c = *p;
+                *p = double2{entry(i, j, c.x, s_gi[r], s_hi[r], gj0, hj0), entry(i, j + 1, c.y, s_gi[r], s_hi[r], gj1, hj1)};
             }
-            D.C[i * n + j] = out;
+        }
+    } else {
+        for (int64_t j = threadIdx.x; j < n; j += VT) {
+            const double gj = mbeta(j) * kuu, hj = D.h[j];
+#pragma unroll
+            for (int r = 0; r < LG_RB; ++r) {
+                const int64_t i = i0 + r;
+                if (i >= n) break;
+                D.C[i * n + j] = entry(i, j, D.C[i * n + j], s_gi[r], s_hi[r], gj, hj);
+            }
         }
     }
 }
@@ -1921,17 +1930,34 @@ __global__ __launch_bounds__(VT) void k_lg_update_g2(LgDev D, int64_t u, int64_t
     const double det = s11 * s22 - s12 * s21;
     const double i11 = s22 / det, i12 = -s12 / det, i21 = -s21 / det, i22 = s11 / det;  // inverse of S
     const int64_t i0 = (int64_t)blockIdx.x * LG_RB;
-    for (int64_t j = threadIdx.x; j < n; j += VT) {
-        const double gj = D.gcol[j], hj = D.h[j];
+    auto corr = [&](double gi, double hi, double gj, double hj) { return gi * (i11 * hj + i12 * gj) + hi * (i21 * hj + i22 * gj); };  // [g_i h_i] S^-1 [h_j ; g_j]
+    if ((n & 1) == 0) {  // rows start 16-byte aligned: two columns per access
+        for (int64_t j = 2 * (int64_t)threadIdx.x; j < n; j += 2 * VT) {
+            const double gj0 = D.gcol[j], hj0 = D.h[j], gj1 = D.gcol[j + 1], hj1 = D.h[j + 1];
 #pragma unroll
-        for (int r = 0; r < LG_RB; ++r) {
-            const int64_t i = i0 + r;
-            if (i >= n) break;
-            const double gi = D.gcol[i], hi = D.h[i];
-            const double corr = gi * (i11 * hj + i12 * gj) + hi * (i21 * hj + i22 * gj);  // [g_i h_i] S^-1 [h_j ; g_j]
-            const double gn = D.G[i * n + j] - corr;
-            D.G[i * n + j] = gn;
-            if (j == u_next) D.gcol_next[i] = gn;
+            for (int r = 0; r < LG_RB; ++r) {
+                const int64_t i = i0 + r;
+                if (i >= n) break;
+                const double gi = D.gcol[i], hi = D.h[i];
+                double2 *p = reinterpret_cast<double2 *>(D.G + i * n + j);
+                const double2 g = *p;
+                const double2 gn = double2{g.x - corr(gi, hi, gj0, hj0), g.y - corr(gi, hi, gj1, hj1)};
+                *p = gn;
+                if (j == u_next) D.gcol_next[i] = gn.x;
+                if (j + 1 == u_next) D.gcol_next[i] = gn.y;
+            }
+        }
+    } else {
+        for (int64_t j = threadIdx.x; j < n; j += VT) {
+            const double gj = D.gcol[j], hj = D.h[j];
+#pragma unroll
+            for (int r = 0; r < LG_RB; ++r) {
+                const int64_t i = i0 + r;
+                if (i >= n) break;
+                const double gn = D.G[i * n + j] - corr(D.gcol[i], D.h[i], gj, hj);
+                D.G[i * n + j] = gn;
+                if (j == u_next) D.gcol_next[i] = gn;
+            }
         }
     }
 }

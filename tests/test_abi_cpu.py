@@ -77,7 +77,8 @@ def test_no_device_fails_loudly(built):
 def test_product_never_imports_the_oracle():
     """oracle/ is test infrastructure: nothing under graph_learning_amd/ may reference it."""
     pkg = os.path.join(ROOT, "graph_learning_amd")
-    for dirpath, _, files in os.walk(pkg):
+    for dirpath, dirs, files in os.walk(pkg):
+        dirs[:] = [d for d in dirs if d != "build"]      # (build artefacts, variant builds: not product source)
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
