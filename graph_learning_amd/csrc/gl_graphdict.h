@@ -21,6 +21,7 @@ struct GdDev {
     double *WS;       // n_pad x n_pad x KP
     double *C;        // K x T: coefficients_, reference layout (repeated over windows)
     double *CT;       // Tp x KP: the same, sample-major, zero padded
+    float *WSf, *CTf; // fp32 mirrors of WS / CT while the contractions run in fp32 (else NULL): every writer of WS / CT keeps them
     double *Cw;       // KP x Tw: new window coefficients of the running step
     double *dual;     // Tw x n
     double *deg;      // KP x n_pad: S W' of the current weights
@@ -57,6 +58,10 @@ struct gl_graphdict {
     hipGraphExec_t step_graph[4] = {nullptr, nullptr, nullptr, nullptr};  // [2 * fit_mode + parity]
     int step_parity = 0;  // which of (deg, deg_new) is current: flips with every step
     double *dbgbuf = nullptr;  // tuning aid (GD_EXP & 8): 4 doubles per wave of k_gd_grad_w
+    // side branch of a step: the folds that only need the coefficient gradient's partials and the dual variable run beside
+    // the weight gradient (GRAPHLEARN_AMD_GD_FORK=1; measured without gain, off by default)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // small engine (gl_graphdict_small.hip): result words + history of a run, on the device
     double *small_hist = nullptr;
     int64_t small_hist_steps = 0;

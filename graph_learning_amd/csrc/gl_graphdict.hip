@@ -261,6 +261,7 @@ __global__ void k_gd_logc_reset(GdDev P) {
         for (int k = 0; k < P.K; ++k) {
             P.C[(int64_t)k * P.T + t] = P.log_c;
             P.CT[t * P.KP + k] = P.log_c;
+            if (P.CTf) P.CTf[t * P.KP + k] = (float)P.log_c;
         }
 }
 
@@ -285,17 +286,28 @@ __device__ __forceinline__ void gd_sc_reduce_body(const GdDev &P, const int bx) 
 // ------------------------------------------------------------------------------------------
 // coefficient update (base_model.py:373-401), one wave per window
 template <int KP>
-__device__ __forceinline__ void gd_coef_update_body(const GdDev &P, const int bx) {
+__device__ __forceinline__ void gd_coef_update_body(const GdDev &P, const int tw, const int lane) {
     if (P.stat[5] != 0.0) return;
-    const int lane = threadIdx.x, tw = bx;
     // adjoint term  W @ (S' dual')  ==  <S W_k, dual_tw>   (log_model.py:33-34)
     double dt[KP];
 #pragma unroll
     for (int k = 0; k < KP; ++k) dt[k] = 0.0;
-    for (int i = lane; i < P.n; i += 64) {
-        const double dv = P.dual[(int64_t)tw * P.n + i];
+    // (the loads of G x 64 nodes in flight: one node group per round trip it was n / 64 dependent round trips a wave)
+    constexpr int G = KP >= 16 ? 2 : 4;
+    for (int i0 = 0; i0 < P.n; i0 += 64 * G) {
+        double dv[G], dg[G][KP];
 #pragma unroll
-        for (int k = 0; k < KP; ++k) dt[k] += P.deg[(int64_t)k * P.n_pad + i] * dv;  // rows k >= K are zero
+        for (int r = 0; r < G; ++r) {
+            const int i = i0 + r * 64 + lane, ic = min(i, P.n - 1);
+            const double v = P.dual[(int64_t)tw * P.n + ic];
+            dv[r] = i < P.n ? v : 0.0;  // (past the last node: exact zeros, added to sums that x + 0.0 leaves alone)
+#pragma unroll
+            for (int k = 0; k < KP; ++k) dg[r][k] = P.deg[(int64_t)k * P.n_pad + ic];  // rows k >= K are zero
+        }
+#pragma unroll
+        for (int r = 0; r < G; ++r)
+#pragma unroll
+            for (int k = 0; k < KP; ++k) dt[k] += dg[r][k] * dv[r];
     }
 #pragma unroll
     for (int k = 0; k < KP; ++k) dt[k] = gd_wave_sum(dt[k]);
@@ -349,18 +361,53 @@ __device__ __forceinline__ void gd_coef_finish_body(const GdDev &P) {
 
 // ------------------------------------------------------------------------------------------
 // M[k][i] = sum_t C[k,t] dual[t / W, i]  (log_model.py:36-37: C @ (S' dual_rep')' = S'(C @ dual_rep) pairwise)
-__global__ __launch_bounds__(64) void k_gd_m(GdDev P, int tchunk) {
+template <int KP>
+__global__ __launch_bounds__(256) void k_gd_m(GdDev P, int tchunk) {
     if (P.stat[5] != 0.0) return;
-    const int i = blockIdx.x * 64 + threadIdx.x, ms = blockIdx.y;
-    double acc[GD_MAXK];
-    for (int k = 0; k < P.K; ++k) acc[k] = 0.0;
-    const int tA = ms * tchunk, tB = min(P.T, tA + tchunk);
-    if (i < P.n)
-        for (int t = tA; t < tB; ++t) {
-            const double dv = P.dual[(int64_t)(t / P.W) * P.n + i];
-            for (int k = 0; k < P.K; ++k) acc[k] += P.CT[(int64_t)t * P.KP + k] * dv;
+    // one wave per (64 nodes, sample chunk), four chunks per workgroup.  Per 32 samples a wave stages their coefficients
+    // (sample-major: one contiguous piece of CT) in its own corner of LDS and reads them back as broadcasts; eight
+    // samples' loads of the dual variable in flight, the K sums in registers, no branch inside.  (Round 4: before, a
+    // runtime K indexed the sums in scratch; a first templated form came out as a branch and a vmcnt(0) per
+    // (sample, atom): 35 us for 33.5 MB either way.)
+    __shared__ double s_ct[4][32 * KP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane, ms = blockIdx.y * 4 + wv;
+    if (ms >= P.MS) return;  // (whole waves; no workgroup barrier below)
+    const int ii = min(i, P.n - 1);
+    double acc[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) acc[k] = 0.0;
+    const int tA = min(P.T, ms * tchunk), tB = min(P.T, tA + tchunk);
+    const double *__restrict__ dual = P.dual;
+    const double *__restrict__ CT = P.CT;
+    double *ct = s_ct[wv];
+    for (int t0 = tA; t0 < tB; t0 += 32) {
+        const int cnt = min(32, tB - t0) * KP;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < KP / 2; ++r) {
+            const int idx = r * 64 + lane;
+            const double v = idx < cnt ? CT[(int64_t)t0 * KP + idx] : 0.0;
+            ct[idx] = (idx & (KP - 1)) < P.K ? v : 0.0;  // samples past the chunk and atoms past K add exact zeros
         }
-    for (int k = 0; k < P.K; ++k) P.MSL[((int64_t)ms * P.KP + k) * P.n_pad + i] = i < P.n ? acc[k] : 0.0;
+        __builtin_amdgcn_wave_barrier();
+        for (int j0 = 0; j0 < 32 && t0 + j0 < tB; j0 += 8) {
+            double dl[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int t = t0 + j0 + j;
+                const double v = dual[(int64_t)(min(t, tB - 1) / P.W) * P.n + ii];
+                dl[j] = t < tB ? v : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int k = 0; k < KP; ++k) acc[k] += ct[(j0 + j) * KP + k] * dl[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KP; ++k) P.MSL[((int64_t)ms * KP + k) * P.n_pad + i] = i < P.n ? acc[k] : 0.0;
 }
 __device__ __forceinline__ void gd_m_reduce_body(const GdDev &P, const int bx) {
     if (P.stat[5] != 0.0) return;
@@ -381,27 +428,50 @@ __device__ __forceinline__ void gd_m_reduce_body(const GdDev &P, const int bx) {
 // ------------------------------------------------------------------------------------------
 // weight update (base_model.py:444-461): one wave per (row i, column block); in place
 template <int KP>
-__device__ __forceinline__ void gd_weight_update_body(const GdDev &P, const int jb, const int i, const int nbj) {
+__device__ __forceinline__ void gd_weight_update_body(const GdDev &P, const int jb, const int i, const int nbj, const int lane) {
+    if (jb * 64 + 63 <= i) {  // (a column block on or below the diagonal's row: nothing to update, nothing to load)
+        if (lane == 0) {
+            double *o = P.wpart + ((int64_t)i * nbj + jb) * 3;
+            o[0] = o[1] = o[2] = 0.0;
+        }
+        return;
+    }
     if (P.stat[5] != 0.0) return;
-    const int lane = threadIdx.x;
     const int j = jb * 64 + lane;
     double num = 0, den = 0, wmax = 0;
-    if (jb * 64 + 63 > i && j > i && j < P.n) {
+    if (j > i && j < P.n) {
         double *w = P.WS + ((int64_t)i * P.n_pad + j) * KP;
-        double wo[KP], g[KP];
+        double wo[KP], g[KP], mi[KP], mj[KP];
+        // Everything the update reads is requested before anything is used (round 4: the slabs came one round trip
+        // after the other and the two dual terms of every atom one after the other: twelve dependent round trips a wave).
 #pragma unroll
         for (int k = 0; k < KP; k += 2) {  // 16-byte accesses: a lane owns KP contiguous doubles
             const double2 v = *reinterpret_cast<const double2 *>(w + k);
             wo[k] = v.x, wo[k + 1] = v.y;
             g[k] = g[k + 1] = 0.0;
         }
-        for (int ts = 0; ts < P.TS; ++ts) {
-            const double *gp = P.GS + (((int64_t)ts * P.n_pad + i) * P.n_pad + j) * KP;
 #pragma unroll
-            for (int k = 0; k < KP; k += 2) {
-                const double2 v = *reinterpret_cast<const double2 *>(gp + k);
-                g[k] += v.x, g[k + 1] += v.y;
+        for (int k = 0; k < KP; ++k) {
+            mi[k] = P.M[(int64_t)k * P.n_pad + i];
+            mj[k] = P.M[(int64_t)k * P.n_pad + j];
+        }
+        for (int ts0 = 0; ts0 < P.TS; ts0 += 4) {  // four slabs in flight; added in the order of the slabs
+            double2 gv[4][KP / 2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (ts0 + u < P.TS) {
+                    const double *gp = P.GS + (((int64_t)(ts0 + u) * P.n_pad + i) * P.n_pad + j) * KP;
+#pragma unroll
+                    for (int k = 0; k < KP; k += 2) gv[u][k / 2] = *reinterpret_cast<const double2 *>(gp + k);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < KP; k += 2) gv[u][k / 2] = double2{0.0, 0.0};  // (g is never -0.0: adding +0.0 changes nothing)
+                }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < KP; k += 2) g[k] += gv[u][k / 2].x, g[k + 1] += gv[u][k / 2].y;
         }
         double wsum = 0.0;
 #pragma unroll
@@ -412,7 +482,7 @@ __device__ __forceinline__ void gd_weight_update_body(const GdDev &P, const int 
         for (int k = 0; k < KP; ++k) {
             double gk = g[k] + P.l1_w * Tn;                                       // :448
             if (P.ortho_w > 0) gk += P.ortho_w * Tn * (wsum - wo[k]);             // :450-451
-            const double dterm = P.M[(int64_t)k * P.n_pad + i] + P.M[(int64_t)k * P.n_pad + j];
+            const double dterm = mi[k] + mj[k];
             double v = wo[k] - P.step_w / Tn * (dterm + gk);                      // :456
             v = v < 0 ? 0.0 : v;                                                  // :459
             wn[k] = k < P.K ? v : 0.0;
@@ -424,6 +494,12 @@ __device__ __forceinline__ void gd_weight_update_body(const GdDev &P, const int 
         }
 #pragma unroll
         for (int k = 0; k < KP; k += 2) *reinterpret_cast<double2 *>(w + k) = double2{wn[k], wn[k + 1]};
+        if (P.WSf) {  // the fp32 mirror the next step's contractions read (round 4: a pass of its own over all of WS before)
+            float *wf = P.WSf + ((int64_t)i * P.n_pad + j) * KP;
+#pragma unroll
+            for (int k = 0; k < KP; k += 4)
+                *reinterpret_cast<float4 *>(wf + k) = float4{(float)wn[k], (float)wn[k + 1], (float)wn[k + 2], (float)wn[k + 3]};
+        }
     }
     num = gd_wave_sum(num);
     den = gd_wave_sum(den);
@@ -442,10 +518,25 @@ __device__ __forceinline__ void gd_weight_finish_body(const GdDev &P, const int6
     __shared__ double s_a[NT], s_b[NT], s_c[NT];
     const int tid = threadIdx.x;
     double num = 0, den = 0, mx = 0;
-    for (int64_t q = tid; q < nparts; q += NT) {
-        num += P.wpart[3 * q];
-        den += P.wpart[3 * q + 1];
-        mx = fmax(mx, P.wpart[3 * q + 2]);
+    // (one workgroup folds n x n / 64 partials: eight entries' loads in flight, added in the order they always were)
+    const double *__restrict__ wp = P.wpart;
+    for (int64_t q0 = tid; q0 < nparts; q0 += 8 * NT) {
+        double a[8], b[8], c[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t q = q0 + (int64_t)j * NT;
+            const bool in = q < nparts;
+            a[j] = in ? wp[3 * q] : 0.0;
+            b[j] = in ? wp[3 * q + 1] : 0.0;
+            c[j] = in ? wp[3 * q + 2] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (q0 + (int64_t)j * NT < nparts) {
+                num += a[j];
+                den += b[j];
+                mx = fmax(mx, c[j]);
+            }
     }
     s_a[tid] = num;
     s_b[tid] = den;
@@ -463,20 +554,28 @@ __device__ __forceinline__ void gd_weight_finish_body(const GdDev &P, const int6
 }
 
 // degrees S W_k' of the weights in WS: one wave per node
+template <int KP>
 __device__ __forceinline__ void gd_degree_body(const GdDev &P, double *__restrict__ out, const int chk_done, const int v, const int lane) {
     if (chk_done && P.stat[5] != 0.0) return;
     if (v >= P.n_pad) return;  // a wave past the last node (four nodes per block in k_gd_finish3)
-    double acc[GD_MAXK];
-    for (int k = 0; k < P.K; ++k) acc[k] = 0.0;
+    // (KP is the compile-time stride of an entry's atoms: with the runtime K the sums were indexed in scratch)
+    double acc[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) acc[k] = 0.0;
     if (v < P.n)
         for (int u = lane; u < P.n; u += 64) {
             if (u == v) continue;
-            const double *p = u < v ? P.WS + ((int64_t)u * P.n_pad + v) * P.KP : P.WS + ((int64_t)v * P.n_pad + u) * P.KP;
-            for (int k = 0; k < P.K; ++k) acc[k] += p[k];
+            const double *p = u < v ? P.WS + ((int64_t)u * P.n_pad + v) * KP : P.WS + ((int64_t)v * P.n_pad + u) * KP;
+#pragma unroll
+            for (int k = 0; k < KP; k += 2) {  // (16-byte accesses: an entry's KP atoms are contiguous and 16-byte aligned)
+                const double2 w = *reinterpret_cast<const double2 *>(p + k);
+                acc[k] += w.x, acc[k + 1] += w.y;
+            }
         }
-    for (int k = 0; k < P.K; ++k) {
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
         const double s = gd_wave_sum(acc[k]);
-        if (lane == 0) out[(int64_t)k * P.n_pad + v] = s;
+        if (lane == 0 && k < P.K) out[(int64_t)k * P.n_pad + v] = s;
     }
 }
 
@@ -493,24 +592,30 @@ __global__ __launch_bounds__(256) void k_gd_reduce2(GdDev P, int nsc) {  // bloc
 }
 template <int KP>
 __global__ __launch_bounds__(64) void k_gd_coef_update(GdDev P) {
-    gd_coef_update_body<KP>(P, (int)blockIdx.x);
+    gd_coef_update_body<KP>(P, (int)blockIdx.x, (int)threadIdx.x);
 }
+// four waves per workgroup, a window or a (row, column block) each: blocks [0, ceil(Tw / 4)) take the windows, the
+// others (row i, column blocks 4 q .. 4 q + 3)
 template <int KP>
-__global__ __launch_bounds__(64) void k_gd_update2(GdDev P, int nbj) {  // blocks [0, Tw): windows, then (column block, row)
-    const int b = (int)blockIdx.x;
-    if (b < P.Tw) {
-        gd_coef_update_body<KP>(P, b);
+__global__ __launch_bounds__(256) void k_gd_update2(GdDev P, int nbj, int cblocks) {
+    const int b = (int)blockIdx.x, wv = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    if (b < cblocks) {
+        const int tw = b * 4 + wv;
+        if (tw < P.Tw) gd_coef_update_body<KP>(P, tw, lane);
     } else {
-        const int r = b - P.Tw;
-        gd_weight_update_body<KP>(P, r % nbj, r / nbj, nbj);
+        const int nq = (nbj + 3) / 4, r = b - cblocks;
+        const int jb = (r % nq) * 4 + wv, i = r / nq;
+        if (jb < nbj) gd_weight_update_body<KP>(P, jb, i, nbj, lane);
     }
 }
 __global__ __launch_bounds__(256) void k_gd_coef_finish(GdDev P) { gd_coef_finish_body(P); }
+template <int KP>
 __global__ __launch_bounds__(64) void k_gd_degree(GdDev P, double *__restrict__ out, int chk_done) {
-    gd_degree_body(P, out, chk_done, (int)blockIdx.x, (int)threadIdx.x);
+    gd_degree_body<KP>(P, out, chk_done, (int)blockIdx.x, (int)threadIdx.x);
 }
 // block 0: all-zero guard of the coefficients; block 1: relative change of the weights; then four nodes'
 // degrees per block
+template <int KP>
 __global__ __launch_bounds__(256) void k_gd_finish3(GdDev P, int64_t nparts, double *__restrict__ deg_out) {
     const int b = (int)blockIdx.x;
     if (b == 0)
@@ -518,15 +623,25 @@ __global__ __launch_bounds__(256) void k_gd_finish3(GdDev P, int64_t nparts, dou
     else if (b == 1)
         gd_weight_finish_body<256>(P, nparts);
     else
-        gd_degree_body(P, deg_out, 1, (b - 2) * 4 + ((int)threadIdx.x >> 6), (int)threadIdx.x & 63);
+        gd_degree_body<KP>(P, deg_out, 1, (b - 2) * 4 + ((int)threadIdx.x >> 6), (int)threadIdx.x & 63);
 }
 
 // ------------------------------------------------------------------------------------------
 // dual update (log_model.py:39-50) with the overshoot 2 new - old of weights and coefficients
 // (base_model.py:509-514).  fixed_weights: predict() passes the weights themselves (:665-669).
 template <int KP>
-__global__ void k_gd_dual_update(GdDev P, int fixed_weights) {
+__global__ __launch_bounds__(256) void k_gd_dual_update(GdDev P, int fixed_weights) {
     if (P.stat[5] != 0.0) return;
+    // the overshoot coefficients 2 new - old of this workgroup's 8 windows, once per workgroup (round 4: every thread used
+    // to fetch the 2 x K of every window itself, window after window, each window's load of the dual variable behind the
+    // previous window's store: 46 us for 67 MB of traffic)
+    __shared__ double s_cf[8][KP];
+    const int tw0 = blockIdx.y * 8;
+    if (threadIdx.x < 8 * KP) {
+        const int w = threadIdx.x / KP, k = threadIdx.x % KP, tw = tw0 + w;
+        s_cf[w][k] = (k < P.K && tw < P.Tw) ? 2.0 * P.Cw[(int64_t)k * P.Tw + tw] - P.C[(int64_t)k * P.T + (int64_t)tw * P.W] : 0.0;
+    }
+    __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
     double dv[KP];  // overshoot degrees of node i, shared by the 8 windows of this thread
@@ -536,13 +651,19 @@ __global__ void k_gd_dual_update(GdDev P, int fixed_weights) {
         dv[k] = fixed_weights ? dold : 2.0 * dn - dold;
     }
     const double sigma = P.step_dual;
-    for (int tw = blockIdx.y * 8; tw < min(P.Tw, (int)blockIdx.y * 8 + 8); ++tw) {
+    double *__restrict__ dual = P.dual;
+    double dl[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) dl[w] = tw0 + w < P.Tw ? dual[(int64_t)(tw0 + w) * P.n + i] : 0.0;  // all eight in flight
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        if (tw0 + w >= P.Tw) break;
         double step = 0.0;
 #pragma unroll
         for (int k = 0; k < KP; ++k)
-            if (k < P.K) step += dv[k] * (2.0 * P.Cw[(int64_t)k * P.Tw + tw] - P.C[(int64_t)k * P.T + (int64_t)tw * P.W]);
-        const double d = P.dual[(int64_t)tw * P.n + i] + sigma * step;
-        P.dual[(int64_t)tw * P.n + i] = (d - sqrt(d * d + 4.0 * sigma)) / 2.0;
+            if (k < P.K) step += dv[k] * s_cf[w][k];
+        const double d = dl[w] + sigma * step;
+        dual[(int64_t)(tw0 + w) * P.n + i] = (d - sqrt(d * d + 4.0 * sigma)) / 2.0;
     }
 }
 
@@ -561,6 +682,7 @@ __global__ __launch_bounds__(256) void k_gd_coef_commit(GdDev P) {
         omax = fmax(omax, fabs(o));
         P.C[q] = nw;
         P.CT[t * P.KP + k] = nw;
+        if (P.CTf) P.CTf[t * P.KP + k] = (float)nw;
     }
     s_a[tid] = num;
     s_b[tid] = den;
@@ -680,13 +802,21 @@ int gd_alloc(gl_graphdict *s, T **p, size_t count) {
     return GL_OK;
 }
 
+// fp32 mirrors of the state from scratch (a new state, a switch of precision); the steps keep them from there
+void gd_refresh_f32(gl_graphdict *s) {
+    const GdDev &P = s->dev;
+    if (!s->f32 || !s->have_state) return;
+    hipStream_t st = s->ctx->stream;
+    const int64_t cw = (int64_t)P.n_pad * P.n_pad * P.KP, cc = (int64_t)P.Tp * P.KP;
+    k_gd_to_f32<<<dim3((unsigned)std::min<int64_t>(4096, (cw + 255) / 256)), 256, 0, st>>>(P.WS, s->WSf, cw, nullptr);
+    k_gd_to_f32<<<dim3((unsigned)std::min<int64_t>(1024, (cc + 255) / 256)), 256, 0, st>>>(P.CT, s->CTf, cc, nullptr);
+}
+
 int gd_launch_grad_c(gl_graphdict *s) {
     const GdDev &P = s->dev;
     dim3 grid((unsigned)(P.Tp / GD_SB), (unsigned)P.NG);
     hipStream_t st = s->ctx->stream;
-    if (s->f32) {  // the weights changed in the last step: refresh their fp32 copy
-        const int64_t cnt = (int64_t)P.n_pad * P.n_pad * P.KP;
-        k_gd_to_f32<<<dim3((unsigned)std::min<int64_t>(4096, (cnt + 255) / 256)), 256, 0, st>>>(P.WS, s->WSf, cnt, P.stat + 5);
+    if (s->f32) {  // (WSf is kept by the weight update)
         switch (P.KP) {
             case 4: k_gd_grad_c<float, 4, 2><<<grid, 64, 0, st>>>(s->XTf, s->WSf, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5); break;
             case 8: k_gd_grad_c<float, 8, 2><<<grid, 64, 0, st>>>(s->XTf, s->WSf, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5); break;
@@ -727,9 +857,7 @@ int gd_launch_grad_w(gl_graphdict *s) {
     const int tchunk = (P.Tp + P.TS - 1) / P.TS;
     hipStream_t st = s->ctx->stream;
     dim3 grid((unsigned)(P.nwtasks * P.TS));
-    if (s->f32) {  // the coefficients changed in the last step: refresh their fp32 copy
-        const int64_t cnt = (int64_t)P.Tp * P.KP;
-        k_gd_to_f32<<<dim3((unsigned)std::min<int64_t>(1024, (cnt + 255) / 256)), 256, 0, st>>>(P.CT, s->CTf, cnt, P.stat + 5);
+    if (s->f32) {  // (CTf is kept by k_gd_coef_commit)
         switch (P.KP) {
             case 4: k_gd_grad_w<float, 4, 8><<<grid, 256, 0, st>>>(s->Xf, s->CTf, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, s->dbgbuf, P.stat + 5); break;
             case 8: k_gd_grad_w<float, 8, 8><<<grid, 256, 0, st>>>(s->Xf, s->CTf, P.GS, P.wtasks, P.nwtasks, P.n_pad, P.Tp, tchunk, s->dbgbuf, P.stat + 5); break;
@@ -748,31 +876,72 @@ int gd_launch_grad_w(gl_graphdict *s) {
 }
 
 int gd_degrees(gl_graphdict *s, double *out, int chk_done = 0) {
-    k_gd_degree<<<dim3((unsigned)s->dev.n), 64, 0, s->ctx->stream>>>(s->dev, out, chk_done);
+    switch (s->dev.KP) {
+        case 4: k_gd_degree<4><<<dim3((unsigned)s->dev.n), 64, 0, s->ctx->stream>>>(s->dev, out, chk_done); break;
+        case 8: k_gd_degree<8><<<dim3((unsigned)s->dev.n), 64, 0, s->ctx->stream>>>(s->dev, out, chk_done); break;
+        default: k_gd_degree<16><<<dim3((unsigned)s->dev.n), 64, 0, s->ctx->stream>>>(s->dev, out, chk_done); break;
+    }
     GL_HIP(s->ctx, hipGetLastError());
     return GL_OK;
 }
 
 // one primal-dual step (base_model.py:485-527); the relative changes land in stat[0..1]
+int gd_side_branch(gl_graphdict *s) {  // (outside any capture)
+    // (measured at K = 8, n = 1024, T = 4096: 1.006 ms per step with the branch, 1.007 without -- the folds stretch to the
+    //  length of the kernel beside them and that one slows by as much: opt-in)
+    if (s->side || !getenv("GRAPHLEARN_AMD_GD_FORK") || atoi(getenv("GRAPHLEARN_AMD_GD_FORK")) == 0) return GL_OK;
+    gl_ctx *ctx = s->ctx;
+    GL_HIP(ctx, hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+    GL_HIP(ctx, hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+    GL_HIP(ctx, hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+    return GL_OK;
+}
+
 int gd_step(gl_graphdict *s, int fit_mode = 0) {
     gl_ctx *ctx = s->ctx;
     GdDev &P = s->dev;
     hipStream_t st = ctx->stream;
     if (P.log_c > 0) k_gd_logc_reset<<<dim3((unsigned)((P.Tw + 255) / 256)), 256, 0, st>>>(P);
     GL_TRY(gd_launch_grad_c(s));
-    GL_TRY(gd_launch_grad_w(s));
-    const int mchunk = (P.T + P.MS - 1) / P.MS;
-    k_gd_m<<<dim3((unsigned)(P.n_pad / 64), (unsigned)P.MS), 64, 0, st>>>(P, mchunk);
-    const int nsc = (int)(((int64_t)P.KP * P.Tp + 63) / 64), nmr = (int)(((int64_t)P.KP * P.n_pad + 63) / 64);
-    k_gd_reduce2<<<dim3((unsigned)(nsc + nmr)), dim3(64, 4), 0, st>>>(P, nsc);
-    const int nbj = P.n_pad / 64;
-    const dim3 gu((unsigned)(P.Tw + nbj * P.n));
-    switch (P.KP) {
-        case 4: k_gd_update2<4><<<gu, 64, 0, st>>>(P, nbj); break;
-        case 8: k_gd_update2<8><<<gu, 64, 0, st>>>(P, nbj); break;
-        default: k_gd_update2<16><<<gu, 64, 0, st>>>(P, nbj); break;
+    // C @ dual and the two folds need the coefficient gradient's partials, the coefficients and the dual variable -- not the
+    // weight gradient: they run beside it on a branch of their own (bandwidth- and latency-bound beside a kernel that
+    // is neither).  Inside a capture the events become the graph's edges.
+    hipStream_t sb = st;
+    if (s->side) {
+        GL_HIP(ctx, hipEventRecord(s->ev_fork, st));
+        GL_HIP(ctx, hipStreamWaitEvent(s->side, s->ev_fork, 0));
+        sb = s->side;
     }
-    k_gd_finish3<<<dim3((unsigned)(2 + (P.n + 3) / 4)), 256, 0, st>>>(P, (int64_t)P.n * nbj, P.deg_new);
+    const int mchunk = (P.T + P.MS - 1) / P.MS;
+    {
+        const dim3 gm((unsigned)(P.n_pad / 64), (unsigned)((P.MS + 3) / 4));
+        switch (P.KP) {
+            case 4: k_gd_m<4><<<gm, 256, 0, sb>>>(P, mchunk); break;
+            case 8: k_gd_m<8><<<gm, 256, 0, sb>>>(P, mchunk); break;
+            default: k_gd_m<16><<<gm, 256, 0, sb>>>(P, mchunk); break;
+        }
+    }
+    const int nsc = (int)(((int64_t)P.KP * P.Tp + 63) / 64), nmr = (int)(((int64_t)P.KP * P.n_pad + 63) / 64);
+    k_gd_reduce2<<<dim3((unsigned)(nsc + nmr)), dim3(64, 4), 0, sb>>>(P, nsc);
+    if (s->side) GL_HIP(ctx, hipEventRecord(s->ev_join, s->side));
+    GL_TRY(gd_launch_grad_w(s));
+    if (s->side) GL_HIP(ctx, hipStreamWaitEvent(st, s->ev_join, 0));
+    const int nbj = P.n_pad / 64;
+    const int cblocks = (P.Tw + 3) / 4;
+    const dim3 gu((unsigned)(cblocks + (nbj + 3) / 4 * P.n));
+    switch (P.KP) {
+        case 4: k_gd_update2<4><<<gu, 256, 0, st>>>(P, nbj, cblocks); break;
+        case 8: k_gd_update2<8><<<gu, 256, 0, st>>>(P, nbj, cblocks); break;
+        default: k_gd_update2<16><<<gu, 256, 0, st>>>(P, nbj, cblocks); break;
+    }
+    {
+        const dim3 gf((unsigned)(2 + (P.n + 3) / 4));
+        switch (P.KP) {
+            case 4: k_gd_finish3<4><<<gf, 256, 0, st>>>(P, (int64_t)P.n * nbj, P.deg_new); break;
+            case 8: k_gd_finish3<8><<<gf, 256, 0, st>>>(P, (int64_t)P.n * nbj, P.deg_new); break;
+            default: k_gd_finish3<16><<<gf, 256, 0, st>>>(P, (int64_t)P.n * nbj, P.deg_new); break;
+        }
+    }
     gd_launch_dual_update(P, st, 0);
     const int cb = gd_commit_blocks(P);
     k_gd_coef_commit<<<dim3((unsigned)cb), 256, 0, st>>>(P);
@@ -789,6 +958,7 @@ int gd_step(gl_graphdict *s, int fit_mode = 0) {
 int gd_step_replayed(gl_graphdict *s, int fit_mode) {
     gl_ctx *ctx = s->ctx;
     GdDev &P = s->dev;
+    GL_TRY(gd_side_branch(s));
     if (getenv("GRAPHLEARN_AMD_NO_GRAPH")) return gd_step(s, fit_mode);
     const int par = s->step_parity;
     hipGraphExec_t &exec = s->step_graph[2 * fit_mode + par];
@@ -905,6 +1075,12 @@ GL_API void gl_graphdict_destroy(gl_graphdict *s) {
         (void)hipStreamSynchronize(s->ctx->stream);
     }
     gd_drop_graphs(s);
+    if (s->side) {
+        (void)hipStreamSynchronize(s->side);
+        (void)hipEventDestroy(s->ev_fork);
+        (void)hipEventDestroy(s->ev_join);
+        (void)hipStreamDestroy(s->side);
+    }
     for (void *p : s->allocs) (void)hipFree(p);
     delete s;
 }
@@ -949,9 +1125,10 @@ GL_API int gl_graphdict_set_state(gl_graphdict *s, const double *coefficients, c
     else
         GL_HIP(ctx, hipMemsetAsync(P.dual, 0, (size_t)P.Tw * P.n * 8, ctx->stream));
     GL_TRY(gd_degrees(s, P.deg));
+    s->have_state = true;
+    gd_refresh_f32(s);
     GL_HIP(ctx, hipGetLastError());
     GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    s->have_state = true;
     return GL_OK;
 }
 
@@ -1012,6 +1189,10 @@ GL_API int gl_graphdict_set_precision(gl_graphdict *s, int bits) {
     }
     if (s->f32 != (bits == 32)) gd_drop_graphs(s);  // the captured steps launch the other instantiations
     s->f32 = bits == 32;
+    P.WSf = s->f32 ? s->WSf : nullptr;
+    P.CTf = s->f32 ? s->CTf : nullptr;
+    gd_refresh_f32(s);
+    GL_HIP(ctx, hipGetLastError());
     return GL_OK;
 }
 

@@ -1799,6 +1799,15 @@ GL_API int gl_logdeg_get_weights_condensed(gl_logdeg *s, double edge_tol, double
 // The thresholded iterates of B sessions (same context, same n) in one go: B conversions into one device
 // buffer, ONE copy, ONE synchronisation (a batch of windows otherwise pays a round trip per graph).
 // w_out is B x E, row b = session b (the layout of the reference's edge_w.T, smooth_learning.py:174).
+namespace {
+struct ThetaPtrs {
+    const double *p[32];
+};
+__global__ void k_gather_thetas(ThetaPtrs q, int count, double *__restrict__ out) {
+    if ((int)threadIdx.x < count) out[threadIdx.x] = q.p[threadIdx.x][0];
+}
+}  // namespace
+
 GL_API int gl_logdeg_batch_get_weights(gl_logdeg **sessions, int B, double edge_tol, double *w_out) {
     if (!sessions || B < 1 || !w_out) return GL_E_INVALID;
     for (int a = 0; a < B; ++a) GL_TRY(check(sessions[a]));
@@ -1820,9 +1829,25 @@ GL_API int gl_logdeg_batch_get_weights(gl_logdeg **sessions, int B, double edge_
         k_to_condensed<<<dim3((unsigned)s->dev.ntiles), dim3(256), 0, ctx->stream>>>(s->dev.w[s->it & 1], buf + (size_t)a * E, s->n,
                                                                                   s->dev.nb, edge_tol);
     }
+    // thetas that never left the device (set_signals with a deferred theta) come back with the same synchronisation: a batch of
+    // windows otherwise pays a round trip per window for them afterwards (10 x 20 us for ten windows)
+    constexpr size_t THETA_WORD0 = 4096;  // (word offset in the pinned status area: far behind the kernels' status words)
+    const bool gather = rc == GL_OK && (size_t)B <= (GL_STATUS_BYTES / 8 - THETA_WORD0);
+    for (int a0 = 0; gather && a0 < B; a0 += 32) {
+        ThetaPtrs q{};
+        const int cnt = std::min(32, B - a0);
+        for (int a = 0; a < cnt; ++a) q.p[a] = sessions[a0 + a]->dev.dstat + 4;
+        k_gather_thetas<<<1, 64, 0, ctx->stream>>>(q, cnt, (double *)ctx->pinned_dev + THETA_WORD0 + a0);
+    }
     if (rc == GL_OK && hipGetLastError() != hipSuccess) rc = gl_set_error(ctx, GL_E_HIP, "k_to_condensed launch failed");
     if (rc == GL_OK) rc = gl_d2h(ctx, w_out, buf, (size_t)B * E * 8);
     (void)hipStreamSynchronize(ctx->stream);
+    if (rc == GL_OK && gather)
+        for (int a = 0; a < B; ++a)
+            if (sessions[a]->theta_pending) {
+                sessions[a]->theta = ((const double *)ctx->pinned)[THETA_WORD0 + a];
+                sessions[a]->theta_pending = false;
+            }
     return rc;
 }
 
@@ -2248,6 +2273,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
     // two iterates side by side, which only the launches below keep.
     int64_t cruised = 0;
     bool ring_finished = false;  // the deciding chunks (below) have brought the call to its end
+    bool ring_exact = false;     // ... and ring_rp / ring_rd are the exact ratios of its last iteration
     double ring_rp = std::numeric_limits<double>::infinity(), ring_rd = ring_rp;
     {
         bool same = sessions[0]->it == 0 && maxit >= 64 && !getenv("GRAPHLEARN_AMD_BATCH_NO_CRUISE");
@@ -2278,6 +2304,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
             k_batch_copy_state<<<cgrid, 256, 0, ctx->stream>>>((const LogdegDev *)sc.devs, C, tiled1, D0.n_pad, D0.nb, 0, 0, 0);
             GL_HIP(ctx, hipGetLastError());
             GL_TRY(gl_tile_batch_make_zg(&cs, (const LogdegDev *)sc.devs, B));
+            const auto t_cruise0 = std::chrono::steady_clock::now();
             GL_TRY(gl_tile_launch(&cs, maxit - 1, tol, true, -1));
             int64_t ran = 0;
             bool stopped = false, not_resident = false;
@@ -2291,8 +2318,9 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
             }
             if (getenv("GRAPHLEARN_AMD_BATCH_TEST_OVERSHOOT")) keep = false;  // (test hook: as if the screen had overshot)
             if (getenv("GRAPHLEARN_AMD_BATCH_DEBUG"))
-                fprintf(stderr, "[batch cruise] n %lld B %d: ran %lld of %lld, stopped %d, not resident %d, kept %d\n", (long long)sessions[0]->n, B,
-                        (long long)ran, (long long)(maxit - 1), (int)stopped, (int)not_resident, (int)keep);
+                fprintf(stderr, "[batch cruise] n %lld B %d: ran %lld of %lld in %.2f ms, stopped %d, not resident %d, kept %d\n", (long long)sessions[0]->n, B,
+                        (long long)ran, (long long)(maxit - 1), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_cruise0).count(),
+                        (int)stopped, (int)not_resident, (int)keep);
             if (not_resident) {  // shared GPU: this context's batches stay on the launches below
                 batch_cruise_free(bc);
                 ctx->batch_cruise = nullptr;
@@ -2340,6 +2368,9 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                 const size_t wbytes = (size_t)B * tiled1 * 8, dbytes = (size_t)C.n_pad * 8;
                 const double t2r = tol * tol;
                 int chunks = 0, replays = 0;
+                double ms_run = 0, ms_judge = 0, ms_replay = 0, ms_exact = 0;  // (debug print below)
+                auto now = []() { return std::chrono::steady_clock::now(); };
+                auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
                 // (chunks of 16, 32, then K = 64 iterations: a short deciding stretch wastes little behind its stopping
                 //  iteration, a long one spreads a chunk's fixed cost -- ~150 us -- over many)
                 int kcur = getenv("GRAPHLEARN_AMD_BATCH_RING_K") ? bc->ring_k : std::min(16, bc->ring_k);
@@ -2347,6 +2378,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                     const int Kc = (int)std::min<int64_t>(kcur, maxit - n_done);
                     kcur = std::min(bc->ring_k, 2 * kcur);
                     const int64_t it_ck = cs.it;
+                    auto t_ph = now();
                     GL_HIP(ctx, hipMemcpyAsync(bc->ring, C.w[it_ck & 1], wbytes, hipMemcpyDeviceToDevice, ctx->stream));
                     GL_HIP(ctx, hipMemcpyAsync(bc->dring, C.dvar, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
                     GL_HIP(ctx, hipMemcpyAsync(bc->ckpt, C.ybar, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -2374,6 +2406,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                         break;
                     }
                     ++chunks;
+                    ms_run += since(t_ph), t_ph = now();
                     const dim3 gg(ge + 1, (unsigned)Kc);
                     if (B <= 16)
                         k_batch_gram_ring<1><<<gg, GRAM_WAVES * 64, 0, ctx->stream>>>(bc->ring, bc->dring, B, (int64_t)B * tiled1, tiled1, C.n_pad, D0.n_pad,
@@ -2388,6 +2421,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                     int hit = -1;
                     for (int j = 0; j < Kc && hit < 0; ++j)
                         if (jh->decision[j] != 0) hit = j;
+                    ms_judge += since(t_ph), t_ph = now();
                     if (hit < 0) {  // the whole chunk was short of the rule
                         n_done += Kc;
                         w_old = bc->ring + (size_t)(Kc - 1) * B * tiled1;
@@ -2405,6 +2439,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                         }
                     }
                     n_done += hit + 1;
+                    ms_replay += since(t_ph), t_ph = now();
                     w_old = bc->ring + (size_t)hit * B * tiled1;
                     // the sessions get this state (both iterates), the host forms the exact ratios: met -> done; a tie that was
                     // not met after all -> the chunks go on from here
@@ -2413,14 +2448,18 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                     GL_HIP(ctx, hipGetLastError());
                     for (int a = 0; a < B; ++a) sessions[a]->it = n_done;
                     GL_TRY(exact(ring_rp, ring_rd));
+                    ring_exact = true;
+                    ms_exact += since(t_ph);
                     if (jh->decision[hit] == 3 || (ring_rp < tol && ring_rd < tol)) {
                         ring_finished = true;
                         break;
                     }
+                    ring_exact = false;  // (a tie that was not met: the chunks go on, these ratios go stale)
                 }
                 if (getenv("GRAPHLEARN_AMD_BATCH_DEBUG") && ring_ok)
-                    fprintf(stderr, "[batch ring] %d chunks of up to %d iterations, %d replays, at iteration %lld, finished %d, back to the launches %d\n", chunks,
-                            bc->ring_k, replays, (long long)n_done, (int)ring_finished, (int)back_to_launches);
+                    fprintf(stderr, "[batch ring] %d chunks of up to %d iterations, %d replays, at iteration %lld, finished %d, back to the launches %d; "
+                            "ms: chunks' launches %.2f, judging %.2f, replays %.2f, exact ratios %.2f\n", chunks,
+                            bc->ring_k, replays, (long long)n_done, (int)ring_finished, (int)back_to_launches, ms_run, ms_judge, ms_replay, ms_exact);
                 if (!ring_finished) {  // the budget ran out, or the ring is not available: the sessions take over where the engine stands
                     k_batch_copy_state<<<cgrid, 256, 0, ctx->stream>>>((const LogdegDev *)sc.devs, C, tiled1, D0.n_pad, D0.nb, (int)(n_done & 1), 1,
                                                                        (long long)n_done, w_old);
@@ -2516,6 +2555,11 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
     bool have_exact = false, converged = false;
     int64_t n_iter = cruised;
     const int64_t it0 = sessions[0]->it - cruised;
+    if (ring_finished && ring_exact) {  // (formed where the chunks ended: not a second time below)
+        rp = ring_rp, rd = ring_rd;
+        have_exact = true;
+        converged = rp < tol && rd < tol;
+    }
     while (n_iter < maxit && !ring_finished) {
         const int par0 = (int)((it0 + n_iter) & 1);
         if (use_graph) {

@@ -127,6 +127,9 @@ struct TileDev {
     // both ratios must be below tol) -- and ends (ctr[0] = 2) once it comes below it; the primal norms, a third of the pass,
     // are not formed at all.  0: no gate (a fixed number of iterations).
     double gate;
+    // tuning aid: units of 128 clocks a consumer / an owner sleeps before its first probe (GRAPHLEARN_AMD_TILE_ACQ_SLEEP /
+    // _OWN_SLEEP; 0: none).  A probe that reaches memory just before the record costs a whole round trip more.
+    int acq_sleep, own_sleep;
     long long it0;
     int maxit;
     unsigned tag0;
@@ -821,7 +824,17 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     // norms; lambda_max of a Gram matrix lies in [max diagonal, trace]):  s = {max_g ||dW_g||^2, sum_g ||W_g||^2,
     // max_g ||dD_g||^2, sum_g ||D_g||^2} of local iteration j from the node blocks' norm records -- lane = block, whole graphs
     // per sweep of the wave, every sum in a fixed order.
-    auto screen_of = [&](int j, double (&s)[4]) -> bool {
+    // (pre: the first sweep's records as requested earlier -- screen_request -- or null)
+    auto screen_request = [&](int j, tl_u4 (&r)[4]) {
+        const unsigned tag = P.tag0 + (unsigned)j + 1u;
+        const bool mine = lane < (64 / nb1) * nb1 && lane < P.nb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            r[q] = tl_u4{0u, tag, 0u, tag};
+            if (mine) r[q] = __builtin_amdgcn_raw_buffer_load_b128(r_bn, (((j & 3) * (int)P.nb + lane) * 4 + q) * 16, 0, 16);
+        }
+    };
+    auto screen_of_pre = [&](int j, double (&s)[4], const tl_u4 (&pre)[4], const bool with_pre) -> bool {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         unsigned spins = 0;
         const unsigned tag = P.tag0 + (unsigned)j + 1u;
@@ -832,14 +845,17 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         for (int b0 = 0; b0 < (int)P.nb; b0 += per) {
             const bool mine = lane < per && b0 + lane < P.nb;
             tl_u4 r[4];
+            bool use_pre = with_pre && b0 == 0;
             for (;;) {
                 bool ok = true;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     r[q] = tl_u4{0u, tag, 0u, tag};
-                    if (mine) r[q] = __builtin_amdgcn_raw_buffer_load_b128(r_bn, (((j & 3) * (int)P.nb + b0 + lane) * 4 + q) * 16, 0, 16);
+                    if (use_pre) r[q] = pre[q];
+                    else if (mine) r[q] = __builtin_amdgcn_raw_buffer_load_b128(r_bn, (((j & 3) * (int)P.nb + b0 + lane) * 4 + q) * 16, 0, 16);
                     ok = ok && tl_ok(r[q], tag);
                 }
+                use_pre = false;
                 asm volatile("" ::: "memory");
                 if (__all(ok)) break;
                 if (!tl_spin(spins, t0, err)) return false;
@@ -857,6 +873,12 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             s[2] = fmax(s[2], tl_wave_max(mine ? a2 : 0.0));
         }
         return true;
+    };
+    auto screen_of = [&](int j, double (&s)[4]) -> bool {
+        tl_u4 none[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) none[q] = tl_u4{0u, 0u, 0u, 0u};
+        return screen_of_pre(j, s, none, false);
     };
     // The iterate's way back to memory.  At the end of the call -- or, in a call whose last iteration is known in advance
     // (tol = 0, below the rounds, no norms: what bench.py times), right after the last pass: the stores then drain underneath
@@ -905,6 +927,18 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         // ================= acquire: {gamma d, gamma u} of my node blocks, and the norm records of iteration it - 1 =================
         {
             bool good = true;
+            // (a batch: the records the screen looks at -- a whole iteration old -- are requested in front of the poll for the
+            //  node values, not behind it: the screen's round trip and its arithmetic cost every workgroup 1.7 us per iteration)
+            tl_u4 spre[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) spre[q] = tl_u4{0u, 0u, 0u, 0u};
+            bool have_pre = false;
+            if constexpr (BATCH && !FIRST) {
+                if (want_rule && !last_pass && wave == TW - 1 && it >= 2 && P.it0 + it - 2 >= 1) {
+                    screen_request(it - 2, spre);
+                    have_pre = true;
+                }
+            }
             if (!last_pass) {
                 if constexpr (FIRST) {  // (the state the previous call, or init, left in memory: in s_node since the prologue)
                 } else if (wave < nblk) {
@@ -912,6 +946,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     //  scratch, and most first probes succeed anyway)
                     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                     unsigned spins = 0;
+                    for (int d = P.acq_sleep; d > 0; --d) __builtin_amdgcn_s_sleep(2);
                     tl_u4 g[NACQ][2];
                     auto probe = [&](tl_u4 (&q)[NACQ][2]) {
 #pragma unroll
@@ -990,20 +1025,35 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     // are the host's business from there on.  Should the lower bounds of that very iteration already lie below
                     // tol (a drop of 5 % in one iteration, or a start from a converged iterate) the rule may have held for
                     // an iterate these registers no longer hold: reported (rp = 1), and the caller redoes the run its own way.
-                    good = good && screen_of(it - 1, b);
-                    if (good && P.it0 + it - 1 >= 1) {  // never at iteration 0 (:156-161)
-                        const bool degenerate = !(b[1] > 0) || !(b[3] > 0);
-                        // how far the larger lower bound is above tol (squared): the cruise goes on while it has 5 % to spare
-                        // now AND, extrapolated by its last step's factor, after the next iteration (early in a run, and
-                        // on inputs that converge geometrically, one step is more than 5 %)
-                        const double rk = degenerate ? 0.0 : fmax(b[0] / b[1], b[2] / b[3]) / P.t2lo;
-                        const double next = (screen_prev > rk && screen_prev < INFINITY) ? rk * (rk / screen_prev) : rk;
-                        const bool not_yet = !degenerate && rk > 1.05 * 1.05 && next > 1.05 * 1.05;
-                        screen_prev = rk;
-                        const bool surely_not = !degenerate && (b[0] > P.t2lo * b[1] || b[2] > P.t2lo * b[3]);
-                        stop = not_yet ? 0 : 1;
-                        rp = surely_not ? 0.0 : 1.0;
-                        rd = degenerate ? 0.0 : fmax(b[0] / b[1], b[2] / b[3]);
+                    // Round 4: the look that keeps the cruise going reads the records of iteration it - 2 -- published a whole
+                    // iteration ago, no waiting (the records of it - 1 arrive behind the node values: every workgroup sat
+                    // 1.5-2 us per iteration at this point) -- and extrapolates TWO iterations ahead; the fresh records are
+                    // read once, where the cruise ends, and what is reported covers both iterations the look had not seen.
+                    auto sure = [&](const double (&v)[4]) { return v[1] > 0 && v[3] > 0 && (v[0] > P.t2lo * v[1] || v[2] > P.t2lo * v[3]); };
+                    auto ahead = [&](const double (&v)[4]) {  // the larger lower bound over tol, squared; 0: degenerate
+                        return (v[1] > 0 && v[3] > 0) ? fmax(v[0] / v[1], v[2] / v[3]) / P.t2lo : 0.0;
+                    };
+                    bool end_now = last_pass, lag_sure = true, lag_room = true;
+                    if (it >= 2 && P.it0 + it - 2 >= 1) {  // never at iteration 0 (:156-161)
+                        good = good && screen_of_pre(it - 2, b, spre, have_pre);
+                        if (good) {
+                            const double rk = ahead(b);
+                            const double f = (screen_prev > rk && screen_prev < INFINITY) ? rk / screen_prev : 1.0;
+                            lag_room = rk > 1.05 * 1.05 && rk * f * f > 1.05 * 1.05;
+                            lag_sure = sure(b);
+                            screen_prev = rk;
+                            if (!lag_room) end_now = true;
+                        }
+                    }
+                    if (end_now && good && P.it0 + it - 1 >= 1) {
+                        good = good && screen_of(it - 1, b);
+                        if (good) {
+                            const double rk = ahead(b);
+                            // (the budget ran out with room to spare in both iterations: not a stop)
+                            stop = (last_pass && lag_room && rk > 1.05 * 1.05) ? 0 : 1;
+                            rp = (lag_sure && sure(b)) ? 0.0 : 1.0;
+                            rd = rk * P.t2lo;
+                        }
                     }
                     if (lane == 0) {
                         s_rel[0] = rp;
@@ -1440,6 +1490,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     }
                 };
                 load_gu();
+                for (int d = P.own_sleep; d > 0; --d) __builtin_amdgcn_s_sleep(2);
                 for (int eb = own_e0 + wave; eb < own_e1 && good; eb += TW * RND) {  // rounds of up to RND records per wave
                     tl_u4 g[RND];
                     auto probe = [&](tl_u4 (&q)[RND]) {
@@ -2138,6 +2189,8 @@ int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int fina
     P.dring_stride = t->dring_stride;
     if ((tol > 0 && !(gate > 0 && !norms)) || t->batch) norms = true;
     P.gate = (!norms && tol > 0) ? gate * tol : 0.0;
+    P.acq_sleep = getenv("GRAPHLEARN_AMD_TILE_ACQ_SLEEP") ? std::max(0, std::min(64, atoi(getenv("GRAPHLEARN_AMD_TILE_ACQ_SLEEP")))) : 0;
+    P.own_sleep = getenv("GRAPHLEARN_AMD_TILE_OWN_SLEEP") ? std::max(0, std::min(64, atoi(getenv("GRAPHLEARN_AMD_TILE_OWN_SLEEP")))) : 0;
     P.it0 = s->it;
     P.maxit = (int)std::min<int64_t>(iters, 1 << 30);
     if (t->next_tag == 0u || t->next_tag > 0xE0000000u - (unsigned)P.maxit) {  // the tags would wrap into old ones

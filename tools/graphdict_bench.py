@@ -16,8 +16,9 @@ with _lib.GraphDictSession(n, t, k) as s:
     s.set_signals(x)
     s.set_params(l1_w=0.01, step_c=0.5, step_w=0.5, step_dual=0.5)
     s.set_state(c0, w0)
-    s.fit(2, 0.0)
-    t0 = time.perf_counter(); hist, ran, conv, flags = s.fit(10, 0.0); dt = (time.perf_counter() - t0) / 10
+    steps = int(os.environ.get("GD_STEPS", "50"))
+    s.fit(steps, 0.0)   # (captures the step's graphs for a history of this length: a fit's one-time cost)
+    t0 = time.perf_counter(); hist, ran, conv, flags = s.fit(steps, 0.0); dt = (time.perf_counter() - t0) / steps
     gc, gw = s.time_gradients(5)
     pair_samples = t * e
     lane_ops = pair_samples * (2 + 2 * k)
