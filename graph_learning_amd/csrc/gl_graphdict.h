@@ -29,7 +29,7 @@ struct GdDev {
     double *SC;       // NG x KP x Tp: partial coefficient gradients
     double *SCR;      // KP x Tp: their sum over the strip groups
     double *cnorm;    // 256 x 3: per-workgroup partials of the coefficient change
-    double *GS;       // TS x n_pad x n_pad x KP: partial weight gradients
+    double *GS;       // TS x n_pad x (n_pad / 64) x KP/2 x 64 x 2: partial weight gradients, a column block's atom pair contiguous
     double *MSL;      // MS x KP x n_pad: partial sums of C @ dual
     double *M;        // KP x n_pad
     double *cpart;    // Tw: max |c_new| per window

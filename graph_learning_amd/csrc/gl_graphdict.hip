@@ -240,9 +240,11 @@ __global__ __launch_bounds__(256, 3) void k_gd_grad_w(const T *__restrict__ X, c
                     fold[k] += p.x;
                     fold[k + 1] += p.y;
                 }
-            double *dst = GS + (((int64_t)ts * n_pad + (i0 + a)) * n_pad + j) * KP;
+            // GS[ts][i][column block][k / 2][lane][2]: a store instruction writes 1 KB in one piece (round 4: pair-major, every
+            // instruction wrote 16 bytes into each of 64 lines -- a slab's 67 MB went out, and came back in, as quarter lines)
+            double *dst = GS + ((((int64_t)ts * n_pad + (i0 + a)) * (n_pad / 64) + jb) * (KP / 2)) * 128 + 2 * lane;
 #pragma unroll
-            for (int k = 0; k < KP; k += 2) *reinterpret_cast<double2 *>(dst + k) = double2{fold[k], fold[k + 1]};
+            for (int k = 0; k < KP; k += 2) *reinterpret_cast<double2 *>(dst + (k / 2) * 128) = double2{fold[k], fold[k + 1]};
         }
         __syncthreads();
     }
@@ -428,7 +430,12 @@ __device__ __forceinline__ void gd_m_reduce_body(const GdDev &P, const int bx) {
 // ------------------------------------------------------------------------------------------
 // weight update (base_model.py:444-461): one wave per (row i, column block); in place
 template <int KP>
-__device__ __forceinline__ void gd_weight_update_body(const GdDev &P, const int jb, const int i, const int nbj, const int lane) {
+__device__ __forceinline__ void gd_weight_update_body(const GdDev &P, const int jb, const int i, const int nbj, const int lane,
+                                                      double *__restrict__ s_t) {
+    // s_t: this wave's corner of LDS, 64 rows of KP + 2 doubles.  The weights are pair-major (a pair's KP atoms contiguous: what
+    // the scalar loads of k_gd_grad_c need), so a lane that read and wrote ITS pair touched 16 bytes in each of 64 lines per
+    // instruction; now a wave moves the column block's 64 x KP doubles as whole kilobytes and the rows change hands in LDS
+    // (row stride KP * 8 + 16 bytes: the 16-byte accesses of both views fall on distinct banks).
     if (jb * 64 + 63 <= i) {  // (a column block on or below the diagonal's row: nothing to update, nothing to load)
         if (lane == 0) {
             double *o = P.wpart + ((int64_t)i * nbj + jb) * 3;
@@ -437,68 +444,96 @@ __device__ __forceinline__ void gd_weight_update_body(const GdDev &P, const int 
         return;
     }
     if (P.stat[5] != 0.0) return;
+    constexpr int CPP = KP / 2, RS = KP + 2;  // 16-byte pieces per pair; row stride in doubles
     const int j = jb * 64 + lane;
+    const bool live = j > i && j < P.n;
+    double *wrow = P.WS + ((int64_t)i * P.n_pad + jb * 64) * KP;  // the block's 64 pairs (all inside the padded array)
+    double wo[KP], g[KP], mi[KP], mj[KP];
+    // Everything the update reads is requested before anything is used (round 4: the slabs came one round trip
+    // after the other and the two dual terms of every atom one after the other: twelve dependent round trips a wave).
+    double2 wv[CPP];
+#pragma unroll
+    for (int r = 0; r < CPP; ++r) wv[r] = *reinterpret_cast<const double2 *>(wrow + 2 * (r * 64 + lane));
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        mi[k] = P.M[(int64_t)k * P.n_pad + i];
+        mj[k] = P.M[(int64_t)k * P.n_pad + j];
+        g[k] = 0.0;
+    }
+    for (int ts0 = 0; ts0 < P.TS; ts0 += 4) {  // four slabs in flight; added in the order of the slabs
+        double2 gv[4][KP / 2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (ts0 + u < P.TS) {
+                const double *gp = P.GS + ((((int64_t)(ts0 + u) * P.n_pad + i) * nbj + jb) * (KP / 2)) * 128 + 2 * lane;
+#pragma unroll
+                for (int k = 0; k < KP; k += 2) gv[u][k / 2] = *reinterpret_cast<const double2 *>(gp + (k / 2) * 128);
+            } else {
+#pragma unroll
+                for (int k = 0; k < KP; k += 2) gv[u][k / 2] = double2{0.0, 0.0};  // (g is never -0.0: adding +0.0 changes nothing)
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < KP; k += 2) g[k] += gv[u][k / 2].x, g[k + 1] += gv[u][k / 2].y;
+    }
+    // piece c = r * 64 + lane of the block belongs to pair c / CPP, atoms 2 (c % CPP), 2 (c % CPP) + 1
+#pragma unroll
+    for (int r = 0; r < CPP; ++r) {
+        const int c = r * 64 + lane;
+        *reinterpret_cast<double2 *>(s_t + (c / CPP) * RS + 2 * (c % CPP)) = wv[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < CPP; ++q) {
+        const double2 v = *reinterpret_cast<const double2 *>(s_t + lane * RS + 2 * q);
+        wo[2 * q] = v.x, wo[2 * q + 1] = v.y;
+    }
     double num = 0, den = 0, wmax = 0;
-    if (j > i && j < P.n) {
-        double *w = P.WS + ((int64_t)i * P.n_pad + j) * KP;
-        double wo[KP], g[KP], mi[KP], mj[KP];
-        // Everything the update reads is requested before anything is used (round 4: the slabs came one round trip
-        // after the other and the two dual terms of every atom one after the other: twelve dependent round trips a wave).
+    double wsum = 0.0;
 #pragma unroll
-        for (int k = 0; k < KP; k += 2) {  // 16-byte accesses: a lane owns KP contiguous doubles
-            const double2 v = *reinterpret_cast<const double2 *>(w + k);
-            wo[k] = v.x, wo[k + 1] = v.y;
-            g[k] = g[k + 1] = 0.0;
+    for (int k = 0; k < KP; ++k) wsum += k < P.K ? wo[k] : 0.0;
+    const double Tn = (double)P.T;
+    double wn[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        double gk = g[k] + P.l1_w * Tn;                                       // :448
+        if (P.ortho_w > 0) gk += P.ortho_w * Tn * (wsum - wo[k]);             // :450-451
+        const double dterm = mi[k] + mj[k];
+        double v = wo[k] - P.step_w / Tn * (dterm + gk);                      // :456
+        v = v < 0 ? 0.0 : v;                                                  // :459
+        wn[k] = k < P.K ? v : 0.0;
+        if (live && k < P.K) {
+            num += (v - wo[k]) * (v - wo[k]);
+            den += wo[k] * wo[k];
+            wmax = fmax(wmax, fabs(wo[k]));
         }
+    }
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            mi[k] = P.M[(int64_t)k * P.n_pad + i];
-            mj[k] = P.M[(int64_t)k * P.n_pad + j];
-        }
-        for (int ts0 = 0; ts0 < P.TS; ts0 += 4) {  // four slabs in flight; added in the order of the slabs
-            double2 gv[4][KP / 2];
+    for (int q = 0; q < CPP; ++q) *reinterpret_cast<double2 *>(s_t + lane * RS + 2 * q) = double2{wn[2 * q], wn[2 * q + 1]};
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (ts0 + u < P.TS) {
-                    const double *gp = P.GS + (((int64_t)(ts0 + u) * P.n_pad + i) * P.n_pad + j) * KP;
+    for (int r = 0; r < CPP; ++r) {  // (pairs on or below the diagonal and past the last node keep their zeros: not written)
+        const int c = r * 64 + lane, jp = jb * 64 + c / CPP;
+        const double2 v = *reinterpret_cast<const double2 *>(s_t + (c / CPP) * RS + 2 * (c % CPP));
+        if (jp > i && jp < P.n) *reinterpret_cast<double2 *>(wrow + 2 * c) = v;
+    }
+    if (P.WSf) {  // the fp32 mirror the next step's contractions read (round 4: a pass of its own over all of WS before)
+        constexpr int FPP = KP / 4 > 0 ? KP / 4 : 1, FS = KP + 4;  // 16-byte pieces per pair; row stride in floats
+        float *s_f = reinterpret_cast<float *>(s_t);  // (64 x (KP + 4) floats fit the same corner)
+        float *frow = P.WSf + ((int64_t)i * P.n_pad + jb * 64) * KP;
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int k = 0; k < KP; k += 2) gv[u][k / 2] = *reinterpret_cast<const double2 *>(gp + k);
-                } else {
+        for (int k = 0; k < KP; k += 4)
+            *reinterpret_cast<float4 *>(s_f + lane * FS + k) = float4{(float)wn[k], (float)wn[k + 1], (float)wn[k + 2], (float)wn[k + 3]};
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int k = 0; k < KP; k += 2) gv[u][k / 2] = double2{0.0, 0.0};  // (g is never -0.0: adding +0.0 changes nothing)
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int k = 0; k < KP; k += 2) g[k] += gv[u][k / 2].x, g[k + 1] += gv[u][k / 2].y;
-        }
-        double wsum = 0.0;
-#pragma unroll
-        for (int k = 0; k < KP; ++k) wsum += k < P.K ? wo[k] : 0.0;
-        const double Tn = (double)P.T;
-        double wn[KP];
-#pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            double gk = g[k] + P.l1_w * Tn;                                       // :448
-            if (P.ortho_w > 0) gk += P.ortho_w * Tn * (wsum - wo[k]);             // :450-451
-            const double dterm = mi[k] + mj[k];
-            double v = wo[k] - P.step_w / Tn * (dterm + gk);                      // :456
-            v = v < 0 ? 0.0 : v;                                                  // :459
-            wn[k] = k < P.K ? v : 0.0;
-            if (k < P.K) {
-                num += (v - wo[k]) * (v - wo[k]);
-                den += wo[k] * wo[k];
-                wmax = fmax(wmax, fabs(wo[k]));
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < KP; k += 2) *reinterpret_cast<double2 *>(w + k) = double2{wn[k], wn[k + 1]};
-        if (P.WSf) {  // the fp32 mirror the next step's contractions read (round 4: a pass of its own over all of WS before)
-            float *wf = P.WSf + ((int64_t)i * P.n_pad + j) * KP;
-#pragma unroll
-            for (int k = 0; k < KP; k += 4)
-                *reinterpret_cast<float4 *>(wf + k) = float4{(float)wn[k], (float)wn[k + 1], (float)wn[k + 2], (float)wn[k + 3]};
+        for (int r = 0; r < FPP; ++r) {
+            const int c = r * 64 + lane, jp = jb * 64 + c / FPP;
+            const float4 v = *reinterpret_cast<const float4 *>(s_f + (c / FPP) * FS + 4 * (c % FPP));
+            if (jp > i && jp < P.n) *reinterpret_cast<float4 *>(frow + 4 * c) = v;
         }
     }
     num = gd_wave_sum(num);
@@ -598,6 +633,7 @@ __global__ __launch_bounds__(64) void k_gd_coef_update(GdDev P) {
 // others (row i, column blocks 4 q .. 4 q + 3)
 template <int KP>
 __global__ __launch_bounds__(256) void k_gd_update2(GdDev P, int nbj, int cblocks) {
+    __shared__ double s_t[4][64 * (KP + 2)];  // the weight update's row exchange, a corner per wave
     const int b = (int)blockIdx.x, wv = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     if (b < cblocks) {
         const int tw = b * 4 + wv;
@@ -605,7 +641,7 @@ __global__ __launch_bounds__(256) void k_gd_update2(GdDev P, int nbj, int cblock
     } else {
         const int nq = (nbj + 3) / 4, r = b - cblocks;
         const int jb = (r % nq) * 4 + wv, i = r / nq;
-        if (jb < nbj) gd_weight_update_body<KP>(P, jb, i, nbj, lane);
+        if (jb < nbj) gd_weight_update_body<KP>(P, jb, i, nbj, lane, s_t[wv]);
     }
 }
 __global__ __launch_bounds__(256) void k_gd_coef_finish(GdDev P) { gd_coef_finish_body(P); }

@@ -127,9 +127,6 @@ struct TileDev {
     // both ratios must be below tol) -- and ends (ctr[0] = 2) once it comes below it; the primal norms, a third of the pass,
     // are not formed at all.  0: no gate (a fixed number of iterations).
     double gate;
-    // tuning aid: units of 128 clocks a consumer / an owner sleeps before its first probe (GRAPHLEARN_AMD_TILE_ACQ_SLEEP /
-    // _OWN_SLEEP; 0: none).  A probe that reaches memory just before the record costs a whole round trip more.
-    int acq_sleep, own_sleep;
     long long it0;
     int maxit;
     unsigned tag0;
@@ -171,6 +168,16 @@ __device__ __forceinline__ double tl_wave_max(double v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
     return v;
+}
+
+// a batch's screen of the coupled rule on s = {max_g ||dW_g||^2, sum_g ||W_g||^2, max_g ||dD_g||^2, sum_g ||D_g||^2}: is the rule
+// surely not met; the larger lower bound over tol, squared (0: degenerate).  (Plain functions: as lambdas that capture the
+// kernel's argument block inside other lambdas they made the compiler keep that block -- 330 bytes -- in scratch.)
+__device__ __forceinline__ bool tl_screen_sure(const double (&v)[4], const double t2lo) {
+    return v[1] > 0 && v[3] > 0 && (v[0] > t2lo * v[1] || v[2] > t2lo * v[3]);
+}
+__device__ __forceinline__ double tl_screen_ahead(const double (&v)[4], const double t2lo) {
+    return (v[1] > 0 && v[3] > 0) ? fmax(v[0] / v[1], v[2] / v[3]) / t2lo : 0.0;
 }
 
 // false: give up (error word raised by somebody, or one second without progress)
@@ -550,6 +557,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     __shared__ double s_wn[TW][2];
     __shared__ double s_wcarry[TW];                   // per wave: sum of squares of its current w (the rule's denominator)
     __shared__ int s_flag[4];                         // {rendezvous ok, failed, stop, exact}
+    __shared__ double s_scr[4];                       // a batch's look at the bottom of an iteration (wave RW's own: have, room, sure, figure)
     __shared__ double s_rel[2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -732,6 +740,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         s_flag[1] = 0;
         s_flag[2] = 0;
         s_flag[3] = 0;
+        s_scr[0] = 0.0, s_scr[1] = 1.0, s_scr[2] = 1.0, s_scr[3] = INFINITY;  // (a barrier stands between here and their first use)
     }
     // (Loads and stores of a wave complete out of order with respect to each other on gfx9, so with both kinds pending the
     //  compiler can only wait for vmcnt(0).  The prologue's small stores and loads are therefore drained here, and every
@@ -789,7 +798,6 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     const bool gate_on = !NORMS && !BATCH && P.gate > 0 && P.tol > 0;  // (see TileDev::gate)
     constexpr int QN0 = NORMS ? 0 : 2;  // the norm records there are: all four, or the dual pair only (the gate)
     bool evaluated = false, exact = false;
-    double screen_prev = INFINITY;  // BATCH: the screen's figure of the previous iteration (wave TW - 1)
 
     // (wave TW - 1) one norm record per node block, lane = block
     auto norms_of = [&](int j, double (&b)[4]) -> bool {  // sums of the records of local iteration j
@@ -824,38 +832,28 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     // norms; lambda_max of a Gram matrix lies in [max diagonal, trace]):  s = {max_g ||dW_g||^2, sum_g ||W_g||^2,
     // max_g ||dD_g||^2, sum_g ||D_g||^2} of local iteration j from the node blocks' norm records -- lane = block, whole graphs
     // per sweep of the wave, every sum in a fixed order.
-    // (pre: the first sweep's records as requested earlier -- screen_request -- or null)
-    auto screen_request = [&](int j, tl_u4 (&r)[4]) {
-        const unsigned tag = P.tag0 + (unsigned)j + 1u;
-        const bool mine = lane < (64 / nb1) * nb1 && lane < P.nb;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            r[q] = tl_u4{0u, tag, 0u, tag};
-            if (mine) r[q] = __builtin_amdgcn_raw_buffer_load_b128(r_bn, (((j & 3) * (int)P.nb + lane) * 4 + q) * 16, 0, 16);
-        }
-    };
-    auto screen_of_pre = [&](int j, double (&s)[4], const tl_u4 (&pre)[4], const bool with_pre) -> bool {
+    auto screen_of = [&](int j, double (&s)[4]) __attribute__((always_inline)) -> bool {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         unsigned spins = 0;
         const unsigned tag = P.tag0 + (unsigned)j + 1u;
+        int ls = lane;
+        asm volatile("" : "+v"(ls));  // (what derives from the lane number is formed here and now: hoisted out of the iteration loop, once per copy of this, it lives across the pass -- in scratch)
 #pragma unroll
         for (int q = 0; q < 4; ++q) s[q] = 0.0;
-        const int per = (64 / nb1) * nb1, first = lane - lane % nb1;  // lanes in use per sweep; my graph's first lane
+        const int per = (64 / nb1) * nb1, first = ls - ls % nb1;  // lanes in use per sweep; my graph's first lane
 #pragma unroll 1
         for (int b0 = 0; b0 < (int)P.nb; b0 += per) {
-            const bool mine = lane < per && b0 + lane < P.nb;
+            const bool mine = ls < per && b0 + ls < P.nb;
             tl_u4 r[4];
-            bool use_pre = with_pre && b0 == 0;
             for (;;) {
                 bool ok = true;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     r[q] = tl_u4{0u, tag, 0u, tag};
-                    if (use_pre) r[q] = pre[q];
-                    else if (mine) r[q] = __builtin_amdgcn_raw_buffer_load_b128(r_bn, (((j & 3) * (int)P.nb + b0 + lane) * 4 + q) * 16, 0, 16);
+                    if (mine) r[q] = __builtin_amdgcn_raw_buffer_load_b128(r_bn, (((j & 3) * (int)P.nb + b0 + ls) * 4 + q) * 16, 0, 16);
                     ok = ok && tl_ok(r[q], tag);
                 }
-                use_pre = false;
+
                 asm volatile("" ::: "memory");
                 if (__all(ok)) break;
                 if (!tl_spin(spins, t0, err)) return false;
@@ -863,23 +861,57 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             const double v0 = mine ? tl_val(r[0]) : 0.0, v2 = mine ? tl_val(r[2]) : 0.0;
             s[1] += wave_sum(mine ? tl_val(r[1]) : 0.0);
             s[3] += wave_sum(mine ? tl_val(r[3]) : 0.0);
+            // per-graph sums over the graph's nb1 lanes, then the maximum over the graphs: on the VALU (DPP) where a graph's
+            // lanes are an aligned group of 2, 4, 8 or 16 -- through ds_bpermute the two took ~1 us of dependent LDS round trips
             double a0 = 0.0, a2 = 0.0;
+            if (nb1 == 1) {
+                a0 = v0, a2 = v2;
+            } else if (nb1 == 2 || nb1 == 4 || nb1 == 8 || nb1 == 16) {
+                a0 = v0, a2 = v2;
+                a0 += dpp_mov<DPP_QUAD_XOR1>(a0), a2 += dpp_mov<DPP_QUAD_XOR1>(a2);
+                if (nb1 >= 4) a0 += dpp_mov<DPP_QUAD_XOR2>(a0), a2 += dpp_mov<DPP_QUAD_XOR2>(a2);
+                if (nb1 >= 8) a0 += dpp_mov<DPP_HALF_MIRROR>(a0), a2 += dpp_mov<DPP_HALF_MIRROR>(a2);
+                if (nb1 >= 16) a0 += dpp_mov<DPP_ROW_ROR8>(a0), a2 += dpp_mov<DPP_ROW_ROR8>(a2);
+            } else {
 #pragma unroll 1
-            for (int k = 0; k < nb1; ++k) {
-                a0 += __shfl(v0, first + k);
-                a2 += __shfl(v2, first + k);
+                for (int k = 0; k < nb1; ++k) {
+                    a0 += __shfl(v0, first + k);
+                    a2 += __shfl(v2, first + k);
+                }
             }
-            s[0] = fmax(s[0], tl_wave_max(mine ? a0 : 0.0));
-            s[2] = fmax(s[2], tl_wave_max(mine ? a2 : 0.0));
+            s[0] = fmax(s[0], wave_max(mine ? a0 : 0.0));
+            s[2] = fmax(s[2], wave_max(mine ? a2 : 0.0));
         }
         return true;
     };
-    auto screen_of = [&](int j, double (&s)[4]) -> bool {
-        tl_u4 none[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) none[q] = tl_u4{0u, 0u, 0u, 0u};
-        return screen_of_pre(j, s, none, false);
+    // Round 4: the look that keeps a batch's cruise going costs no workgroup anything at the top of an iteration.  It used to
+    // read the records of iteration it - 1 there -- they arrive behind the node values: every workgroup sat 1.6 us per
+    // iteration (records' round trip + ~1 us of cross-lane arithmetic) between its node values and its pass.  Now wave RW
+    // judges iteration it - 1 at the BOTTOM of iteration it -- its records have been out for a whole pass, and the wave
+    // would only wait: for node values (consumers), for wave 0's update (owners) --, extrapolates TWO iterations ahead, and the
+    // next top only reads what it found.  The fresh records are read once, where the cruise ends; what is reported then
+    // covers both iterations the look had not judged.
+    constexpr int RW = BATCH ? TW - 2 : TW - 1;  // the wave that evaluates the rule (a batch: not the slice's wave)
+    // (its findings wait in LDS -- written and read by wave RW alone, in program order -- not in registers across the pass)
+    auto screen_bottom = [&](const int it) __attribute__((always_inline)) {  // (wave RW of a batch with the rule on)
+        double have = 0.0, room = 1.0, sr = 1.0, fig = s_scr[3];
+        if (it >= 1 && P.it0 + it - 1 >= 1) {  // never at iteration 0 (:156-161)
+            double b[4];
+            if (screen_of(it - 1, b)) {
+                const double rk = tl_screen_ahead(b, P.t2lo);
+                const double f = (fig > rk && fig < INFINITY) ? rk / fig : 1.0;
+                room = (rk > 1.05 * 1.05 && rk * f * f > 1.05 * 1.05) ? 1.0 : 0.0;
+                sr = tl_screen_sure(b, P.t2lo) ? 1.0 : 0.0;
+                fig = rk;
+                have = 1.0;
+            } else if (lane == 0) {
+                s_flag[1] = 1;  // (seen at the next top)
+            }
+        }
+        if (lane == 0) s_scr[0] = have, s_scr[1] = room, s_scr[2] = sr, s_scr[3] = fig;
     };
+
+
     // The iterate's way back to memory.  At the end of the call -- or, in a call whose last iteration is known in advance
     // (tol = 0, below the rounds, no norms: what bench.py times), right after the last pass: the stores then drain underneath
     // the last hand-off instead of after it (3 of the ~33 us a call costs beyond its iterations).
@@ -927,18 +959,6 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         // ================= acquire: {gamma d, gamma u} of my node blocks, and the norm records of iteration it - 1 =================
         {
             bool good = true;
-            // (a batch: the records the screen looks at -- a whole iteration old -- are requested in front of the poll for the
-            //  node values, not behind it: the screen's round trip and its arithmetic cost every workgroup 1.7 us per iteration)
-            tl_u4 spre[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) spre[q] = tl_u4{0u, 0u, 0u, 0u};
-            bool have_pre = false;
-            if constexpr (BATCH && !FIRST) {
-                if (want_rule && !last_pass && wave == TW - 1 && it >= 2 && P.it0 + it - 2 >= 1) {
-                    screen_request(it - 2, spre);
-                    have_pre = true;
-                }
-            }
             if (!last_pass) {
                 if constexpr (FIRST) {  // (the state the previous call, or init, left in memory: in s_node since the prologue)
                 } else if (wave < nblk) {
@@ -946,7 +966,6 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     //  scratch, and most first probes succeed anyway)
                     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                     unsigned spins = 0;
-                    for (int d = P.acq_sleep; d > 0; --d) __builtin_amdgcn_s_sleep(2);
                     tl_u4 g[NACQ][2];
                     auto probe = [&](tl_u4 (&q)[NACQ][2]) {
 #pragma unroll
@@ -1006,7 +1025,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     }
                 }
             }
-            if (want_rule && wave == TW - 1) {
+            if (want_rule && wave == RW) {
                 // The rule of iteration it - 1 needs the norm partials of EVERY owner, i.e. the slowest workgroup of the
                 // chip, every iteration (measured: 1.8 us of 17).  So while the ratios are clearly above tol only the
                 // records of iteration it - 2 are looked at -- published a whole iteration ago, no waiting -- and the exact
@@ -1025,33 +1044,17 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     // are the host's business from there on.  Should the lower bounds of that very iteration already lie below
                     // tol (a drop of 5 % in one iteration, or a start from a converged iterate) the rule may have held for
                     // an iterate these registers no longer hold: reported (rp = 1), and the caller redoes the run its own way.
-                    // Round 4: the look that keeps the cruise going reads the records of iteration it - 2 -- published a whole
-                    // iteration ago, no waiting (the records of it - 1 arrive behind the node values: every workgroup sat
-                    // 1.5-2 us per iteration at this point) -- and extrapolates TWO iterations ahead; the fresh records are
-                    // read once, where the cruise ends, and what is reported covers both iterations the look had not seen.
-                    auto sure = [&](const double (&v)[4]) { return v[1] > 0 && v[3] > 0 && (v[0] > P.t2lo * v[1] || v[2] > P.t2lo * v[3]); };
-                    auto ahead = [&](const double (&v)[4]) {  // the larger lower bound over tol, squared; 0: degenerate
-                        return (v[1] > 0 && v[3] > 0) ? fmax(v[0] / v[1], v[2] / v[3]) / P.t2lo : 0.0;
-                    };
-                    bool end_now = last_pass, lag_sure = true, lag_room = true;
-                    if (it >= 2 && P.it0 + it - 2 >= 1) {  // never at iteration 0 (:156-161)
-                        good = good && screen_of_pre(it - 2, b, spre, have_pre);
-                        if (good) {
-                            const double rk = ahead(b);
-                            const double f = (screen_prev > rk && screen_prev < INFINITY) ? rk / screen_prev : 1.0;
-                            lag_room = rk > 1.05 * 1.05 && rk * f * f > 1.05 * 1.05;
-                            lag_sure = sure(b);
-                            screen_prev = rk;
-                            if (!lag_room) end_now = true;
-                        }
-                    }
+                    // (round 4: the look itself sits at the bottom of the previous iteration -- screen_bottom)
+                    const bool scr_have = s_scr[0] != 0.0;
+                    const bool lag_sure = !scr_have || s_scr[2] != 0.0, lag_room = !scr_have || s_scr[1] != 0.0;
+                    const bool end_now = last_pass || !lag_room;
                     if (end_now && good && P.it0 + it - 1 >= 1) {
                         good = good && screen_of(it - 1, b);
                         if (good) {
-                            const double rk = ahead(b);
+                            const double rk = tl_screen_ahead(b, P.t2lo);
                             // (the budget ran out with room to spare in both iterations: not a stop)
                             stop = (last_pass && lag_room && rk > 1.05 * 1.05) ? 0 : 1;
-                            rp = (lag_sure && sure(b)) ? 0.0 : 1.0;
+                            rp = (lag_sure && tl_screen_sure(b, P.t2lo)) ? 0.0 : 1.0;
                             rd = rk * P.t2lo;
                         }
                     }
@@ -1490,7 +1493,6 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     }
                 };
                 load_gu();
-                for (int d = P.own_sleep; d > 0; --d) __builtin_amdgcn_s_sleep(2);
                 for (int eb = own_e0 + wave; eb < own_e1 && good; eb += TW * RND) {  // rounds of up to RND records per wave
                     tl_u4 g[RND];
                     auto probe = [&](tl_u4 (&q)[RND]) {
@@ -1655,6 +1657,15 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             }
             tl_barrier();  // s_own has been read: s_part is free for the next pass (its zeros first, below)
             if (U < SLOTS) s_part[wave][0][lane] = 0.0;  // s_own overwrote row vectors: back to zero outside the chunks' rows
+        }
+        if constexpr (BATCH) {
+            // A batch's look at iteration it - 1 for the next top (screen_bottom), at the very end of the iteration: the workgroup's
+            // other waves go on to poll for node values, which are a hand-off away -- for consumers since their records went
+            // out, for owners since wave 0 stored its own -- and meet this wave at the barrier behind that poll.  (Other places
+            // tried: in front of an owner's poll for its records it held the barrier behind that poll back, 0.85 us per
+            // iteration.  The lambdas of the look are always_inline: left to the inliner's judgement the kernel's argument block
+            // -- captured by reference two lambdas deep -- stayed in scratch, 450-720 bytes.)
+            if (rule_on && wave == RW) screen_bottom(it);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see the prologue (by now everything has long completed)
         if (it == 0) call_stamp(3);  // end of the first iteration
@@ -2189,8 +2200,6 @@ int gl_tile_launch(gl_logdeg *s, int64_t iters, double tol, bool norms, int fina
     P.dring_stride = t->dring_stride;
     if ((tol > 0 && !(gate > 0 && !norms)) || t->batch) norms = true;
     P.gate = (!norms && tol > 0) ? gate * tol : 0.0;
-    P.acq_sleep = getenv("GRAPHLEARN_AMD_TILE_ACQ_SLEEP") ? std::max(0, std::min(64, atoi(getenv("GRAPHLEARN_AMD_TILE_ACQ_SLEEP")))) : 0;
-    P.own_sleep = getenv("GRAPHLEARN_AMD_TILE_OWN_SLEEP") ? std::max(0, std::min(64, atoi(getenv("GRAPHLEARN_AMD_TILE_OWN_SLEEP")))) : 0;
     P.it0 = s->it;
     P.maxit = (int)std::min<int64_t>(iters, 1 << 30);
     if (t->next_tag == 0u || t->next_tag > 0xE0000000u - (unsigned)P.maxit) {  // the tags would wrap into old ones
