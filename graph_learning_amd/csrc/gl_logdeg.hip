@@ -2341,10 +2341,11 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                 const auto t_ring0 = std::chrono::steady_clock::now();
                 if (ring_ok && !bc->ring_arena) {
                     int K = getenv("GRAPHLEARN_AMD_BATCH_RING_K") ? std::max(2, std::min(64, atoi(getenv("GRAPHLEARN_AMD_BATCH_RING_K")))) : 64;
-                    const size_t slot = (size_t)B * tiled1 * 8, dslot = (size_t)C.n_pad * 8;
+                    // (a slot of the dual ring: {d, ybar, pbar, dprev} of the whole lattice and the node blocks' four norm partials)
+                    const size_t slot = (size_t)B * tiled1 * 8, dslot = (size_t)(4 * C.n_pad + 4 * C.nb) * 8;
                     while (K > 4 && (K + 1) * slot > ((size_t)3 << 30)) K /= 2;
                     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
-                    const size_t b_ring = up((K + 1) * slot), b_dring = up((K + 1) * dslot), b_ck = up(3 * dslot);
+                    const size_t b_ring = up((K + 1) * slot), b_dring = up((K + 1) * dslot), b_ck = 0;
                     const size_t b_part = up((size_t)K * (ge + 1) * 2 * nbk * 256 * 8), b_j = up(sizeof(RingJudge));
                     if (gl_ctx_malloc(ctx, &bc->ring_arena, b_ring + b_dring + b_ck + b_part + b_j, "ring") == hipSuccess) {
                         char *at = (char *)bc->ring_arena;
@@ -2368,6 +2369,8 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                 const size_t wbytes = (size_t)B * tiled1 * 8, dbytes = (size_t)C.n_pad * 8;
                 const double t2r = tol * tol;
                 int chunks = 0, replays = 0;
+                const size_t dstride = (size_t)4 * C.n_pad + 4 * C.nb;  // doubles per slot of the dual ring
+                const bool replay_hits = getenv("GRAPHLEARN_AMD_BATCH_REPLAY") != nullptr;
                 double ms_run = 0, ms_judge = 0, ms_replay = 0, ms_exact = 0;  // (debug print below)
                 auto now = []() { return std::chrono::steady_clock::now(); };
                 auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
@@ -2380,11 +2383,24 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                     const int64_t it_ck = cs.it;
                     auto t_ph = now();
                     GL_HIP(ctx, hipMemcpyAsync(bc->ring, C.w[it_ck & 1], wbytes, hipMemcpyDeviceToDevice, ctx->stream));
+                    // the dual state of ring slot q -> the stand-in session (its norm partials belong to iteration `itn - 1`); slot 0 is
+                    // the chunk's start, slot q the state after q of its iterations
+                    auto dual_from_slot = [&](int q, int64_t itn, bool with_norms) -> int {
+                        const double *dr = bc->dring + (size_t)q * dstride;
+                        GL_HIP(ctx, hipMemcpyAsync(C.dvar, dr, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
+                        GL_HIP(ctx, hipMemcpyAsync(C.ybar, dr + C.n_pad, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
+                        GL_HIP(ctx, hipMemcpyAsync(C.pbar, dr + 2 * C.n_pad, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
+                        GL_HIP(ctx, hipMemcpyAsync(C.dprev, dr + 3 * C.n_pad, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
+                        if (with_norms)
+                            GL_HIP(ctx, hipMemcpyAsync(C.bnorm + ((itn - 1) & 1) * 4 * C.nb, dr + 4 * C.n_pad, (size_t)4 * C.nb * 8, hipMemcpyDeviceToDevice,
+                                                       ctx->stream));
+                        return GL_OK;
+                    };
                     GL_HIP(ctx, hipMemcpyAsync(bc->dring, C.dvar, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
-                    GL_HIP(ctx, hipMemcpyAsync(bc->ckpt, C.ybar, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
-                    GL_HIP(ctx, hipMemcpyAsync(bc->ckpt + C.n_pad, C.pbar, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
-                    GL_HIP(ctx, hipMemcpyAsync(bc->ckpt + 2 * C.n_pad, C.dprev, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
-                    gl_tile_batch_set_ring(&cs, bc->ring, (int64_t)B * tiled1, bc->dring, C.n_pad);
+                    GL_HIP(ctx, hipMemcpyAsync(bc->dring + C.n_pad, C.ybar, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
+                    GL_HIP(ctx, hipMemcpyAsync(bc->dring + 2 * C.n_pad, C.pbar, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
+                    GL_HIP(ctx, hipMemcpyAsync(bc->dring + 3 * C.n_pad, C.dprev, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
+                    gl_tile_batch_set_ring(&cs, bc->ring, (int64_t)B * tiled1, bc->dring, (int64_t)dstride);
                     GL_TRY(gl_tile_launch(&cs, Kc, 0.0, true, -1));
                     gl_tile_batch_set_ring(&cs, nullptr, 0, nullptr, 0);
                     int64_t got = 0;
@@ -2393,11 +2409,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                     auto restore = [&]() -> int {  // the chunk's start
                         cs.it = it_ck;
                         GL_HIP(ctx, hipMemcpyAsync(C.w[it_ck & 1], bc->ring, wbytes, hipMemcpyDeviceToDevice, ctx->stream));
-                        GL_HIP(ctx, hipMemcpyAsync(C.dvar, bc->dring, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
-                        GL_HIP(ctx, hipMemcpyAsync(C.ybar, bc->ckpt, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
-                        GL_HIP(ctx, hipMemcpyAsync(C.pbar, bc->ckpt + C.n_pad, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
-                        GL_HIP(ctx, hipMemcpyAsync(C.dprev, bc->ckpt + 2 * C.n_pad, dbytes, hipMemcpyDeviceToDevice, ctx->stream));
-                        return GL_OK;
+                        return dual_from_slot(0, it_ck, false);
                     };
                     // (the workgroups did not meet: nothing was written; the launches below go on from here.  Test hook: as if)
                     if (nr2 || got != Kc || (chunks == 1 && getenv("GRAPHLEARN_AMD_BATCH_TEST_RING_FAIL"))) {
@@ -2409,10 +2421,10 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                     ms_run += since(t_ph), t_ph = now();
                     const dim3 gg(ge + 1, (unsigned)Kc);
                     if (B <= 16)
-                        k_batch_gram_ring<1><<<gg, GRAM_WAVES * 64, 0, ctx->stream>>>(bc->ring, bc->dring, B, (int64_t)B * tiled1, tiled1, C.n_pad, D0.n_pad,
+                        k_batch_gram_ring<1><<<gg, GRAM_WAVES * 64, 0, ctx->stream>>>(bc->ring, bc->dring, B, (int64_t)B * tiled1, tiled1, (int64_t)dstride, D0.n_pad,
                                                                                       bc->gpart, t2r, bc->judge);
                     else
-                        k_batch_gram_ring<2><<<gg, GRAM_WAVES * 64, 0, ctx->stream>>>(bc->ring, bc->dring, B, (int64_t)B * tiled1, tiled1, C.n_pad, D0.n_pad,
+                        k_batch_gram_ring<2><<<gg, GRAM_WAVES * 64, 0, ctx->stream>>>(bc->ring, bc->dring, B, (int64_t)B * tiled1, tiled1, (int64_t)dstride, D0.n_pad,
                                                                                       bc->gpart, t2r, bc->judge);
                     GL_HIP(ctx, hipGetLastError());
                     RingJudge *jh = (RingJudge *)((char *)ctx->pinned + GL_STATUS_BYTES);
@@ -2427,7 +2439,14 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                         w_old = bc->ring + (size_t)(Kc - 1) * B * tiled1;
                         continue;
                     }
-                    if (hit + 1 < Kc) {  // the state after iteration `hit`: from the chunk's start, hit + 1 iterations
+                    if (hit + 1 < Kc && !replay_hits) {
+                        // The state after iteration `hit` is in the rings (round 4: the iterate always was; the dual state -- ybar, pbar,
+                        // dprev, the norm partials beside d -- was not, and a launch of hit + 1 iterations from the chunk's start rebuilt
+                        // it: 54 iterations, 0.36 ms of a 6.5 ms WindowLogModel fit).  GRAPHLEARN_AMD_BATCH_REPLAY=1: the old way.
+                        cs.it = it_ck + hit + 1;
+                        GL_HIP(ctx, hipMemcpyAsync(C.w[cs.it & 1], bc->ring + (size_t)(hit + 1) * B * tiled1, wbytes, hipMemcpyDeviceToDevice, ctx->stream));
+                        GL_TRY(dual_from_slot(hit + 1, cs.it, true));
+                    } else if (hit + 1 < Kc) {  // the state after iteration `hit`: from the chunk's start, hit + 1 iterations
                         GL_TRY(restore());
                         GL_TRY(gl_tile_launch(&cs, hit + 1, 0.0, true, -1));
                         GL_TRY(gl_resident_finish(&cs, &got, &st2, &nr2));

@@ -139,7 +139,7 @@ struct TileDev {
     double t2lo;          // the coupled rule's screen: tol^2 (1 + 1e-9)
     // ... and, where the exact coupled rule is judged afterwards (gl_logdeg.hip: the deciding chunks): every iteration's new
     // iterate is also written out, iteration it of the call to slot it + 1 of a ring of whole tiled batches (slot 0: the
-    // call's start, by the host) and its dual variable to the same slot of dring; null: not
+    // call's start, by the host) and its dual state {d, ybar, pbar, dprev, norm partials} to the same slot of dring; null: not
     double *ring, *dring;
     int64_t ring_stride, dring_stride;  // doubles per slot
 };
@@ -1462,6 +1462,10 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             }
         };
         if (own < 0) early_look();
+        if constexpr (BATCH) {
+            // A batch's look at iteration it - 1 for the next top (screen_bottom).  A consumer would only wait for node values now.
+            if (own < 0 && rule_on && wave == RW) screen_bottom(it);
+        }
 
         // ================= node phase: the owner of a block sums its records and updates the dual state =================
         if (own >= 0) {
@@ -1598,7 +1602,14 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 s_dual[3][ln] = d_cur;
                 s_dual[0][ln] = d_new;
                 if constexpr (BATCH) {
-                    if (P.dring) P.dring[(int64_t)(it + 1) * P.dring_stride + (int64_t)own * TB + ln] = d_new;
+                    if (P.dring) {  // the dual state after this iteration, as the end of a call would leave it: {d, ybar, pbar, dprev}
+                        double *ds = P.dring + (int64_t)(it + 1) * P.dring_stride + (int64_t)own * TB + ln;
+                        const int64_t np = (int64_t)P.nb * TB;
+                        ds[0] = d_new;
+                        ds[np] = real ? ybn : 0.0;
+                        ds[2 * np] = pb_new;
+                        ds[3 * np] = d_cur;
+                    }
                 }
                 s_dual[1][ln] = real ? ybn : 0.0;
                 s_dual[2][ln] = pb_new;
@@ -1617,8 +1628,20 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                         const double v = ln == 2 ? dq2 : d2;
                         s_bn[ln] = v;
                         __builtin_amdgcn_raw_buffer_store_b128(tl_gran(v, tag_out), r_bn, ((((it & 3) * (int)P.nb + own) * 4) + ln) * 16, 0, 16);
+                        if constexpr (BATCH) {  // (... and its norm partials, behind the four vectors)
+                            if (P.dring) P.dring[(int64_t)(it + 1) * P.dring_stride + 4 * (int64_t)P.nb * TB + 4 * own + ln] = v;
+                        }
                     }
                 }
+            } else if (BATCH && rule_on && wave == RW) {
+                // An owner's look: beside wave 0's update and wave TW - 1's slice.  The node values leave on time; the workgroup itself
+                // reaches its next top a few tenths of a microsecond later, where it waits a hand-off for the other owners' values
+                // anyway.  (Measured elsewhere: in front of the owner's poll for its records the look held the barrier behind that
+                // poll back -- 6.4 us per iteration at n = 256, B = 10; at the very end of the iteration it held the next top's
+                // barrier back -- 6.7; at the top itself it was 7.1; 5.3 without the rule.  The lambdas of the look are always_inline:
+                // left to the inliner's judgement the kernel's argument block -- captured by reference two lambdas deep -- stayed
+                // in scratch, 450-720 bytes.)
+                screen_bottom(it);
             } else if (NORMS && wave == TW - 1) {
                 // my slice of the workgroups' norm records (workgroups own, own + nb, ...), beside wave 0's update and off the
                 // owner's critical path (in front of the barrier above it cost 0.5-1 us per iteration: the node values of
@@ -1653,19 +1676,13 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     const double v = l2 == 0 ? n0 : n1;
                     s_bn[l2] = v;
                     __builtin_amdgcn_raw_buffer_store_b128(tl_gran(v, tag_out), r_bn, ((((it & 3) * (int)P.nb + own) * 4) + l2) * 16, 0, 16);
+                    if constexpr (BATCH) {
+                        if (P.dring) P.dring[(int64_t)(it + 1) * P.dring_stride + 4 * (int64_t)P.nb * TB + 4 * own + l2] = v;
+                    }
                 }
             }
             tl_barrier();  // s_own has been read: s_part is free for the next pass (its zeros first, below)
             if (U < SLOTS) s_part[wave][0][lane] = 0.0;  // s_own overwrote row vectors: back to zero outside the chunks' rows
-        }
-        if constexpr (BATCH) {
-            // A batch's look at iteration it - 1 for the next top (screen_bottom), at the very end of the iteration: the workgroup's
-            // other waves go on to poll for node values, which are a hand-off away -- for consumers since their records went
-            // out, for owners since wave 0 stored its own -- and meet this wave at the barrier behind that poll.  (Other places
-            // tried: in front of an owner's poll for its records it held the barrier behind that poll back, 0.85 us per
-            // iteration.  The lambdas of the look are always_inline: left to the inliner's judgement the kernel's argument block
-            // -- captured by reference two lambdas deep -- stayed in scratch, 450-720 bytes.)
-            if (rule_on && wave == RW) screen_bottom(it);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see the prologue (by now everything has long completed)
         if (it == 0) call_stamp(3);  // end of the first iteration

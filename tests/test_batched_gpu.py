@@ -282,3 +282,50 @@ def test_batch_gram_entry_point():
     for got, want in zip(gram, (dw @ dw.T, np.array(prev_w) @ np.array(prev_w).T, dd @ dd.T,
                                 np.array(prev_d) @ np.array(prev_d).T)):
         np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-14)
+
+
+def test_stopping_state_comes_out_of_the_rings_not_out_of_a_replay(monkeypatch, capfd):
+    """Where a deciding chunk is stopped in mid-chunk the state of the stopping iteration -- iterate, dual variable, ybar, pbar,
+    dprev and the node blocks' norm partials -- is read back from the rings the chunk wrote (round 4); before, a launch of exactly
+    that many iterations from the chunk's start rebuilt it (GRAPHLEARN_AMD_BATCH_REPLAY=1).  Both ways must leave the sessions
+    in the same state bit for bit: the weights, the dual variable, and -- what only shows when a session goes on alone, with
+    its own lagged rule reading those norm partials -- every later iterate and the iteration a continued run stops at."""
+    from graph_learning_amd import _lib
+    from graph_learning_amd.batched import _run_sessions
+
+    n, b = 256, 6
+    e = n * (n - 1) // 2
+    rng = default_rng(11)
+    z = rng.uniform(0.05, 4.0, size=(1, e)) * rng.uniform(0.9, 1.1, size=(b, e))   # (one pattern: a long deciding stretch)
+    ctx = _lib.default_context()
+    results = {}
+    for mode in ("rings", "replay"):
+        if mode == "replay":
+            monkeypatch.setenv("GRAPHLEARN_AMD_BATCH_REPLAY", "1")
+        monkeypatch.setenv("GRAPHLEARN_AMD_BATCH_DEBUG", "1")
+        sessions = [_lib.LogDegreeSession(n, ctx) for _ in range(b)]
+        try:
+            for s, zz in zip(sessions, z):
+                s.set_distances(zz)
+                s.init(1.0, 1.0, 0.5, None)
+            out, info = _run_sessions(sessions, ctx, 5000, 1e-5, -np.inf)
+            err = capfd.readouterr().err
+            ring = [l for l in err.splitlines() if l.startswith("[batch ring]")]
+            assert len(ring) == 1 and "finished 1" in ring[0], err
+            assert (" 0 replays" in ring[0]) == (mode == "rings"), ring[0]
+            duals = [s.dual() for s in sessions]
+            cont = [s.iterate(400, 2e-6) for s in sessions]           # each graph goes on alone, with its own rule
+            later = [s.weights_condensed() for s in sessions]
+        finally:
+            for s in sessions:
+                s.close()
+        results[mode] = (out, info, duals, cont, later)
+    a, r = results["rings"], results["replay"]
+    assert a[1] == r[1] and np.array_equal(a[0], r[0])
+    ref, oinfo = old.learn_log_degrees(z, 1.0, 1.0, maxit=5000, tol=1e-5, edge_tol=-np.inf, return_info=True)
+    assert a[1]["n_iter"] == oinfo["n_iter"]
+    np.testing.assert_allclose(a[0], ref, rtol=0, atol=1e-10)
+    for k in range(b):
+        assert np.array_equal(a[2][k], r[2][k])
+        assert a[3][k] == r[3][k] and a[3][k][0] > 0
+        assert np.array_equal(a[4][k], r[4][k])
