@@ -832,7 +832,19 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     // norms; lambda_max of a Gram matrix lies in [max diagonal, trace]):  s = {max_g ||dW_g||^2, sum_g ||W_g||^2,
     // max_g ||dD_g||^2, sum_g ||D_g||^2} of local iteration j from the node blocks' norm records -- lane = block, whole graphs
     // per sweep of the wave, every sum in a fixed order.
-    auto screen_of = [&](int j, double (&s)[4]) __attribute__((always_inline)) -> bool {
+    // (pre / with_pre: the first sweep's records as requested earlier by screen_request)
+    auto screen_request = [&](int j, tl_u4 (&r)[4]) __attribute__((always_inline)) {
+        const unsigned tag = P.tag0 + (unsigned)j + 1u;
+        int ls = lane;
+        asm volatile("" : "+v"(ls));
+        const bool mine = ls < (64 / nb1) * nb1 && ls < P.nb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            r[q] = tl_u4{0u, tag, 0u, tag};
+            if (mine) r[q] = __builtin_amdgcn_raw_buffer_load_b128(r_bn, (((j & 3) * (int)P.nb + ls) * 4 + q) * 16, 0, 16);
+        }
+    };
+    auto screen_of = [&](int j, double (&s)[4], const tl_u4 (&pre)[4], const bool with_pre) __attribute__((always_inline)) -> bool {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         unsigned spins = 0;
         const unsigned tag = P.tag0 + (unsigned)j + 1u;
@@ -845,14 +857,17 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         for (int b0 = 0; b0 < (int)P.nb; b0 += per) {
             const bool mine = ls < per && b0 + ls < P.nb;
             tl_u4 r[4];
+            bool use_pre = with_pre && b0 == 0;
             for (;;) {
                 bool ok = true;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     r[q] = tl_u4{0u, tag, 0u, tag};
-                    if (mine) r[q] = __builtin_amdgcn_raw_buffer_load_b128(r_bn, (((j & 3) * (int)P.nb + b0 + ls) * 4 + q) * 16, 0, 16);
+                    if (use_pre) r[q] = pre[q];
+                    else if (mine) r[q] = __builtin_amdgcn_raw_buffer_load_b128(r_bn, (((j & 3) * (int)P.nb + b0 + ls) * 4 + q) * 16, 0, 16);
                     ok = ok && tl_ok(r[q], tag);
                 }
+                use_pre = false;
 
                 asm volatile("" ::: "memory");
                 if (__all(ok)) break;
@@ -893,11 +908,11 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
     // covers both iterations the look had not judged.
     constexpr int RW = BATCH ? TW - 2 : TW - 1;  // the wave that evaluates the rule (a batch: not the slice's wave)
     // (its findings wait in LDS -- written and read by wave RW alone, in program order -- not in registers across the pass)
-    auto screen_bottom = [&](const int it) __attribute__((always_inline)) {  // (wave RW of a batch with the rule on)
+    auto screen_bottom = [&](const int it, const tl_u4 (&pre)[4], const bool with_pre) __attribute__((always_inline)) {  // (wave RW of a batch with the rule on)
         double have = 0.0, room = 1.0, sr = 1.0, fig = s_scr[3];
         if (it >= 1 && P.it0 + it - 1 >= 1) {  // never at iteration 0 (:156-161)
             double b[4];
-            if (screen_of(it - 1, b)) {
+            if (screen_of(it - 1, b, pre, with_pre)) {
                 const double rk = tl_screen_ahead(b, P.t2lo);
                 const double f = (fig > rk && fig < INFINITY) ? rk / fig : 1.0;
                 room = (rk > 1.05 * 1.05 && rk * f * f > 1.05 * 1.05) ? 1.0 : 0.0;
@@ -1049,7 +1064,10 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                     const bool lag_sure = !scr_have || s_scr[2] != 0.0, lag_room = !scr_have || s_scr[1] != 0.0;
                     const bool end_now = last_pass || !lag_room;
                     if (end_now && good && P.it0 + it - 1 >= 1) {
-                        good = good && screen_of(it - 1, b);
+                        tl_u4 none[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) none[q] = tl_u4{0u, 0u, 0u, 0u};
+                        good = good && screen_of(it - 1, b, none, false);
                         if (good) {
                             const double rk = tl_screen_ahead(b, P.t2lo);
                             // (the budget ran out with room to spare in both iterations: not a stop)
@@ -1464,7 +1482,12 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
         if (own < 0) early_look();
         if constexpr (BATCH) {
             // A batch's look at iteration it - 1 for the next top (screen_bottom).  A consumer would only wait for node values now.
-            if (own < 0 && rule_on && wave == RW) screen_bottom(it);
+            if (own < 0 && rule_on && wave == RW) {
+                tl_u4 none[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) none[q] = tl_u4{0u, 0u, 0u, 0u};
+                screen_bottom(it, none, false);
+            }
         }
 
         // ================= node phase: the owner of a block sums its records and updates the dual state =================
@@ -1479,8 +1502,18 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
             // (not in the variants with the norms: eight more registers across the poll put theirs into scratch)
             double d_cur = 0, yb_cur = 0, pb_cur = 0, gsw_cur = 0;
             if (!NORMS && wave == 0) d_cur = s_dual[0][lnp], yb_cur = s_dual[1][lnp], pb_cur = s_dual[2][lnp], gsw_cur = s_dual[4][lnp];
+            tl_u4 spre[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) spre[q] = tl_u4{0u, 0u, 0u, 0u};
+            bool have_pre = false;
             {
                 early_look();  // (wave TW - 1: before its share of the poll, whose records are still on their way)
+                if constexpr (BATCH && U < 16) {  // (wave RW: the records its look will read, requested now -- their round trip passes during the poll; U = 16 and 32 have no 16 registers to hold them across it: 68 and 300 bytes of scratch)
+                    if (rule_on && wave == RW && it >= 1 && P.it0 + it - 1 >= 1) {
+                        screen_request(it - 1, spre);
+                        have_pre = true;
+                    }
+                }
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 unsigned spins = 0;
                 // wave 1 also fetches the block sums of gamma u that this iteration's input state was published with (a whole
@@ -1641,7 +1674,7 @@ __global__ __launch_bounds__(TT, 2) void k_tile(TileDev P) {
                 // barrier back -- 6.7; at the top itself it was 7.1; 5.3 without the rule.  The lambdas of the look are always_inline:
                 // left to the inliner's judgement the kernel's argument block -- captured by reference two lambdas deep -- stayed
                 // in scratch, 450-720 bytes.)
-                screen_bottom(it);
+                screen_bottom(it, spre, have_pre);
             } else if (NORMS && wave == TW - 1) {
                 // my slice of the workgroups' norm records (workgroups own, own + nb, ...), beside wave 0's update and off the
                 // owner's critical path (in front of the barrier above it cost 0.5-1 us per iteration: the node values of
