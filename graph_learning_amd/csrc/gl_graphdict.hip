@@ -597,25 +597,17 @@ __device__ __forceinline__ void gd_degree_body(const GdDev &P, double *__restric
     double acc[KP];
 #pragma unroll
     for (int k = 0; k < KP; ++k) acc[k] = 0.0;
-    // (G x 64 neighbours' entries in flight -- one group per round trip it was n / 64 dependent round trips a wave, 17 us at
-    //  n = 1024; the sums keep their order: a lane adds its neighbours in ascending order, the skipped ones as + 0.0)
-    constexpr int G = KP >= 16 ? 2 : 4;
+    // (a gather of n 64-byte pieces, 64 KB apart below the diagonal: more of them in flight -- four neighbour groups per round
+    //  trip -- measured slower, 18.2 against 17.3 us at n = 1024: the pieces themselves are the cost, not the round trips)
     if (v < P.n)
-        for (int u0 = 0; u0 < P.n; u0 += 64 * G) {
-            double2 w[G][KP / 2];
-            bool ok[G];
+        for (int u = lane; u < P.n; u += 64) {
+            if (u == v) continue;
+            const double *p = u < v ? P.WS + ((int64_t)u * P.n_pad + v) * KP : P.WS + ((int64_t)v * P.n_pad + u) * KP;
 #pragma unroll
-            for (int r = 0; r < G; ++r) {
-                const int u = u0 + r * 64 + lane, uc = min(u, P.n - 1);
-                ok[r] = u < P.n && u != v;
-                const double *p = uc < v ? P.WS + ((int64_t)uc * P.n_pad + v) * KP : P.WS + ((int64_t)v * P.n_pad + uc) * KP;
-#pragma unroll
-                for (int k = 0; k < KP; k += 2) w[r][k / 2] = *reinterpret_cast<const double2 *>(p + k);  // (16-byte accesses)
+            for (int k = 0; k < KP; k += 2) {  // (16-byte accesses: an entry's KP atoms are contiguous and 16-byte aligned)
+                const double2 w = *reinterpret_cast<const double2 *>(p + k);
+                acc[k] += w.x, acc[k + 1] += w.y;
             }
-#pragma unroll
-            for (int r = 0; r < G; ++r)
-#pragma unroll
-                for (int k = 0; k < KP; k += 2) acc[k] += ok[r] ? w[r][k / 2].x : 0.0, acc[k + 1] += ok[r] ? w[r][k / 2].y : 0.0;
         }
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
