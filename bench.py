@@ -164,13 +164,17 @@ def other_configs(ctx):
         adj = adj + adj.T
         chol = np.linalg.cholesky(np.linalg.inv(np.diag(adj.sum(1)) - adj + np.eye(n)))
         xw = (chol @ rs.standard_normal((n, 10 * 256))).T
-        WindowLogModel(window_size=256, avg_degree=6, maxit=50, tol=1e-4).fit(xw)
+        # (warm-up = the same fit: the first batch of a new (n, B) shape builds the context's stand-in session for the cruise,
+        #  ~0.8 ms that every later fit of that shape does not pay; reported beside the steady figure)
+        t0 = time.perf_counter()
+        WindowLogModel(window_size=256, avg_degree=6, maxit=20000, tol=1e-4).fit(xw)
+        t_first = time.perf_counter() - t0
         t0 = time.perf_counter()
         wm = WindowLogModel(window_size=256, avg_degree=6, maxit=20000, tol=1e-4).fit(xw)
         t_fit = time.perf_counter() - t0
         out["window_n256"] = {"workload": "WindowLogModel.fit, 10 windows of 256 samples of one smooth process on 256 nodes (temporal/smooth.py:12-61), "
                                           "host signals in, (10, E) weights out", "dtype": "f64", "iterations": int(wm.n_iter_),
-                              "converged": bool(wm.converged_), "ms_end_to_end": t_fit * 1e3,
+                              "converged": bool(wm.converged_), "ms_end_to_end": t_fit * 1e3, "ms_first_fit_of_the_shape": t_first * 1e3,
                               "us_per_iteration_all_in": t_fit / max(int(wm.n_iter_), 1) * 1e6}
     except Exception as exc:
         out["batched_error"] = repr(exc)
