@@ -270,17 +270,18 @@ __global__ void k_gd_logc_reset(GdDev P) {
 // sum of the strip-group partials of k_gd_grad_c, fixed order: 4 interleaved partial sums per
 // element (threadIdx.y), then ((p0 + p1) + p2) + p3
 __device__ __forceinline__ void gd_sc_reduce_body(const GdDev &P, const int bx) {
-    if (P.stat[5] != 0.0) return;
+    const double done_flag = P.stat[5];  // ("done" is looked at where the first store would be: tested up front, every wave of the tail spent a round trip on it before its first load)
     __shared__ double s_p[4][64];
     const int64_t q = (int64_t)bx * 64 + threadIdx.x;  // (k, t)
     const int gy = threadIdx.y;
     double v = 0.0;
     if (q < (int64_t)P.KP * P.Tp) {
-#pragma unroll 8
+#pragma unroll 16
         for (int g = gy; g < P.NG; g += 4) v += P.SC[(int64_t)g * P.KP * P.Tp + q];
     }
     s_p[gy][threadIdx.x] = v;
     __syncthreads();
+    if (done_flag != 0.0) return;
     if (gy == 0 && q < (int64_t)P.KP * P.Tp)
         P.SCR[q] = ((s_p[0][threadIdx.x] + s_p[1][threadIdx.x]) + s_p[2][threadIdx.x]) + s_p[3][threadIdx.x];
 }
@@ -289,7 +290,7 @@ __device__ __forceinline__ void gd_sc_reduce_body(const GdDev &P, const int bx) 
 // coefficient update (base_model.py:373-401), one wave per window
 template <int KP>
 __device__ __forceinline__ void gd_coef_update_body(const GdDev &P, const int tw, const int lane) {
-    if (P.stat[5] != 0.0) return;
+    const double done_flag = P.stat[5];
     // adjoint term  W @ (S' dual')  ==  <S W_k, dual_tw>   (log_model.py:33-34)
     double dt[KP];
 #pragma unroll
@@ -313,6 +314,7 @@ __device__ __forceinline__ void gd_coef_update_body(const GdDev &P, const int tw
     }
 #pragma unroll
     for (int k = 0; k < KP; ++k) dt[k] = gd_wave_sum(dt[k]);
+    if (done_flag != 0.0) return;
     // lane k finishes atom k
     double dterm = 0.0;
 #pragma unroll
@@ -365,7 +367,7 @@ __device__ __forceinline__ void gd_coef_finish_body(const GdDev &P) {
 // M[k][i] = sum_t C[k,t] dual[t / W, i]  (log_model.py:36-37: C @ (S' dual_rep')' = S'(C @ dual_rep) pairwise)
 template <int KP>
 __global__ __launch_bounds__(256) void k_gd_m(GdDev P, int tchunk) {
-    if (P.stat[5] != 0.0) return;
+    const double done_flag = P.stat[5];
     // one wave per (64 nodes, sample chunk), four chunks per workgroup.  Per 32 samples a wave stages their coefficients
     // (sample-major: one contiguous piece of CT) in its own corner of LDS and reads them back as broadcasts; eight
     // samples' loads of the dual variable in flight, the K sums in registers, no branch inside.  (Round 4: before, a
@@ -408,11 +410,12 @@ __global__ __launch_bounds__(256) void k_gd_m(GdDev P, int tchunk) {
             }
         }
     }
+    if (done_flag != 0.0) return;
 #pragma unroll
     for (int k = 0; k < KP; ++k) P.MSL[((int64_t)ms * KP + k) * P.n_pad + i] = i < P.n ? acc[k] : 0.0;
 }
 __device__ __forceinline__ void gd_m_reduce_body(const GdDev &P, const int bx) {
-    if (P.stat[5] != 0.0) return;
+    const double done_flag = P.stat[5];
     __shared__ double s_p[4][64];
     const int64_t q = (int64_t)bx * 64 + threadIdx.x;
     const int gy = threadIdx.y;
@@ -423,6 +426,7 @@ __device__ __forceinline__ void gd_m_reduce_body(const GdDev &P, const int bx) {
     }
     s_p[gy][threadIdx.x] = v;
     __syncthreads();
+    if (done_flag != 0.0) return;
     if (gy == 0 && q < (int64_t)P.KP * P.n_pad)
         P.M[q] = ((s_p[0][threadIdx.x] + s_p[1][threadIdx.x]) + s_p[2][threadIdx.x]) + s_p[3][threadIdx.x];
 }
@@ -443,7 +447,7 @@ __device__ __forceinline__ void gd_weight_update_body(const GdDev &P, const int 
         }
         return;
     }
-    if (P.stat[5] != 0.0) return;
+    const double done_flag = P.stat[5];
     constexpr int CPP = KP / 2, RS = KP + 2;  // 16-byte pieces per pair; row stride in doubles
     const int j = jb * 64 + lane;
     const bool live = j > i && j < P.n;
@@ -510,6 +514,7 @@ __device__ __forceinline__ void gd_weight_update_body(const GdDev &P, const int 
             wmax = fmax(wmax, fabs(wo[k]));
         }
     }
+    if (done_flag != 0.0) return;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int q = 0; q < CPP; ++q) *reinterpret_cast<double2 *>(s_t + lane * RS + 2 * q) = double2{wn[2 * q], wn[2 * q + 1]};
@@ -549,7 +554,7 @@ __device__ __forceinline__ void gd_weight_update_body(const GdDev &P, const int 
 
 template <int NT>
 __device__ __forceinline__ void gd_weight_finish_body(const GdDev &P, const int64_t nparts) {
-    if (P.stat[5] != 0.0) return;
+    const double done_flag = P.stat[5];
     __shared__ double s_a[NT], s_b[NT], s_c[NT];
     const int tid = threadIdx.x;
     double num = 0, den = 0, mx = 0;
@@ -585,13 +590,13 @@ __device__ __forceinline__ void gd_weight_finish_body(const GdDev &P, const int6
         }
         __syncthreads();
     }
-    if (tid == 0) P.stat[1] = s_c[0] <= 1e-8 ? sqrt(s_a[0]) : sqrt(s_a[0]) / sqrt(s_b[0]);
+    if (tid == 0 && done_flag == 0.0) P.stat[1] = s_c[0] <= 1e-8 ? sqrt(s_a[0]) : sqrt(s_a[0]) / sqrt(s_b[0]);
 }
 
 // degrees S W_k' of the weights in WS: one wave per node
 template <int KP>
 __device__ __forceinline__ void gd_degree_body(const GdDev &P, double *__restrict__ out, const int chk_done, const int v, const int lane) {
-    if (chk_done && P.stat[5] != 0.0) return;
+    const double done_flag = chk_done ? P.stat[5] : 0.0;
     if (v >= P.n_pad) return;  // a wave past the last node (four nodes per block in k_gd_finish3)
     // (KP is the compile-time stride of an entry's atoms: with the runtime K the sums were indexed in scratch)
     double acc[KP];
@@ -612,7 +617,7 @@ __device__ __forceinline__ void gd_degree_body(const GdDev &P, double *__restric
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
         const double s = gd_wave_sum(acc[k]);
-        if (lane == 0 && k < P.K) out[(int64_t)k * P.n_pad + v] = s;
+        if (lane == 0 && k < P.K && done_flag == 0.0) out[(int64_t)k * P.n_pad + v] = s;
     }
 }
 
@@ -669,7 +674,7 @@ __global__ __launch_bounds__(256) void k_gd_finish3(GdDev P, int64_t nparts, dou
 // (base_model.py:509-514).  fixed_weights: predict() passes the weights themselves (:665-669).
 template <int KP>
 __global__ __launch_bounds__(256) void k_gd_dual_update(GdDev P, int fixed_weights) {
-    if (P.stat[5] != 0.0) return;
+    const double done_flag = P.stat[5];
     // the overshoot coefficients 2 new - old of this workgroup's 8 windows, once per workgroup (round 4: every thread used
     // to fetch the 2 x K of every window itself, window after window, each window's load of the dual variable behind the
     // previous window's store: 46 us for 67 MB of traffic)
@@ -693,6 +698,7 @@ __global__ __launch_bounds__(256) void k_gd_dual_update(GdDev P, int fixed_weigh
     double dl[8];
 #pragma unroll
     for (int w = 0; w < 8; ++w) dl[w] = tw0 + w < P.Tw ? dual[(int64_t)(tw0 + w) * P.n + i] : 0.0;  // all eight in flight
+    if (done_flag != 0.0) return;
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
         if (tw0 + w >= P.Tw) break;

@@ -113,7 +113,9 @@ int gl_logdeg_iterate_async(gl_logdeg *s, int64_t n_iter);
  * get_weights_condensed(w_out = NULL) only stages the vector on the device. */
 int gl_logdeg_get_weights_condensed(gl_logdeg *s, double edge_tol, double *w_out);
 /* The same for B sessions (same context, same n_nodes) with one copy and one synchronisation: w_out is
- * B x E, row b = session b (the reference's edge_w.T of the batched branch, smooth_learning.py:174). */
+ * B x E, row b = session b (the reference's edge_w.T of the batched branch, smooth_learning.py:174).  Thetas that
+ * set_signals left on the device (theta_out = NULL) come back with the same synchronisation: gl_logdeg_theta
+ * of these sessions returns at once afterwards. */
 int gl_logdeg_batch_get_weights(gl_logdeg **sessions, int n_sessions, double edge_tol, double *w_out);
 int gl_logdeg_get_weights_square(gl_logdeg *s, double edge_tol, double *w_out);
 /* Dual variable dvar (n) -- for checkpoint/resume and the parity tests. */
