@@ -30,6 +30,10 @@
 #include <new>
 #include <vector>
 
+#ifndef GD_UPD_EXP
+#define GD_UPD_EXP 0  // tools/build_variant_gd.sh: ablations of k_gd_update2 (timing only)
+#endif
+
 namespace {
 
 __device__ __forceinline__ double gd_wave_sum(double v) { return wave_sum(v); }  // gl_lanes.h
@@ -464,7 +468,7 @@ __device__ __forceinline__ void gd_weight_update_body(const GdDev &P, const int 
         mj[k] = P.M[(int64_t)k * P.n_pad + j];
         g[k] = 0.0;
     }
-    for (int ts0 = 0; ts0 < P.TS; ts0 += 4) {  // four slabs in flight; added in the order of the slabs
+    for (int ts0 = 0; ts0 < (GD_UPD_EXP == 4 ? 0 : P.TS); ts0 += 4) {  // four slabs in flight; added in the order of the slabs
         double2 gv[4][KP / 2];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -523,9 +527,9 @@ __device__ __forceinline__ void gd_weight_update_body(const GdDev &P, const int 
     for (int r = 0; r < CPP; ++r) {  // (pairs on or below the diagonal and past the last node keep their zeros: not written)
         const int c = r * 64 + lane, jp = jb * 64 + c / CPP;
         const double2 v = *reinterpret_cast<const double2 *>(s_t + (c / CPP) * RS + 2 * (c % CPP));
-        if (jp > i && jp < P.n) *reinterpret_cast<double2 *>(wrow + 2 * c) = v;
+        if (GD_UPD_EXP != 5 && jp > i && jp < P.n) *reinterpret_cast<double2 *>(wrow + 2 * c) = v;
     }
-    if (P.WSf) {  // the fp32 mirror the next step's contractions read (round 4: a pass of its own over all of WS before)
+    if (GD_UPD_EXP != 3 && GD_UPD_EXP != 5 && P.WSf) {  // the fp32 mirror the next step's contractions read (round 4: a pass of its own over all of WS before)
         constexpr int FPP = KP / 4 > 0 ? KP / 4 : 1, FS = KP + 4;  // 16-byte pieces per pair; row stride in floats
         float *s_f = reinterpret_cast<float *>(s_t);  // (64 x (KP + 4) floats fit the same corner)
         float *frow = P.WSf + ((int64_t)i * P.n_pad + jb * 64) * KP;
@@ -642,6 +646,11 @@ template <int KP>
 __global__ __launch_bounds__(256) void k_gd_update2(GdDev P, int nbj, int cblocks) {
     __shared__ double s_t[4][64 * (KP + 2)];  // the weight update's row exchange, a corner per wave
     const int b = (int)blockIdx.x, wv = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+#if GD_UPD_EXP == 1  // (tools/build_variant_gd.sh: what the parts of this kernel cost; results are wrong in these builds)
+    if (b < cblocks) return;
+#elif GD_UPD_EXP == 2
+    if (b >= cblocks) return;
+#endif
     if (b < cblocks) {
         const int tw = b * 4 + wv;
         if (tw < P.Tw) gd_coef_update_body<KP>(P, tw, lane);
