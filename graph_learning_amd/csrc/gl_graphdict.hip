@@ -292,40 +292,66 @@ __device__ __forceinline__ void gd_sc_reduce_body(const GdDev &P, const int bx) 
 
 // ------------------------------------------------------------------------------------------
 // coefficient update (base_model.py:373-401), one wave per window
+// maximum over an aligned group of KP lanes (KP = 4, 8, 16), in every lane of the group: DPP
 template <int KP>
-__device__ __forceinline__ void gd_coef_update_body(const GdDev &P, const int tw, const int lane) {
-    const double done_flag = P.stat[5];
+__device__ __forceinline__ double gd_group_max(double v) {
+    v = fmax(v, dpp_mov<DPP_QUAD_XOR1>(v));
+    v = fmax(v, dpp_mov<DPP_QUAD_XOR2>(v));
+    if (KP >= 8) v = fmax(v, dpp_mov<DPP_HALF_MIRROR>(v));
+    if (KP >= 16) v = fmax(v, dpp_mov<DPP_ROW_ROR8>(v));
+    return v;
+}
+
+// NW windows per wave (tw0 .. tw0 + NW - 1): the degrees, which every window's adjoint term reads in full (KP x n: 64 KB at
+// n = 1024 -- one window per wave, that was 295 MB through L2 for a step's 4096 windows, 23 us of k_gd_update2 by ablation),
+// are fetched once for the NW of them; every sum keeps its order (a lane adds its nodes in ascending order).
+template <int KP, int NW>
+__device__ __forceinline__ void gd_coef_update_body(const GdDev &P, const int tw0, const int lane) {
+    static_assert(NW * KP <= 64, "a lane per (window, atom) finishes the update");
+    const double done_flag = P.stat[5];  // ("done" is looked at where the first store would be: tested up front, every wave of the tail spent a round trip on it before its first load)
     // adjoint term  W @ (S' dual')  ==  <S W_k, dual_tw>   (log_model.py:33-34)
-    double dt[KP];
+    double dt[NW][KP];
 #pragma unroll
-    for (int k = 0; k < KP; ++k) dt[k] = 0.0;
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int k = 0; k < KP; ++k) dt[w][k] = 0.0;
     // (the loads of G x 64 nodes in flight: one node group per round trip it was n / 64 dependent round trips a wave)
-    constexpr int G = KP >= 16 ? 2 : 4;
+    constexpr int G = KP * NW >= 32 ? 2 : 4;
     for (int i0 = 0; i0 < P.n; i0 += 64 * G) {
-        double dv[G], dg[G][KP];
+        double dv[G][NW], dg[G][KP];
 #pragma unroll
         for (int r = 0; r < G; ++r) {
             const int i = i0 + r * 64 + lane, ic = min(i, P.n - 1);
-            const double v = P.dual[(int64_t)tw * P.n + ic];
-            dv[r] = i < P.n ? v : 0.0;  // (past the last node: exact zeros, added to sums that x + 0.0 leaves alone)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const double v = P.dual[(int64_t)min(tw0 + w, P.Tw - 1) * P.n + ic];
+                dv[r][w] = (i < P.n && tw0 + w < P.Tw) ? v : 0.0;  // (past the last node / window: exact zeros, added to sums that x + 0.0 leaves alone)
+            }
 #pragma unroll
             for (int k = 0; k < KP; ++k) dg[r][k] = P.deg[(int64_t)k * P.n_pad + ic];  // rows k >= K are zero
         }
 #pragma unroll
         for (int r = 0; r < G; ++r)
 #pragma unroll
-            for (int k = 0; k < KP; ++k) dt[k] += dg[r][k] * dv[r];
+            for (int w = 0; w < NW; ++w)
+#pragma unroll
+                for (int k = 0; k < KP; ++k) dt[w][k] += dg[r][k] * dv[r][w];
     }
 #pragma unroll
-    for (int k = 0; k < KP; ++k) dt[k] = gd_wave_sum(dt[k]);
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int k = 0; k < KP; ++k) dt[w][k] = gd_wave_sum(dt[w][k]);
     if (done_flag != 0.0) return;
-    // lane k finishes atom k
+    // lane w * KP + k finishes atom k of window tw0 + w
     double dterm = 0.0;
 #pragma unroll
-    for (int k = 0; k < KP; ++k) dterm = lane == k ? dt[k] : dterm;
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int k = 0; k < KP; ++k) dterm = lane == w * KP + k ? dt[w][k] : dterm;
+    const int k = lane % KP, tw = tw0 + lane / KP;
+    const bool mine = lane < NW * KP && tw < P.Tw;
     double cmax = 0.0;
-    if (lane < P.K) {
-        const int k = lane;
+    if (mine && k < P.K) {
         // smoothness term: mean over the window's samples (:375-379) of the summed strip-group partials
         double tot = 0.0;
         for (int q = 0; q < P.W; ++q) tot += P.SCR[(int64_t)k * P.Tp + (int64_t)tw * P.W + q];
@@ -344,8 +370,8 @@ __device__ __forceinline__ void gd_coef_update_body(const GdDev &P, const int tw
         P.Cw[(int64_t)k * P.Tw + tw] = cn;
         cmax = fabs(cn);
     }
-    cmax = gd_wave_max(cmax);
-    if (lane == 0) P.cpart[tw] = cmax;
+    cmax = gd_group_max<KP>(cmax);  // over the window's KP lanes (those past K hold 0)
+    if (mine && k == 0) P.cpart[tw] = cmax;
 }
 
 // all-zero guard (:406-408); one workgroup
@@ -638,10 +664,10 @@ __global__ __launch_bounds__(256) void k_gd_reduce2(GdDev P, int nsc) {  // bloc
 }
 template <int KP>
 __global__ __launch_bounds__(64) void k_gd_coef_update(GdDev P) {
-    gd_coef_update_body<KP>(P, (int)blockIdx.x, (int)threadIdx.x);
+    gd_coef_update_body<KP, 1>(P, (int)blockIdx.x, (int)threadIdx.x);
 }
-// four waves per workgroup, a window or a (row, column block) each: blocks [0, ceil(Tw / 4)) take the windows, the
-// others (row i, column blocks 4 q .. 4 q + 3)
+// four waves per workgroup, NW windows or a (row, column block) each: the first blocks take the windows, the others
+// (row i, column blocks 4 q .. 4 q + 3)
 template <int KP>
 __global__ __launch_bounds__(256) void k_gd_update2(GdDev P, int nbj, int cblocks) {
     __shared__ double s_t[4][64 * (KP + 2)];  // the weight update's row exchange, a corner per wave
@@ -652,8 +678,9 @@ __global__ __launch_bounds__(256) void k_gd_update2(GdDev P, int nbj, int cblock
     if (b >= cblocks) return;
 #endif
     if (b < cblocks) {
-        const int tw = b * 4 + wv;
-        if (tw < P.Tw) gd_coef_update_body<KP>(P, tw, lane);
+        constexpr int NW = KP >= 16 ? 2 : 4;  // windows per wave
+        const int tw0 = (b * 4 + wv) * NW;
+        if (tw0 < P.Tw) gd_coef_update_body<KP, NW>(P, tw0, lane);
     } else {
         const int nq = (nbj + 3) / 4, r = b - cblocks;
         const int jb = (r % nq) * 4 + wv, i = r / nq;
@@ -980,7 +1007,8 @@ int gd_step(gl_graphdict *s, int fit_mode = 0) {
     GL_TRY(gd_launch_grad_w(s));
     if (s->side) GL_HIP(ctx, hipStreamWaitEvent(st, s->ev_join, 0));
     const int nbj = P.n_pad / 64;
-    const int cblocks = (P.Tw + 3) / 4;
+    const int wpb = 4 * (P.KP >= 16 ? 2 : 4);  // windows per workgroup: four waves, NW each (k_gd_update2)
+    const int cblocks = (P.Tw + wpb - 1) / wpb;
     const dim3 gu((unsigned)(cblocks + (nbj + 3) / 4 * P.n));
     switch (P.KP) {
         case 4: k_gd_update2<4><<<gu, 256, 0, st>>>(P, nbj, cblocks); break;
