@@ -2004,7 +2004,7 @@ struct BatchCruise {
     // state, the Gram partials and the per-iteration decisions -- one allocation, made when a call first gets there
     void *ring_arena = nullptr;
     int ring_k = 0;  // iterations per chunk
-    double *ring = nullptr, *dring = nullptr, *ckpt = nullptr, *gpart = nullptr;
+    double *ring = nullptr, *dring = nullptr, *gpart = nullptr;
     RingJudge *judge = nullptr;
 };
 static void batch_cruise_free(void *p) {
@@ -2345,13 +2345,12 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                     const size_t slot = (size_t)B * tiled1 * 8, dslot = (size_t)(4 * C.n_pad + 4 * C.nb) * 8;
                     while (K > 4 && (K + 1) * slot > ((size_t)3 << 30)) K /= 2;
                     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
-                    const size_t b_ring = up((K + 1) * slot), b_dring = up((K + 1) * dslot), b_ck = 0;
+                    const size_t b_ring = up((K + 1) * slot), b_dring = up((K + 1) * dslot);
                     const size_t b_part = up((size_t)K * (ge + 1) * 2 * nbk * 256 * 8), b_j = up(sizeof(RingJudge));
-                    if (gl_ctx_malloc(ctx, &bc->ring_arena, b_ring + b_dring + b_ck + b_part + b_j, "ring") == hipSuccess) {
+                    if (gl_ctx_malloc(ctx, &bc->ring_arena, b_ring + b_dring + b_part + b_j, "ring") == hipSuccess) {
                         char *at = (char *)bc->ring_arena;
                         bc->ring = (double *)at, at += b_ring;
                         bc->dring = (double *)at, at += b_dring;
-                        bc->ckpt = (double *)at, at += b_ck;
                         bc->gpart = (double *)at, at += b_part;
                         bc->judge = (RingJudge *)at;
                         bc->ring_k = K;
@@ -2495,7 +2494,7 @@ GL_API int gl_logdeg_batch_iterate(gl_logdeg **sessions, int B, int64_t maxit, d
                         GL_HIP(ctx, hipStreamSynchronize(ctx->stream));
                         (void)hipFree(bc->ring_arena);
                         bc->ring_arena = nullptr;
-                        bc->ring = bc->dring = bc->ckpt = bc->gpart = nullptr;
+                        bc->ring = bc->dring = bc->gpart = nullptr;
                         bc->judge = nullptr;
                         bc->ring_k = 0;
                     }

@@ -164,12 +164,6 @@ __device__ __forceinline__ double lane_bcast(double v, int l) {  // lane l's val
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-__device__ __forceinline__ double tl_wave_max(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
-    return v;
-}
-
 // a batch's screen of the coupled rule on s = {max_g ||dW_g||^2, sum_g ||W_g||^2, max_g ||dD_g||^2, sum_g ||D_g||^2}: is the rule
 // surely not met; the larger lower bound over tol, squared (0: degenerate).  (Plain functions: as lambdas that capture the
 // kernel's argument block inside other lambdas they made the compiler keep that block -- 330 bytes -- in scratch.)
