@@ -52,6 +52,8 @@ struct gl_graphdict {
     bool have_x = false, have_state = false;
     // fp32 form of the two gradient contractions (gl_graphdict_set_precision): fp32 copies of their operands
     bool f32 = false;
+    int rc32 = 2;            // rows per strip of the fp32 k_gd_grad_c (gl_graphdict_create)
+    int ng64 = 1, ng32 = 1;  // strip groups of k_gd_grad_c in either precision (dev.NG is the current one)
     float *Xf = nullptr, *XTf = nullptr, *WSf = nullptr, *CTf = nullptr;
     // one step (memset + 14 kernels + copy of the status words) captured per parity of the degree
     // ping-pong and replayed: one graph launch per step instead of 16 enqueues (matters below ~1 ms/step)

@@ -899,7 +899,11 @@ int gd_launch_grad_c(gl_graphdict *s) {
     if (s->f32) {  // (WSf is kept by the weight update)
         switch (P.KP) {
             case 4: k_gd_grad_c<float, 4, 2><<<grid, 64, 0, st>>>(s->XTf, s->WSf, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5); break;
-            case 8: k_gd_grad_c<float, 8, 2><<<grid, 64, 0, st>>>(s->XTf, s->WSf, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5); break;
+            case 8:
+                if (s->rc32 == 4) k_gd_grad_c<float, 8, 4><<<grid, 64, 0, st>>>(s->XTf, s->WSf, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5);
+                else if (s->rc32 == 3) k_gd_grad_c<float, 8, 3><<<grid, 64, 0, st>>>(s->XTf, s->WSf, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5);
+                else k_gd_grad_c<float, 8, 2><<<grid, 64, 0, st>>>(s->XTf, s->WSf, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5);
+                break;
             default: k_gd_grad_c<float, 16, 1><<<grid, 64, 0, st>>>(s->XTf, s->WSf, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5); break;
         }
         GL_HIP(s->ctx, hipGetLastError());
@@ -1091,9 +1095,19 @@ GL_API int gl_graphdict_create(gl_ctx *ctx, int64_t n_nodes, int64_t n_samples, 
     P.K = n_atoms;
     P.KP = n_atoms <= 4 ? 4 : (n_atoms <= 8 ? 8 : 16);
     // enough waves to fill 256 CUs x 4 SIMDs a few times over, slabs kept small
+    // Rows per strip of k_gd_grad_c: 2 at K <= 8 in fp64 (a weight is two scalar registers, and two operand sets of rows x K
+    // weights must fit the scalar file), 3 in the fp32 form at K = 8 -- a third fewer loads of x_j per fused multiply-add:
+    // 0.455 -> 0.435 ms on the same GPU (4 spills 53 scalar registers: 0.563).  GRAPHLEARN_AMD_GD_RC32=2: as before.
+    s->rc32 = P.KP == 8 ? 3 : 2;
+    if (const char *e = getenv("GRAPHLEARN_AMD_GD_RC32"))
+        if (P.KP == 8 && (atoi(e) == 2 || atoi(e) == 3 || atoi(e) == 4)) s->rc32 = atoi(e);
     const int nstrips = (P.n + gd_rows_c(P.KP) - 1) / gd_rows_c(P.KP);
     const int sblocks = P.Tp / GD_SB;
     P.NG = std::max(1, std::min(nstrips, std::min(512, (8192 + sblocks - 1) / sblocks)));
+    // (the strip groups of either precision: one strip per group where there are enough of them; the partials are sized for
+    //  the larger count)
+    s->ng64 = P.NG;
+    s->ng32 = P.KP == 8 ? std::max(1, std::min((P.n + s->rc32 - 1) / s->rc32, P.NG)) : P.NG;
     std::vector<int2> tasks;
     {
         const int sw = gd_strip_w(P.KP);
@@ -1105,7 +1119,7 @@ GL_API int gl_graphdict_create(gl_ctx *ctx, int64_t n_nodes, int64_t n_samples, 
     const int64_t wtasks = P.nwtasks;
     P.TS = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, (P.Tp + 511) / 512), (3072 + wtasks - 1) / wtasks));
     if (const char *e = getenv("GRAPHLEARN_AMD_GD_TS")) P.TS = std::max(1, std::min(64, atoi(e)));  // tuning aid
-    if (const char *e = getenv("GRAPHLEARN_AMD_GD_NG")) P.NG = std::max(1, std::min(nstrips, atoi(e)));
+    if (const char *e = getenv("GRAPHLEARN_AMD_GD_NG")) P.NG = s->ng64 = s->ng32 = std::max(1, std::min(nstrips, atoi(e)));
     P.MS = std::max(1, std::min(128, P.T / 32));
     const size_t np2 = (size_t)P.n_pad * P.n_pad;
     // every buffer of the session in ONE zeroed allocation (21 hipMalloc + memset pairs cost more than a
@@ -1272,6 +1286,7 @@ GL_API int gl_graphdict_set_precision(gl_graphdict *s, int bits) {
     s->f32 = bits == 32;
     P.WSf = s->f32 ? s->WSf : nullptr;
     P.CTf = s->f32 ? s->CTf : nullptr;
+    P.NG = s->f32 ? s->ng32 : s->ng64;
     gd_refresh_f32(s);
     GL_HIP(ctx, hipGetLastError());
     return GL_OK;
