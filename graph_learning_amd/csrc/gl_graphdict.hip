@@ -1095,10 +1095,12 @@ GL_API int gl_graphdict_create(gl_ctx *ctx, int64_t n_nodes, int64_t n_samples, 
     P.K = n_atoms;
     P.KP = n_atoms <= 4 ? 4 : (n_atoms <= 8 ? 8 : 16);
     // enough waves to fill 256 CUs x 4 SIMDs a few times over, slabs kept small
-    // Rows per strip of k_gd_grad_c: 2 at K <= 8 in fp64 (a weight is two scalar registers, and two operand sets of rows x K
-    // weights must fit the scalar file), 3 in the fp32 form at K = 8 -- a third fewer loads of x_j per fused multiply-add:
-    // 0.455 -> 0.435 ms on the same GPU (4 spills 53 scalar registers: 0.563).  GRAPHLEARN_AMD_GD_RC32=2: as before.
-    s->rc32 = P.KP == 8 ? 3 : 2;
+    // Rows per strip of k_gd_grad_c: 2 at K <= 8 (two operand sets of rows x K weights must fit the scalar file; in fp64 a weight
+    // is two scalar registers).  GRAPHLEARN_AMD_GD_RC32=3 / 4: three / four rows in the fp32 form at K = 8 -- fewer loads of x_j
+    // per fused multiply-add.  Measured on one GPU, 100-step fits: three rows are faster back to back (0.430 against 0.440 ms)
+    // and slower inside a step (450 against 435 us under rocprofv3), their fewer strip groups fold faster (16 against 22 us),
+    // and the step comes out the same (0.959 ms both); four rows spill 53 scalar registers (0.563 ms).  Default: 2.
+    s->rc32 = 2;
     if (const char *e = getenv("GRAPHLEARN_AMD_GD_RC32"))
         if (P.KP == 8 && (atoi(e) == 2 || atoi(e) == 3 || atoi(e) == 4)) s->rc32 = atoi(e);
     const int nstrips = (P.n + gd_rows_c(P.KP) - 1) / gd_rows_c(P.KP);
@@ -1107,7 +1109,7 @@ GL_API int gl_graphdict_create(gl_ctx *ctx, int64_t n_nodes, int64_t n_samples, 
     // (the strip groups of either precision: one strip per group where there are enough of them; the partials are sized for
     //  the larger count)
     s->ng64 = P.NG;
-    s->ng32 = P.KP == 8 ? std::max(1, std::min((P.n + s->rc32 - 1) / s->rc32, P.NG)) : P.NG;
+    s->ng32 = (P.KP == 8 && s->rc32 != 2) ? std::max(1, std::min((P.n + s->rc32 - 1) / s->rc32, P.NG)) : P.NG;
     std::vector<int2> tasks;
     {
         const int sw = gd_strip_w(P.KP);
