@@ -12,7 +12,7 @@ before = {"k_gd_update2<8>": 71.8, "k_gd_dual_update<8>": 46.4, "k_gd_m<8>": 35.
 if "k_gd_grad_c<float, 8, 3>" in rows:  # (round 4's last change: strips of three rows; the same kernel as far as this table goes)
     before["k_gd_grad_c<float, 8, 3>"] = before.pop("k_gd_grad_c<float, 8, 2>")
 out = ["# GraphDictLog K = 8, n = 1024, T = 4096, fp32 contractions: the kernels of a step", "",
-       "`rocprofv3 --kernel-trace --stats -- python3 tools/graphdict_bench.py` (GD_BITS=32; 2 x 50 steps of `fit` + the gradient",
+       "`rocprofv3 --kernel-trace --stats -- python3 tools/graphdict_bench.py` (GD_BITS=32; two `fit` calls of GD_STEPS steps + the gradient",
        "timing aid), average us per launch.  Round 3: the same kernels before this round's work on the tail (`k_gd_to_f32`: three",
        "launches per step then, 33 us together; now only at set-up).", "",
        "| kernel | round 3, us | now: launches | us |", "|---|---:|---:|---:|"]
