@@ -75,9 +75,11 @@ def other_configs(ctx):
                block-coordinate descent (lgmrf.py:175-219), timed through the C ABI between HIP events
                (gl_lgmrf_time_node_updates); every QP runs its 100 ADMM steps on this input.
     graphdict  BASELINE configs[4]: GraphDictLog K=8, n=1024, T=4096: ms per primal-dual step, fp64 (what the reference
-               computes) and fp32 contractions (what the config names).
+               computes) and fp32 contractions (what the config names); 50 steps of one fit call behind a fit of the same
+               length (a fit captures its step graphs once per history length).
     batched_n256    the 2-D branch (B = 8 graphs of n = 256): us per iteration of the bare loop and of a run to tol.
-    window_n256     WindowLogModel.fit end to end, 10 windows of one smooth process on 256 nodes.
+    window_n256     WindowLogModel.fit end to end, 10 windows of one smooth process on 256 nodes: the second fit of the shape
+               (ms_end_to_end) and the first one, which builds the context's stand-in session for the cruise beside it.
     logmodel_n8192  the headline loop on a lattice four times as large (SURVEY section 8 row d quotes the roofline for
                n >= 4096): time per iteration and its fraction of 24 E bytes / 8 TB/s."""
     import numpy as np
