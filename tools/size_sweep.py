@@ -1,4 +1,4 @@
-"""Dev tool: the tile engine against the streaming engine by size -> a markdown table (profiles/r03_size_sweep.md).
+"""Dev tool: the tile engine against the streaming engine by size -> a markdown table (profiles/r0N_size_sweep.md).
 Both engines run 17 + 24 iterations from the same start (max |difference| of the edge iterate and of the dual), then to
 tol = 1e-4 (stopping iterations); then a 2000-iteration asynchronous call is timed with HIP events (us per iteration), a
 20-iteration call (us per call), and the converge-mode rate (variant with the norms).
@@ -45,7 +45,7 @@ for n in sizes:
     rows.append(f"| {n} | {a[0]} | {dw:.2e} | {dd:.2e} | {a[3]} / {b[3]} | {a[5]:.2f} | {b[5]:.2f} | {a[6]:.1f} | {a[7]:.1f} | {frac:.2f} |")
     print(rows[-1], flush=True)
 if out_md:
-    head = ["# Tile engine against the streaming engine by size (round 3)", "",
+    head = ["# Tile engine against the streaming engine by size (" + os.environ.get("GRAPHLEARN_AMD_ROUND_LABEL", "round 4") + ")", "",
             "`tools/size_sweep.py` on one MI355X: both engines run 17 + 24 iterations from the same start (max |difference| of the edge",
             "iterate and of the dual below), then to tol = 1e-4 (stopping iterations; the last column but one is the wall-clock rate of that",
             "run, variant with the norms, host round trips included), then a 2000-iteration (n > 6144: 500) asynchronous call is timed with",
