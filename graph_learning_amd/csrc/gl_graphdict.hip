@@ -33,6 +33,12 @@
 #ifndef GD_UPD_EXP
 #define GD_UPD_EXP 0  // tools/build_variant_gd.sh: ablations of k_gd_update2 (timing only)
 #endif
+#ifndef GD_GC_EXP
+#define GD_GC_EXP 0  // tools/build_variant_gd.sh: ablations of k_gd_grad_c (timing only): 1 = x_j always from the strip's first two columns, 2 = the weights, 3 = both
+#endif
+#ifndef GD_XD32_DEFAULT
+#define GD_XD32_DEFAULT 4  // k_gd_grad_c<float, 8, 2>: columns of x_j in flight (GRAPHLEARN_AMD_GD_XD = 2 | 4 overrides; fp64: 2)
+#endif
 
 namespace {
 
@@ -66,7 +72,13 @@ __device__ __forceinline__ void gd_sqdiff2<float>(const float a0, const float a1
     s0 = q.x, s1 = q.y;
 }
 
-template <typename T, int KP, int RC>
+// XD: columns of x_j in flight -- 2: one operand set ahead, together with the weights; 4: the x_j of three columns ahead.
+// A column's accumulation is ~0.1-0.3 us of a SIMD that 4-7 waves share, and X' (16 / 32 MB) does not fit an XCD's L2: with one
+// column of lead the loads are waited for.  Measured at K = 8, n = 1024, T = 4096, same GPU (tools/gd_gradc_ab.sh): fp32
+// 0.435-0.447 -> 0.405-0.412 ms although the 16 registers cost two waves of occupancy (7 -> 5); fp64 (4 waves either way)
+// 0.728 -> 0.743: there the loads are bandwidth, not latency -- without them (-DGD_GC_EXP=1) the kernel takes 0.59 ms in fp64,
+// 0.365 in fp32.  Same sums in the same order for every XD.
+template <typename T, int KP, int RC, int XD = 2>
 __global__ __launch_bounds__(64) void k_gd_grad_c(const T *__restrict__ XT, const T *__restrict__ WS,
                                                   double *__restrict__ SC, int n, int n_pad, int Tp, int NG,
                                                   const double *__restrict__ done) {
@@ -97,14 +109,16 @@ __global__ __launch_bounds__(64) void k_gd_grad_c(const T *__restrict__ XT, cons
         T wA[RC][KP], xjA[GD_SPL], wB[RC][KP], xjB[GD_SPL];
         auto request = [&](int j, T (&w)[RC][KP], T (&xj)[GD_SPL]) {
             const int jc = j < n ? j : n - 1;
+            const int jf = i0 + 1 + (jc & 1) < n ? i0 + 1 + (jc & 1) : n - 1;  // (ablations: rows / columns inside the matrices)
+            const int jw = (GD_GC_EXP & 2) ? jf : jc, jx = (GD_GC_EXP & 1) ? jf : jc;
 #pragma unroll
             for (int a = 0; a < RC; ++a) {
-                const T *__restrict__ wp = WS + ((int64_t)(i0 + a) * n_pad + jc) * KP;  // wave-uniform
+                const T *__restrict__ wp = WS + ((int64_t)(i0 + a) * n_pad + jw) * KP;  // wave-uniform
 #pragma unroll
                 for (int k = 0; k < KP; ++k) w[a][k] = wp[k];
             }
 #pragma unroll
-            for (int q = 0; q < GD_SPL; ++q) xj[q] = XT[(int64_t)jc * Tp + t0 + 64 * q];
+            for (int q = 0; q < GD_SPL; ++q) xj[q] = XT[(int64_t)jx * Tp + t0 + 64 * q];
         };
         auto accumulate = [&](const T (&w)[RC][KP], const T (&xj)[GD_SPL]) {
             static_assert(GD_SPL % 2 == 0, "samples per lane are taken in pairs");
@@ -121,6 +135,71 @@ __global__ __launch_bounds__(64) void k_gd_grad_c(const T *__restrict__ XT, cons
                 }
         };
         int j = i0 + 1;
+        if constexpr (XD == 4) {
+            // x_j three columns ahead in four rotating sets, the weights one column ahead as below (scalar cache)
+            T xq[4][GD_SPL];
+            auto request_w = [&](int jj, T (&w)[RC][KP]) {
+                const int jc = jj < n ? jj : n - 1;
+#pragma unroll
+                for (int a = 0; a < RC; ++a) {
+                    const T *__restrict__ wp = WS + ((int64_t)(i0 + a) * n_pad + jc) * KP;  // wave-uniform
+#pragma unroll
+                    for (int k = 0; k < KP; ++k) w[a][k] = wp[k];
+                }
+            };
+            auto request_x = [&](int jj, T (&xj)[GD_SPL]) {
+                const int jc = jj < n ? jj : n - 1;
+#pragma unroll
+                for (int q = 0; q < GD_SPL; ++q) xj[q] = XT[(int64_t)jc * Tp + t0 + 64 * q];
+            };
+            request_x(j, xq[0]);
+            request_x(j + 1, xq[1]);
+            request_x(j + 2, xq[2]);
+            request_w(j, wA);
+            for (; j + 3 < n; j += 4) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): weights A are in
+                request_w(j + 1, wB);
+                request_x(j + 3, xq[3]);
+                __builtin_amdgcn_sched_barrier(0);
+                accumulate(wA, xq[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                request_w(j + 2, wA);
+                request_x(j + 4, xq[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                accumulate(wB, xq[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                request_w(j + 3, wB);
+                request_x(j + 5, xq[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                accumulate(wA, xq[2]);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                request_w(j + 4, wA);
+                request_x(j + 6, xq[2]);
+                __builtin_amdgcn_sched_barrier(0);
+                accumulate(wB, xq[3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // up to three columns left: the x of j, j + 1, j + 2 in xq[0 .. 2], the weights of j in A
+            if (j < n) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                request_w(j + 1, wB);
+                accumulate(wA, xq[0]);
+            }
+            if (j + 1 < n) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                request_w(j + 2, wA);
+                accumulate(wB, xq[1]);
+            }
+            if (j + 2 < n) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                accumulate(wA, xq[2]);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // (nothing scalar pending when the next strip's sets are requested)
+            continue;
+        }
         request(j, wA, xjA);
         for (; j + 1 < n; j += 2) {
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): set A is in
@@ -896,12 +975,15 @@ int gd_launch_grad_c(gl_graphdict *s) {
     const GdDev &P = s->dev;
     dim3 grid((unsigned)(P.Tp / GD_SB), (unsigned)P.NG);
     hipStream_t st = s->ctx->stream;
+    static const int xd_env = getenv("GRAPHLEARN_AMD_GD_XD") ? atoi(getenv("GRAPHLEARN_AMD_GD_XD")) : -1;
     if (s->f32) {  // (WSf is kept by the weight update)
+        const int xd = xd_env >= 0 ? xd_env : GD_XD32_DEFAULT;
         switch (P.KP) {
             case 4: k_gd_grad_c<float, 4, 2><<<grid, 64, 0, st>>>(s->XTf, s->WSf, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5); break;
             case 8:
                 if (s->rc32 == 4) k_gd_grad_c<float, 8, 4><<<grid, 64, 0, st>>>(s->XTf, s->WSf, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5);
                 else if (s->rc32 == 3) k_gd_grad_c<float, 8, 3><<<grid, 64, 0, st>>>(s->XTf, s->WSf, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5);
+                else if (xd == 4) k_gd_grad_c<float, 8, 2, 4><<<grid, 64, 0, st>>>(s->XTf, s->WSf, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5);
                 else k_gd_grad_c<float, 8, 2><<<grid, 64, 0, st>>>(s->XTf, s->WSf, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5);
                 break;
             default: k_gd_grad_c<float, 16, 1><<<grid, 64, 0, st>>>(s->XTf, s->WSf, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5); break;
@@ -911,7 +993,10 @@ int gd_launch_grad_c(gl_graphdict *s) {
     }
     switch (P.KP) {
         case 4: k_gd_grad_c<double, 4, 2><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5); break;
-        case 8: k_gd_grad_c<double, 8, 2><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5); break;
+        case 8:
+            if (xd_env == 4) k_gd_grad_c<double, 8, 2, 4><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5);
+            else k_gd_grad_c<double, 8, 2><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5);
+            break;
         default: k_gd_grad_c<double, 16, 1><<<grid, 64, 0, st>>>(P.XT, P.WS, P.SC, P.n, P.n_pad, P.Tp, P.NG, P.stat + 5); break;
     }
     GL_HIP(s->ctx, hipGetLastError());

@@ -9,6 +9,8 @@ for r in csv.DictReader(open(sys.argv[1])):
 # the same kernels at the end of round 3 (VERDICT r03 "weak" 10 and this round's first profile, gpurun_out/r04m: us per launch)
 before = {"k_gd_update2<8>": 71.8, "k_gd_dual_update<8>": 46.4, "k_gd_m<8>": 35.2, "k_gd_finish3<8>": 32.8, "k_gd_reduce2": 28.5,
           "k_gd_to_f32": 33.0, "k_gd_coef_commit": 5.6, "k_gd_coef_stat": 4.0, "k_gd_grad_c<float, 8, 2>": 467.0, "k_gd_grad_w<float, 8, 8>": 404.0}
+if "k_gd_grad_c<float, 8, 2, 4>" in rows:  # (the x_j of three columns ahead: the same kernel as far as this table goes)
+    before["k_gd_grad_c<float, 8, 2, 4>"] = before.pop("k_gd_grad_c<float, 8, 2>")
 if "k_gd_grad_c<float, 8, 3>" in rows:  # (round 4's last change: strips of three rows; the same kernel as far as this table goes)
     before["k_gd_grad_c<float, 8, 3>"] = before.pop("k_gd_grad_c<float, 8, 2>")
 out = ["# GraphDictLog K = 8, n = 1024, T = 4096, fp32 contractions: the kernels of a step", "",
