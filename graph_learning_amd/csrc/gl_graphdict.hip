@@ -975,7 +975,7 @@ int gd_launch_grad_c(gl_graphdict *s) {
     const GdDev &P = s->dev;
     dim3 grid((unsigned)(P.Tp / GD_SB), (unsigned)P.NG);
     hipStream_t st = s->ctx->stream;
-    static const int xd_env = getenv("GRAPHLEARN_AMD_GD_XD") ? atoi(getenv("GRAPHLEARN_AMD_GD_XD")) : -1;
+    const int xd_env = getenv("GRAPHLEARN_AMD_GD_XD") ? atoi(getenv("GRAPHLEARN_AMD_GD_XD")) : -1;  // (read per launch: a test switches it)
     if (s->f32) {  // (WSf is kept by the weight update)
         const int xd = xd_env >= 0 ? xd_env : GD_XD32_DEFAULT;
         switch (P.KP) {

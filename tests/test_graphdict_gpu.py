@@ -305,3 +305,26 @@ def test_fp32_contractions_mid_size_against_oracle(engine):
         print(f"[fp32 GraphDictLog, n=48 T=256 K=4, {steps} steps] rel-to-max errors C {errs[0]:.1e} W {errs[1]:.1e} dual {errs[2]:.1e}")
         assert max(errs) < 5e-6, (steps, errs)   # observed <= 2e-7
         assert np.isfinite(m.history_.to_numpy()[:steps]).all()
+
+
+@pytest.mark.parametrize("n,t", [(37, 300), (70, 520)])
+def test_fp32_coefficient_gradient_lead_of_three_columns_is_the_same_sum(engine, monkeypatch, n, t):
+    """K = 8 in fp32: k_gd_grad_c keeps the x_j of three columns ahead in flight (four rotating operand sets, round 4) instead of
+    one.  The products and the order of their sums are those of the two-set loop, so three steps of either must leave the SAME
+    bits -- on lattices whose strips end after every possible number of left-over columns (n - i0 - 1 mod 4 takes every value).
+    Against the fp64 oracle (base_model.py:375, :447) both stay within the fp32 form's short-horizon tolerance."""
+    if engine != "launch":
+        pytest.skip("fp32 is a property of the launch form")
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((t, n)) * 0.5
+    kw = dict(n_atoms=8, l1_w=0.01, l1_c=0.01, step=0.5, tol=0.0, random_state=5, max_iter=3)
+    out = {}
+    for xd in ("2", "4"):
+        monkeypatch.setenv("GRAPHLEARN_AMD_GD_XD", xd)
+        m = GraphDictLog(**kw, compute_dtype="float32").fit(x)
+        out[xd] = (m.coefficients_.copy(), m.weights_.copy(), m.dual_.copy())
+    for a, b in zip(out["2"], out["4"]):
+        assert np.array_equal(a, b)
+    o = GraphDictLogOracle(**kw).fit(x)
+    errs = (rel_to_max(out["4"][0], o.coefficients_), rel_to_max(out["4"][1], o.weights_), rel_to_max(out["4"][2], o.dual_))
+    assert max(errs) < 5e-6, errs
