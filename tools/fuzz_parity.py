@@ -104,19 +104,27 @@ while time.time() < t_end:
             fail(kind, desc, f"max diff {np.abs(z - zr).max():.2e}")
     else:
         n, t = int(rng.choice([3, 7, 12, 20, 33, 70])), int(rng.choice([5, 23, 64, 130]))
-        k, w = int(rng.choice([1, 2, 3, 5, 9])), int(rng.choice([1, 1, 2, 5]))
+        k, w = int(rng.choice([1, 2, 3, 5, 8, 9])), int(rng.choice([1, 1, 2, 5]))
         x = rng.standard_normal((t, n)) * 0.5
         eng = rng.choice(["launch", "small"])
         os.environ["GRAPHLEARN_AMD_GD_ENGINE"] = eng
         kw = dict(n_atoms=k, window_size=w, l1_w=float(rng.choice([0, 0.01])), l1_c=float(rng.choice([0, 0.002])),
                   ortho_w=float(rng.choice([0, 0.05])), log_c=float(rng.choice([0, 0.02])), l1_diff_c=float(rng.choice([0, 0.001])),
                   step=float(rng.choice([0.2, 0.5, 1.0])), max_iter=int(rng.integers(1, 7)), tol=0.0, random_state=int(rng.integers(1 << 30)))
+        # the fp32 form of the two contractions (launch engine only; K = 5 .. 8 runs k_gd_grad_c<float, 8, 2, 4>): short horizon,
+        # against the fp64 oracle relative to the state's largest entry (tests/test_graphdict_gpu.py: 5e-6, observed <= 2e-7)
+        f32 = eng == "launch" and rng.uniform() < 0.5
         o = GraphDictLogOracle(**kw).fit(x)
-        m = GraphDictLog(**kw).fit(x)
+        m = GraphDictLog(**kw, **({"compute_dtype": "float32"} if f32 else {})).fit(x)
         os.environ.pop("GRAPHLEARN_AMD_GD_ENGINE", None)
-        desc = f"n={n} T={t} engine={eng} {kw}"
+        desc = f"n={n} T={t} engine={eng} fp32={f32} {kw}"
         for name in ("coefficients_", "weights_", "dual_"):
-            if not np.allclose(getattr(m, name), getattr(o, name), rtol=1e-9, atol=1e-9):
-                fail(kind, desc, f"{name} max diff {np.abs(getattr(m, name) - getattr(o, name)).max():.2e}")
+            got, want = getattr(m, name), getattr(o, name)
+            if f32:
+                err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-300)
+                if not err < 2e-5:
+                    fail(kind, desc, f"{name} rel-to-max {err:.2e}")
+            elif not np.allclose(got, want, rtol=1e-9, atol=1e-9):
+                fail(kind, desc, f"{name} max diff {np.abs(got - want).max():.2e}")
     counts[kind] += 1
 print("fuzz ok:", counts, flush=True)
